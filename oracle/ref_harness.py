@@ -1,0 +1,189 @@
+"""Harness around the UNMODIFIED reference (imported from /root/reference).
+
+TEST INFRASTRUCTURE; works only where /root/reference exists (the build
+container).  Nothing from the reference is copied: the modules are imported
+in place, and the only patches are module attributes --
+  * ``<module>.random`` <- an ``AgentRandom`` (pathfit/rng.py) re-keyed per
+    agent-call, because the reference's single sequential global stream cannot
+    be reproduced by any agent-parallel engine;
+  * ``numpy.random.choice`` <- the same algorithm numpy uses (cumsum, divide by
+    last, searchsorted right) on one ``random()`` draw of the agent's stream
+    (MAACO.py:259 is the reference's only numpy-RNG call site);
+  * ``heapq`` in astar/MPA <- a counting proxy (pops/pushes), same functions.
+"""
+import contextlib
+import io
+import math
+import os
+import sys
+
+import numpy as np
+
+REF = "/root/reference"
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(_HERE), "maaco-path-planing_amd"))
+from pathfit import rng as pfrng  # noqa: E402
+
+
+def available():
+    return os.path.isdir(REF) and os.path.exists(os.path.join(REF, "astar.py"))
+
+
+_mods = {}
+
+
+def mods():
+    """Import the reference once (headless matplotlib, no bytecode writes)."""
+    if not _mods:
+        os.environ.setdefault("MPLBACKEND", "Agg")
+        sys.dont_write_bytecode = True
+        if REF not in sys.path:
+            sys.path.insert(0, REF)
+        import env, helper, astar, ga_solver, pso, MAACO, MPA  # noqa: E401
+        _mods.update(env=env, helper=helper, astar=astar, ga_solver=ga_solver, pso=pso, MAACO=MAACO, MPA=MPA)
+    return _mods
+
+
+@contextlib.contextmanager
+def quiet():
+    with contextlib.redirect_stdout(io.StringIO()):
+        yield
+
+
+class CountingHeapq:
+    def __init__(self):
+        import heapq
+        self._h = heapq
+        self.pops = self.pushes = self.heapifies = self.max_open = 0
+
+    def reset(self):
+        self.pops = self.pushes = self.heapifies = self.max_open = 0
+
+    def heappush(self, h, x):
+        self.pushes += 1
+        self._h.heappush(h, x)
+        self.max_open = max(self.max_open, len(h))
+
+    def heappop(self, h):
+        self.pops += 1
+        return self._h.heappop(h)
+
+    def heapify(self, h):
+        self.heapifies += 1
+        self._h.heapify(h)
+
+
+RNG = pfrng.AgentRandom(0, 0, 0, 0)   # the one object installed as `random` in the reference modules
+HQ = CountingHeapq()
+_installed = False
+
+
+def _np_choice_shim(a, size=None, replace=True, p=None):
+    assert size is None and p is not None
+    p = np.asarray(p, dtype=np.float64)
+    cdf = p.cumsum()
+    cdf /= cdf[-1]
+    u = RNG.random()
+    return int(cdf.searchsorted(u, side="right"))
+
+
+def install():
+    global _installed
+    m = mods()
+    if not _installed:
+        for name in ("MAACO", "MPA", "pso", "ga_solver"):
+            m[name].random = RNG
+        m["astar"].heapq = HQ
+        m["MPA"].heapq = HQ
+        np.random.choice = _np_choice_shim
+        _installed = True
+    return m
+
+
+def to_cells(path, C):
+    return np.array([int(r) * C + int(c) for r, c in path], np.int32)
+
+
+def to_rc(cells, C):
+    return [(int(x) // C, int(x) % C) for x in cells]
+
+
+def mark_grid(grid01, start, target):
+    g = np.array(grid01, dtype=int).copy()
+    g[g > 1] = 0
+    g[start] = 2
+    g[target] = 3
+    return g
+
+
+# ---------------- connectors ----------------
+class RefAStar:
+    """astar.AStarSolver with pop/push counters."""
+
+    def __init__(self, grid, **kw):
+        m = install()
+        with quiet():
+            self.s = m["astar"].AStarSolver(np.array(grid), **kw)
+        self.C = self.s.cols
+
+    def solve(self, start_rc, target_rc, avoid_rc=None):
+        HQ.reset()
+        with quiet():
+            res = self.s.solve(tuple(start_rc), tuple(target_rc), set(avoid_rc) if avoid_rc else None)
+        self.s.convergence_curve.clear()
+        return to_cells(res[0], self.C), res, dict(pops=HQ.pops, pushes=HQ.pushes, heapifies=HQ.heapifies,
+                                                   max_open=HQ.max_open)
+
+
+def make_mpa(grid, num_predators=1, num_iterations=10, **kw):
+    m = install()
+    RNG.rekey(0, 0, 0, 0)
+    with quiet():
+        return m["MPA"].MPA(np.array(grid), num_predators, num_iterations, **kw)
+
+
+def mpa_astar(mpa, start_rc, target_rc, avoid_rc=None):
+    HQ.reset()
+    path, cost = mpa._a_star(tuple(start_rc), tuple(target_rc), set(avoid_rc) if avoid_rc is not None else None)
+    return to_cells(path, mpa.cols), cost, dict(pops=HQ.pops, pushes=HQ.pushes, max_open=HQ.max_open)
+
+
+def levy_sigma(beta):
+    """MPA.py:251-253 (host-side constant)."""
+    num = math.gamma(1 + beta) * math.sin(math.pi * beta / 2)
+    den = math.gamma((1 + beta) / 2) * beta * (2 ** ((beta - 1) / 2))
+    return (num / den) ** (1 / beta) if den > 1e-9 else 1.0
+
+
+def mpa_rebuild(mpa, path_rc, elite_rc, idx, is_levy, scale, seed, it, agent):
+    RNG.rekey(seed, pfrng.DOM_MPA, it, agent)
+    res = mpa._reconstruct_path_segment(list(path_rc), list(elite_rc), idx, is_levy, scale)
+    return to_cells(res[0], mpa.cols), res, RNG.draws
+
+
+# ---------------- GA / PSO ----------------
+def make_ga(grid, W=5, **kw):
+    m = install()
+    with quiet():
+        return m["ga_solver"].GASolver(np.array(grid), num_generations=1, population_size=2,
+                                       num_waypoints_per_chromosome=W, mutation_rate=0.1, crossover_rate=0.8, **kw)
+
+
+def make_pso(grid, W=5, n=2, iters=1, w=0.7, c1=1.5, c2=1.5, **kw):
+    m = install()
+    with quiet():
+        return m["pso"].PSOSolver(np.array(grid), num_iterations=iters, num_particles=n,
+                                  num_waypoints_per_particle=W, w=w, c1=c1, c2=c2, **kw)
+
+
+# ---------------- MAACO ----------------
+def make_maaco(grid, **params):
+    m = install()
+    with quiet():
+        return m["MAACO"].MAACO(np.array(grid), **params)
+
+
+def maaco_walk(ma, it, seed, ant):
+    RNG.rekey(seed, pfrng.DOM_MAACO, it, ant)
+    path, length, turns = ma._construct_ant_solution_maaco(ant, it)
+    return to_cells(path, ma.cols), length, turns, RNG.draws
