@@ -1,0 +1,197 @@
+/*
+ * pathfit.h -- C-ABI of the MI355X population-fitness engine (libpathfit.so).
+ *
+ * The reference (dvnam1605/MAACO-path-planing) has NO plugin / operator / FFI
+ * interface: its boundary is the Python method surface of the solver classes
+ * (SURVEY.md section 8b).  Each entry point below therefore names the
+ * reference *method* whose per-agent inner loop it replaces, batched over the
+ * population.  The Python facades in maaco-path-planing_amd/pathfit/ keep the
+ * reference's class / constructor / solve() surface and call these through
+ * ctypes (binding shown in INTEGRATION.md).
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, scalars; no C++/torch types.
+ *   - every function returns 0 on success, <0 on error (pf_last_error()).
+ *     Per-agent infeasibility is DATA (status arrays), never an error.
+ *   - pointers named d_* are DEVICE pointers (pf_dev_alloc or any HIP
+ *     allocation on the handle's device, e.g. torch tensor .data_ptr());
+ *     all others are host pointers.
+ *   - a cell is r*C + c (int32).  Paths are "strided CSR": agent a's cells are
+ *     d_cells[a*path_cap .. a*path_cap + d_len[a]); d_len[a]==0 is the
+ *     reference's [] (infeasible).
+ *   - calls are synchronous at the ABI (they return after the handle's stream
+ *     has drained) unless the name ends in _async.
+ *   - one host thread per handle.
+ *   - status codes: PF_ST_OK 0, PF_ST_INFEASIBLE 1 (reference returned []),
+ *     PF_ST_STEP_CAP 2 (reference's 3RC / 2RC pop cap hit, also []),
+ *     PF_ST_OVERFLOW 3 (engine scratch or path_cap too small: result not
+ *     produced; never silently truncated), PF_ST_KEPT 4 (MPA: reference fell
+ *     back to the unmodified path).
+ */
+#ifndef PATHFIT_H
+#define PATHFIT_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PF_ST_OK 0
+#define PF_ST_INFEASIBLE 1
+#define PF_ST_STEP_CAP 2
+#define PF_ST_OVERFLOW 3
+#define PF_ST_KEPT 4
+
+#define PF_ASTAR_REF 0 /* AStarSolver.solve semantics, astar.py:33-101 */
+#define PF_ASTAR_MPA 1 /* MPA._a_star semantics, MPA.py:106-151 */
+
+typedef struct pf_handle pf_handle;
+
+/* scoring weights: helper.calculate_path_stats (helper.py:98-113) when
+ * variant==0, MPA._calculate_path_stats (MPA.py:215-229, safety==0) when 1 */
+typedef struct {
+  int32_t variant;
+  int32_t restrict_policy; /* restrict_diagonal_near_obstacle_policy */
+  double w_turn, w_safe, min_safe, diag_pen;
+} pf_score_params;
+
+/* MAACO constructor scalars, MAACO.py:11-14 */
+typedef struct {
+  double alpha, beta, rho, Q, a_turn_coef, wh_max, wh_min, k_h_adaptive, q0_initial, C0_initial_pheromone;
+  int32_t num_iterations;
+  int32_t start, target; /* cells */
+} pf_maaco_params;
+
+/* MPA scalars, MPA.py:10-18 (+ sigma = the Mantegna constant of :251-253,
+ * computed by the caller with math.gamma) */
+typedef struct {
+  double P_const, levy_beta, levy_sigma, FADs_rate;
+  int32_t num_predators; /* global population size (for the i < N//2 split, MPA.py:351) */
+  int32_t start, target;
+  int32_t allow_diag, restrict_corner;
+} pf_mpa_params;
+
+/* per-launch counters (roofline numerators) */
+typedef struct {
+  int64_t pops, pushes, nbr_examined, path_cells, steps, candidates, stale_pops, overflow_agents;
+} pf_counters;
+
+/* ---- lifecycle ---------------------------------------------------- */
+const char* pf_version(void);
+int pf_device_count(void);
+/* grid: R*C bytes with the reference's cell values (env.py:4-7: 1 = obstacle,
+ * anything else free).  Replaces np.array(grid, dtype=int) + obstacle_nodes
+ * (helper.py:121-125).  device: HIP ordinal. */
+int pf_create(const uint8_t* grid, int32_t R, int32_t C, int32_t device, pf_handle** out);
+void pf_destroy(pf_handle* h);
+const char* pf_last_error(pf_handle* h); /* h may be NULL for create errors */
+/* the handle's HIP stream (hipStream_t) so callers can order their own work */
+void* pf_stream(pf_handle* h);
+int pf_sync(pf_handle* h);
+
+/* ---- device memory plumbing --------------------------------------- */
+int pf_dev_alloc(pf_handle* h, int64_t bytes, void** d_out);
+int pf_dev_free(pf_handle* h, void* d_ptr);
+int pf_h2d(pf_handle* h, void* d_dst, const void* src, int64_t bytes);
+int pf_d2h(pf_handle* h, void* dst, const void* d_src, int64_t bytes);
+int pf_memset(pf_handle* h, void* d_dst, int32_t byte, int64_t bytes);
+/* counters of the most recent batch call */
+int pf_get_counters(pf_handle* h, pf_counters* out);
+/* timing of the most recent batch call's dominant kernel, measured with HIP
+ * events on the handle's stream (ms) */
+float pf_last_kernel_ms(pf_handle* h);
+
+/* ---- K2: A* connector batch ---------------------------------------- */
+/* Replaces AStarSolver.solve(start, target, nodes_to_avoid) (astar.py:33) or
+ * MPA._a_star(start, end, nodes_to_avoid) (MPA.py:106) for n independent
+ * queries.  Avoid sets are CSR (d_avoid_off int64[n+1], d_avoid_cells int32)
+ * or NULL.  d_counters: int64[n*4] {pops, pushes, max_open, nbr_examined} or NULL. */
+int pf_astar_batch(pf_handle* h, int32_t variant, int32_t allow_diag, int32_t restrict_corner, int32_t n,
+                   const int32_t* d_start, const int32_t* d_target, const int64_t* d_avoid_off,
+                   const int32_t* d_avoid_cells, int32_t path_cap, int32_t* d_cells, int32_t* d_len,
+                   int32_t* d_status, int64_t* d_counters);
+
+/* ---- K1: path scoring batch ---------------------------------------- */
+/* Replaces BasePathfinder._calculate_stats_for_path (helper.py:138) /
+ * MPA._calculate_path_stats (MPA.py:215).  d_stats: double[n*5] =
+ * {length, turns, safety, diag, fitness}; empty path -> {inf,0,0,0,inf}. */
+int pf_score_batch(pf_handle* h, const pf_score_params* sp, int32_t n, int32_t path_cap,
+                   const int32_t* d_cells, const int32_t* d_len, double* d_stats);
+
+/* ---- K3: chained waypoint decode (+ score) ------------------------- */
+/* Replaces GASolver._reconstruct_path_from_chromosome (ga_solver.py:58) when
+ * d_wp_cells != NULL (int32[n*W]) or PSOSolver._reconstruct_path_from_position
+ * (pso.py:56; round-half-even + clamp) when d_wp_pos != NULL (double[n*W*2]),
+ * followed by _calculate_stats_for_path when sp != NULL. */
+int pf_decode_batch(pf_handle* h, int32_t allow_diag, int32_t restrict_corner, int32_t n, int32_t W,
+                    const int32_t* d_wp_cells, const double* d_wp_pos, int32_t start, int32_t target,
+                    int32_t path_cap, int32_t* d_cells, int32_t* d_len, int32_t* d_status,
+                    const pf_score_params* sp, double* d_stats);
+
+/* ---- K6: PSO velocity/position update ------------------------------ */
+/* Replaces the inner loop pso.py:183-203 for particles agent0..agent0+n with
+ * the sweep-start gbest (synchronous PSO).  In place on
+ * d_pos/d_vel (double[n*W*2]).  Stream (seed, DOM_PSO=3, iter, agent). */
+int pf_pso_update(pf_handle* h, int32_t n, int32_t W, double w, double c1, double c2, double max_vel,
+                  double* d_pos, double* d_vel, const double* d_pbest, const double* d_gbest, uint64_t seed,
+                  uint64_t iter, uint64_t agent0);
+/* pbest bookkeeping pso.py:216-220: where stats fitness < pbest_fit (strict),
+ * copy pos -> pbest and fitness -> pbest_fit.  d_improved int32[n] out. */
+int pf_pso_pbest(pf_handle* h, int32_t n, int32_t W, const double* d_pos, const double* d_stats,
+                 const int32_t* d_len, double* d_pbest, double* d_pbest_fit, int32_t* d_improved);
+
+/* ---- K4/K5: MAACO --------------------------------------------------- */
+/* Replaces MAACO.__init__ state (pheromone_matrix :58-84, dist table :86-91)
+ * plus the per-cell eta'^beta tables derived from :197-210 (host libm, so
+ * bit-identical to the reference's math.exp / pow). */
+int pf_maaco_setup(pf_handle* h, const pf_maaco_params* p);
+/* Replaces MAACO._construct_ant_solution_maaco (MAACO.py:278) for ants
+ * ant0..ant0+n of iteration iter.  d_plen double[n] (inf if failed),
+ * d_turns int32[n] (-1 if failed).  Stream (seed, DOM_MAACO=1, iter, ant). */
+int pf_maaco_walk_batch(pf_handle* h, int32_t iter, uint64_t seed, int32_t ant0, int32_t n, int32_t path_cap,
+                        int32_t* d_cells, int32_t* d_len, double* d_plen, int32_t* d_turns, int32_t* d_status);
+/* Replaces MAACO._update_pheromone_trails_maaco (MAACO.py:304) in three
+ * ordered steps so that a population sharded over GPUs can fold its deposits
+ * in global ant order: evaporate (:305), deposit (:306-311, sequential in ant
+ * order per cell -- bit-exact, no float atomics), clip (:312-332). */
+int pf_maaco_evaporate(pf_handle* h);
+int pf_maaco_deposit(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_cells, const int32_t* d_len,
+                     const double* d_plen);
+int pf_maaco_clip(pf_handle* h, double best_len_overall);
+/* pheromone_matrix attribute round trip (double[R*C]) */
+int pf_maaco_get_pheromone(pf_handle* h, double* tau);
+int pf_maaco_set_pheromone(pf_handle* h, const double* tau);
+void* pf_maaco_tau_dev(pf_handle* h); /* device pointer, for collectives */
+/* sequential best-of-iteration scan MAACO.py:343-349 over host arrays;
+ * inout: best_len/best_turns/best_idx (idx -1 = none yet) */
+int pf_maaco_best_scan(int32_t n, const double* plen, const int32_t* turns, int32_t idx0, double* best_len,
+                       double* best_turns, int32_t* best_idx);
+
+/* ---- K7 + K2b + K1: MPA --------------------------------------------- */
+int pf_mpa_setup(pf_handle* h, const pf_mpa_params* p, const pf_score_params* sp);
+/* One phase sweep MPA.py:339-377 for predators i = agent0..agent0+n (global
+ * indices in the fitness-sorted order): draws start idx + gate from the
+ * predator's stream (seed, DOM_MPA=2, iter, i), then
+ * MPA._reconstruct_path_segment (:284-318) or the phase's no-move branch.
+ * Population = strided paths d_pop_cells/d_pop_len indexed through d_order
+ * (int32[N], sorted position -> storage slot); d_elite_cells/elite_len = the
+ * sweep-start elite path.  phase in {1,2,3}; CF per MPA.py:336.
+ * Outputs candidate paths (strided, same cap) + stats double[n*5]. */
+int pf_mpa_phase_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uint64_t seed, int32_t agent0,
+                       int32_t n, int32_t path_cap, const int32_t* d_pop_cells, const int32_t* d_pop_len,
+                       const double* d_pop_stats, const int32_t* d_order, const int32_t* d_elite_cells,
+                       int32_t elite_len, int32_t* d_out_cells, int32_t* d_out_len, double* d_out_stats,
+                       int32_t* d_status);
+/* FADs sweep MPA.py:387-410 on the post-memory population (in place):
+ * stream (seed, DOM_MPA_FADS=5, iter, i). */
+int pf_mpa_fads_batch(pf_handle* h, double CF, int32_t iter, uint64_t seed, int32_t agent0, int32_t n,
+                      int32_t path_cap, int32_t* d_pop_cells, int32_t* d_pop_len, double* d_pop_stats,
+                      int32_t* d_status);
+/* memory step MPA.py:381-384: pop[i] <- cand[i] where cand fitness < pop fitness */
+int pf_mpa_memory(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_order, int32_t agent0,
+                  const int32_t* d_cand_cells, const int32_t* d_cand_len, const double* d_cand_stats,
+                  int32_t* d_pop_cells, int32_t* d_pop_len, double* d_pop_stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PATHFIT_H */

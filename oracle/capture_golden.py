@@ -1,0 +1,365 @@
+"""Capture golden vectors from the UNMODIFIED reference -> tests/golden/*.npz.
+
+Run in the build container only:  python oracle/capture_golden.py
+(needs /root/reference; the GPU box never has it).  The fixtures hold data only
+-- inputs and the reference's outputs -- never reference source text.  Every
+file records the interpreter/numpy versions that produced it.
+"""
+import os
+import platform
+import random
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "maaco-path-planing_amd"))
+import ref_harness as rh  # noqa: E402
+from pathfit import rng as pfrng  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+META = dict(python=platform.python_version(), numpy=np.__version__)
+
+MAIN_W = dict(turn_penalty_factor=0.3, safety_penalty_factor=0.8, min_safe_distance=1.8,
+              diagonal_obstacle_penalty_value=100.0)            # main.py:21-24
+DEF_W = dict(turn_penalty_factor=0.1, safety_penalty_factor=0.05, min_safe_distance=1.5,
+             diagonal_obstacle_penalty_value=1000.0)            # astar.py:12-15
+
+
+def csr(list_of_arrays, dtype=np.int32):
+    offs = np.zeros(len(list_of_arrays) + 1, np.int64)
+    for i, a in enumerate(list_of_arrays):
+        offs[i + 1] = offs[i] + len(a)
+    flat = np.concatenate([np.asarray(a, dtype) for a in list_of_arrays]) if offs[-1] else np.zeros(0, dtype)
+    return offs, flat.astype(dtype)
+
+
+def grids():
+    env = rh.mods()["env"]
+    out = {}
+    out["fig7"] = rh.mark_grid(np.array(env.grid_fig7_layout_data), (0, 0), (19, 19))      # main.py:27-32
+    out["fig13"] = np.array(env.grid_map_fig13_base_data)
+    out["img1"] = np.array(env.grid_map_from_image_data)
+    out["img2"] = np.array(env.grid_map_from_image_data2)
+    out["img3"] = np.array(env.grid_map_from_image_data3)
+    g256 = np.array(env.grid_map_from_image_data5)
+    out["g256"] = g256
+    crop = g256[:128, :128].copy()
+    crop[crop > 1] = 0
+    crop[0, 0] = 2
+    free = np.argwhere(crop != 1)
+    crop[tuple(free[-1])] = 3
+    out["g128crop"] = crop
+    return out
+
+
+def st_of(g):
+    return tuple(int(x) for x in np.argwhere(g == 2)[0]), tuple(int(x) for x in np.argwhere(g == 3)[0])
+
+
+def cap_grids(G):
+    d = {}
+    for k, g in G.items():
+        d[k + "_shape"] = np.array(g.shape)
+        d[k + "_bits"] = np.packbits((g == 1).astype(np.uint8))
+        s, t = st_of(g)
+        d[k + "_st"] = np.array([s[0], s[1], t[0], t[1]])
+    np.savez_compressed(os.path.join(OUT, "grids.npz"), **d, **{"meta_" + k: v for k, v in META.items()})
+
+
+def cap_astar(G):
+    rnd = random.Random(1234)
+    rows = []
+    plan = [("fig7", 60), ("fig13", 40), ("img1", 40), ("img2", 40), ("img3", 40), ("g128crop", 14), ("g256", 4)]
+    for name, n in plan:
+        g = G[name]
+        R, C = g.shape
+        ra = rh.RefAStar(g)
+        mpa = rh.make_mpa(g) if max(R, C) <= 20 else None
+        if mpa is None:
+            # building MPA runs a full A*; reuse one instance with 1 predator on big grids too
+            mpa = rh.make_mpa(g, num_predators=1)
+        free = [tuple(int(v) for v in x) for x in np.argwhere(g != 1)]
+        obst = [tuple(int(v) for v in x) for x in np.argwhere(g == 1)]
+        S, T = st_of(g)
+        for t in range(n):
+            s, e = rnd.choice(free), rnd.choice(free)
+            if max(R, C) > 20:
+                # keep big-grid searches affordable: nearby pairs, plus one long one
+                s = rnd.choice(free)
+                rad = 24 if R == 128 else 30
+                near = [f for f in free if abs(f[0] - s[0]) <= rad and abs(f[1] - s[1]) <= rad]
+                e = rnd.choice(near)
+                if t == 0:
+                    s, e = S, T
+            if t % 9 == 1:
+                e = s
+            if t % 13 == 2 and obst:
+                s = rnd.choice(obst)
+            if t % 17 == 3 and obst:
+                e = rnd.choice(obst)
+            avoid = None
+            if t % 3 != 0:
+                k = rnd.randint(0, max(1, len(free) // 12))
+                avoid = rnd.sample(free, k)
+                if t % 6 == 1:
+                    avoid.append(e)      # target inside the avoid set
+                if t % 6 == 2:
+                    avoid.append(s)
+            if t % 19 == 4:
+                # wall the target in with avoid cells -> exhausts the open list
+                avoid = [(e[0] + a, e[1] + b) for a in (-1, 0, 1) for b in (-1, 0, 1) if (a or b)]
+                avoid = [a for a in avoid if 0 <= a[0] < R and 0 <= a[1] < C]
+            for variant in (0, 1):
+                if variant == 0:
+                    pc, _, cnt = ra.solve(s, e, avoid)
+                else:
+                    pc, _, cnt = rh.mpa_astar(mpa, s, e, avoid)
+                rows.append(dict(grid=name, variant=variant, start=s[0] * C + s[1], target=e[0] * C + e[1],
+                                 avoid=[a[0] * C + a[1] for a in avoid] if avoid is not None else [],
+                                 has_avoid=avoid is not None, path=pc, pops=cnt["pops"], pushes=cnt["pushes"]))
+    names = sorted(set(r["grid"] for r in rows))
+    ao, af = csr([r["avoid"] for r in rows])
+    po_, pf = csr([r["path"] for r in rows])
+    np.savez_compressed(
+        os.path.join(OUT, "astar_cases.npz"), grid_names=np.array(names),
+        grid_id=np.array([names.index(r["grid"]) for r in rows]), variant=np.array([r["variant"] for r in rows]),
+        start=np.array([r["start"] for r in rows]), target=np.array([r["target"] for r in rows]),
+        has_avoid=np.array([r["has_avoid"] for r in rows]), avoid_off=ao, avoid=af, path_off=po_, path=pf,
+        pops=np.array([r["pops"] for r in rows]), pushes=np.array([r["pushes"] for r in rows]),
+        **{"meta_" + k: v for k, v in META.items()})
+    print("astar cases", len(rows))
+
+
+def cap_decode(G):
+    rnd = random.Random(77)
+    rows = []
+    for name in ("fig7", "fig13", "img1", "img3", "g128crop"):
+        g = G[name]
+        R, C = g.shape
+        n = 40 if R <= 20 else 4
+        free = [tuple(int(v) for v in x) for x in np.argwhere(g != 1)]
+        for wname, Wt in (("main", MAIN_W), ("def", DEF_W)):
+            ga = rh.make_ga(g, W=5, **Wt)
+            ps = rh.make_pso(g, W=5, **Wt)
+            for t in range(n):
+                W = 5 if t % 8 else rnd.choice([1, 2, 3])
+                if R > 20:
+                    S, _ = st_of(g)
+                    near = [f for f in free if abs(f[0] - S[0]) <= 40 and abs(f[1] - S[1]) <= 40]
+                    chrom = [rnd.choice(near) for _ in range(W)]
+                else:
+                    chrom = [rnd.choice(free) if rnd.random() < 0.92 else (rnd.randint(0, R - 1), rnd.randint(0, C - 1))
+                             for _ in range(W)]
+                if R > 20:
+                    # on the 128 crop the goal is far: decode only up to the last waypoint by making it the target
+                    pass
+                with rh.quiet():
+                    p = ga._reconstruct_path_from_chromosome(chrom)
+                    stats = ga._calculate_stats_for_path(p)
+                rows.append(dict(grid=name, w=wname, kind=0, wp=np.array([c[0] * C + c[1] for c in chrom], np.float64),
+                                 path=rh.to_cells(p, C), stats=[stats[1], stats[2], stats[3], stats[4], stats[5]]))
+                if R <= 20:
+                    pos = [[rnd.uniform(-1.5, R + 0.5), rnd.uniform(-1.5, C + 0.5)] for _ in range(W)]
+                    if t % 5 == 0:
+                        pos[0] = [2.5, 3.5]
+                        pos[-1] = [0.5, 1.5]
+                    with rh.quiet():
+                        p = ps._reconstruct_path_from_position(pos)
+                        stats = ps._calculate_stats_for_path(p)
+                    rows.append(dict(grid=name, w=wname, kind=1, wp=np.array(pos, np.float64).ravel(),
+                                     path=rh.to_cells(p, C), stats=[stats[1], stats[2], stats[3], stats[4], stats[5]]))
+    # a hand-built corner-cutting path on fig7 to exercise the diagonal penalty (helper.py:82-96)
+    g = G["fig7"]
+    ga = rh.make_ga(g, W=5, **MAIN_W)
+    cut = [(0, 3), (1, 4), (2, 4), (3, 4), (4, 5), (5, 6)]     # (0,3)->(1,4) passes obstacle (0,4)
+    with rh.quiet():
+        stats = ga._calculate_stats_for_path(cut)
+    rows.append(dict(grid="fig7", w="main", kind=2, wp=np.zeros(0), path=rh.to_cells(cut, 20),
+                     stats=[stats[1], stats[2], stats[3], stats[4], stats[5]]))
+    names = sorted(set(r["grid"] for r in rows))
+    wo, wf = csr([r["wp"] for r in rows], np.float64)
+    po_, pf = csr([r["path"] for r in rows])
+    np.savez_compressed(
+        os.path.join(OUT, "decode_cases.npz"), grid_names=np.array(names),
+        grid_id=np.array([names.index(r["grid"]) for r in rows]), weights=np.array([r["w"] for r in rows]),
+        kind=np.array([r["kind"] for r in rows]), wp_off=wo, wp=wf, path_off=po_, path=pf,
+        stats=np.array([r["stats"] for r in rows], np.float64),
+        main_w=np.array([0.3, 0.8, 1.8, 100.0]), def_w=np.array([0.1, 0.05, 1.5, 1000.0]),
+        **{"meta_" + k: v for k, v in META.items()})
+    print("decode cases", len(rows), "feasible", sum(len(r["path"]) > 0 for r in rows))
+
+
+def cap_maaco(G):
+    d = {}
+    runs = []
+    base = dict(alpha=1.0, rho=0.1, Q=2.5, a_turn_coef=1.0, wh_max=0.9, wh_min=0.2, k_h_adaptive=0.9,
+                q0_initial=0.5, C0_initial_pheromone=0.1)       # main.py:34-38
+    plan = [("fig7", 7.0, 30, 4, 10), ("fig7", 2.0, 30, 4, 10), ("fig13", 7.0, 20, 3, 10), ("img2", 2.0, 20, 3, 50),
+            ("g256", 7.0, 8, 2, 100)]
+    for ri, (name, beta, n_ants, n_it, K) in enumerate(plan):
+        g = G[name]
+        R, C = g.shape
+        ma = rh.make_maaco(g, num_ants=n_ants, num_iterations=K, beta=beta, **base)
+        seed = 1000 + ri
+        d[f"r{ri}_tau0"] = ma.pheromone_matrix.copy()
+        paths, lens, turns, taus = [], [], [], []
+        best = float("inf")
+        for it in range(1, n_it + 1):
+            it_paths = []
+            for ant in range(n_ants):
+                pc, L, T, _ = rh.maaco_walk(ma, it, seed, ant)
+                paths.append(pc); lens.append(L); turns.append(T if T != float("inf") else -1)
+                it_paths.append((rh.to_rc(pc, C), L, T))
+                if L < best:
+                    best = L
+            ma.best_path_length_overall = best                    # MAACO.py:351-352 precedes :359
+            ma._update_pheromone_trails_maaco(it_paths, None)
+            if R <= 20:
+                taus.append(ma.pheromone_matrix.copy())
+        po_, pf = csr(paths)
+        d[f"r{ri}_path_off"], d[f"r{ri}_path"] = po_, pf
+        d[f"r{ri}_len"] = np.array(lens); d[f"r{ri}_turns"] = np.array(turns)
+        if taus:
+            d[f"r{ri}_tau"] = np.array(taus)
+        else:
+            d[f"r{ri}_tau_sum"] = np.array([ma.pheromone_matrix.sum(), ma.pheromone_matrix.max(), ma.pheromone_matrix.min()])
+            d[f"r{ri}_tau_last_rows"] = ma.pheromone_matrix[:4].copy()
+        runs.append((name, beta, n_ants, n_it, K, seed))
+        print("maaco run", ri, name, beta, "success", sum(np.isfinite(lens)), "/", len(lens))
+    d["runs_grid"] = np.array([r[0] for r in runs])
+    d["runs_num"] = np.array([[r[1], r[2], r[3], r[4], r[5]] for r in runs], np.float64)
+    d["base_params"] = np.array([base[k] for k in ("alpha", "rho", "Q", "a_turn_coef", "wh_max", "wh_min",
+                                                   "k_h_adaptive", "q0_initial", "C0_initial_pheromone")])
+    ma = rh.make_maaco(G["fig7"], num_ants=1, num_iterations=3, beta=7.0, **base)
+    for K in (3, 50, 100):
+        ma.num_iterations = K
+        d[f"q0_K{K}"] = np.array([ma._calculate_adaptive_q0(i) for i in range(1, K + 1)])
+    np.savez_compressed(os.path.join(OUT, "maaco_cases.npz"), **d, **{"meta_" + k: v for k, v in META.items()})
+
+
+def cap_mpa(G):
+    rnd = random.Random(4321)
+    rows = []
+    for name in ("fig7", "img1", "g128crop"):
+        g = G[name]
+        R, C = g.shape
+        for beta in (1.5, 2.0):
+            mpa = rh.make_mpa(g, levy_beta=beta)
+            S, T = st_of(g)
+            base = rh.to_cells(mpa.population[0]["path"], C)
+            if R <= 20:
+                mid = (R // 2, 0) if g[R // 2, 0] != 1 else tuple(int(v) for v in np.argwhere(g != 1)[len(np.argwhere(g != 1)) // 2])
+            else:
+                mid = tuple(int(v) for v in np.argwhere(g[:, :40] != 1)[-1])
+            a1, _, _ = rh.mpa_astar(mpa, S, mid)
+            a2, _, _ = rh.mpa_astar(mpa, mid, T, set(rh.to_rc(a1[:-1], C)))
+            alt = np.concatenate([a1, a2[1:]]) if len(a1) and len(a2) else base
+            n = 60 if R <= 20 else 6
+            for t in range(n):
+                path_c, el_c = (base, alt) if t % 2 else (alt, base)
+                idx = rnd.randint(0, len(path_c) - 1) if R <= 20 else rnd.randint(len(path_c) - 40, len(path_c) - 1)
+                is_levy = t % 3 == 0
+                scale = rnd.choice([0.5, 0.25, 0.05, 5.0, 40.0])
+                pc, res, draws = rh.mpa_rebuild(mpa, rh.to_rc(path_c, C), rh.to_rc(el_c, C), idx, is_levy, scale,
+                                                555, 7, t)
+                rows.append(dict(grid=name, beta=beta, path=path_c, elite=el_c, idx=idx, is_levy=int(is_levy),
+                                 scale=scale, agent=t, out=pc, draws=draws,
+                                 stats=[res[1], res[2], res[3], res[4], res[5]]))
+    names = sorted(set(r["grid"] for r in rows))
+    io_, if_ = csr([r["path"] for r in rows]); eo, ef = csr([r["elite"] for r in rows]); oo, of = csr([r["out"] for r in rows])
+    ratio = np.arange(0, 51) / 50.0
+    mpa = rh.make_mpa(G["fig7"])
+    np.savez_compressed(
+        os.path.join(OUT, "mpa_cases.npz"), grid_names=np.array(names),
+        grid_id=np.array([names.index(r["grid"]) for r in rows]), beta=np.array([r["beta"] for r in rows]),
+        in_off=io_, in_path=if_, el_off=eo, el_path=ef, out_off=oo, out_path=of,
+        idx=np.array([r["idx"] for r in rows]), is_levy=np.array([r["is_levy"] for r in rows]),
+        scale=np.array([r["scale"] for r in rows]), agent=np.array([r["agent"] for r in rows]),
+        draws=np.array([r["draws"] for r in rows]), stats=np.array([r["stats"] for r in rows], np.float64),
+        seed_it=np.array([555, 7]), sigma=np.array([rh.levy_sigma(1.5), rh.levy_sigma(2.0)]),
+        **{"meta_" + k: v for k, v in META.items()})
+    print("mpa cases", len(rows), "changed", sum(not np.array_equal(r["out"], r["path"]) for r in rows))
+
+
+def cap_pso_update(G):
+    """Trajectories of the reference's own solve() loop with one particle
+    (pso.py:178-229): position/velocity after each update step."""
+    g = G["fig7"]
+    rows = []
+    for seed, (w, c1, c2) in ((5, (0.7, 1.5, 1.5)), (6, (0.9, 2.0, 0.5)), (7, (0.4, 2.5, 2.5))):
+        ps = rh.make_pso(g, W=5, n=1, iters=1, w=w, c1=c1, c2=c2, **MAIN_W)
+        rec = []
+        orig = ps._reconstruct_path_from_position
+        flag = dict(on=False)
+
+        def hooked(pos, orig=orig, rec=rec, ps=ps, flag=flag):
+            if flag["on"]:
+                rec.append(np.array(pos, float).copy())
+            return orig(pos)
+        ps._reconstruct_path_from_position = hooked
+        rh.RNG.rekey(seed, pfrng.DOM_INIT, 0, 0)
+        with rh.quiet():
+            ok = ps._initialize_particles()
+        assert ok
+        ps._initialize_particles = lambda: True
+        flag["on"] = True
+        for it in range(8):
+            pos0 = np.array(ps.particles[0]["position"], float); vel0 = np.array(ps.particles[0]["velocity"], float)
+            pb = np.array(ps.particles[0]["pbest_position"], float); gb = np.array(ps.gbest_particle_data["position"], float)
+            rh.RNG.rekey(seed, pfrng.DOM_PSO, it, 0)
+            rec.clear()
+            with rh.quiet():
+                ps.solve()
+            rows.append(dict(seed=seed, it=it, params=[w, c1, c2, ps.max_vel], pos0=pos0, vel0=vel0, pb=pb, gb=gb,
+                             pos1=rec[0], vel1=np.array(ps.particles[0]["velocity"], float)))
+    np.savez_compressed(
+        os.path.join(OUT, "pso_update.npz"), seed=np.array([r["seed"] for r in rows]),
+        it=np.array([r["it"] for r in rows]), params=np.array([r["params"] for r in rows]),
+        pos0=np.array([r["pos0"] for r in rows]), vel0=np.array([r["vel0"] for r in rows]),
+        pbest=np.array([r["pb"] for r in rows]), gbest=np.array([r["gb"] for r in rows]),
+        pos1=np.array([r["pos1"] for r in rows]), vel1=np.array([r["vel1"] for r in rows]),
+        **{"meta_" + k: v for k, v in META.items()})
+    print("pso update cases", len(rows))
+
+
+def cap_rng():
+    """CPython's own derivations on the keyed generator."""
+    keys = [(0, 1, 1, 0), (1, 2, 3, 4), (2 ** 40 + 7, 3, 100, 65535), (99, 5, 7, 123456)]
+    d = {"keys": np.array(keys, np.uint64)}
+    for i, k in enumerate(keys):
+        r = pfrng.AgentRandom(*k)
+        d[f"k{i}_next64"] = np.array([r.next64() for _ in range(8)], np.uint64)
+        r = pfrng.AgentRandom(*k)
+        d[f"k{i}_random"] = np.array([r.random() for _ in range(8)])
+        r = pfrng.AgentRandom(*k)
+        d[f"k{i}_randint"] = np.array([r.randint(-5, 17) for _ in range(16)] + [r.randint(0, 0) for _ in range(4)] +
+                                      [r.randint(0, 2 ** 40) for _ in range(4)], np.int64)
+        d[f"k{i}_randint_draws"] = np.array(r.draws)
+        r = pfrng.AgentRandom(*k)
+        d[f"k{i}_normal"] = np.array([r.normalvariate(0, 1) for _ in range(16)] + [r.normalvariate(0, 0.7) for _ in range(4)])
+        d[f"k{i}_normal_draws"] = np.array(r.draws)
+        r = pfrng.AgentRandom(*k)
+        d[f"k{i}_uniform"] = np.array([r.uniform(0, 2 * np.pi) for _ in range(8)])
+        r = pfrng.AgentRandom(*k)
+        d[f"k{i}_choice"] = np.array([r.choice(range(n)) for n in (1, 2, 3, 5, 8, 100, 1000, 7, 1, 1)], np.int64)
+        d[f"k{i}_choice_draws"] = np.array(r.draws)
+    np.savez_compressed(os.path.join(OUT, "rng.npz"), **d, **{"meta_" + k: v for k, v in META.items()})
+
+
+if __name__ == "__main__":
+    assert rh.available(), "needs /root/reference"
+    os.makedirs(OUT, exist_ok=True)
+    rh.install()
+    G = grids()
+    which = sys.argv[1:] or ["grids", "rng", "astar", "decode", "maaco", "mpa", "pso"]
+    if "grids" in which: cap_grids(G)
+    if "rng" in which: cap_rng()
+    if "astar" in which: cap_astar(G)
+    if "decode" in which: cap_decode(G)
+    if "maaco" in which: cap_maaco(G)
+    if "mpa" in which: cap_mpa(G)
+    if "pso" in which: cap_pso_update(G)
+    print("golden fixtures written to", OUT)
