@@ -173,23 +173,44 @@ int pf_mpa_setup(pf_handle* h, const pf_mpa_params* p, const pf_score_params* sp
  * predator's stream (seed, DOM_MPA=2, iter, i), then
  * MPA._reconstruct_path_segment (:284-318) or the phase's no-move branch.
  * Population = strided paths d_pop_cells/d_pop_len indexed through d_order
- * (int32[N], sorted position -> storage slot); d_elite_cells/elite_len = the
- * sweep-start elite path.  phase in {1,2,3}; CF per MPA.py:336.
+ * (int32[N], sorted position -> storage slot); d_elite_cells/elite_len/
+ * d_elite_stats(double[5]) = the sweep-start elite (may alias the population
+ * storage: candidates are written to separate buffers).  phase in {1,2,3}; CF per MPA.py:336.
  * Outputs candidate paths (strided, same cap) + stats double[n*5]. */
 int pf_mpa_phase_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uint64_t seed, int32_t agent0,
                        int32_t n, int32_t path_cap, const int32_t* d_pop_cells, const int32_t* d_pop_len,
                        const double* d_pop_stats, const int32_t* d_order, const int32_t* d_elite_cells,
-                       int32_t elite_len, int32_t* d_out_cells, int32_t* d_out_len, double* d_out_stats,
-                       int32_t* d_status);
+                       int32_t elite_len, const double* d_elite_stats, int32_t* d_out_cells, int32_t* d_out_len,
+                       double* d_out_stats, int32_t* d_status);
 /* FADs sweep MPA.py:387-410 on the post-memory population (in place):
  * stream (seed, DOM_MPA_FADS=5, iter, i). */
 int pf_mpa_fads_batch(pf_handle* h, double CF, int32_t iter, uint64_t seed, int32_t agent0, int32_t n,
-                      int32_t path_cap, int32_t* d_pop_cells, int32_t* d_pop_len, double* d_pop_stats,
-                      int32_t* d_status);
+                      int32_t path_cap, const int32_t* d_order, int32_t* d_pop_cells, int32_t* d_pop_len,
+                      double* d_pop_stats, int32_t* d_status);
+/* MPA._reconstruct_path_segment (MPA.py:284-318) called directly: predator a
+ * modifies population path a against the given elite path with explicit
+ * idx / is_levy / scale and stream (seed, DOM_MPA, iter, d_agent[a]). */
+int pf_mpa_rebuild_batch(pf_handle* h, int32_t iter, uint64_t seed, int32_t n, int32_t path_cap,
+                         const int32_t* d_pop_cells, const int32_t* d_pop_len, const double* d_pop_stats,
+                         const int32_t* d_elite_cells, int32_t elite_len, const int32_t* d_idx,
+                         const int32_t* d_is_levy, const double* d_scale, const int32_t* d_agent,
+                         int32_t* d_out_cells, int32_t* d_out_len, double* d_out_stats, int32_t* d_status);
 /* memory step MPA.py:381-384: pop[i] <- cand[i] where cand fitness < pop fitness */
 int pf_mpa_memory(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_order, int32_t agent0,
                   const int32_t* d_cand_cells, const int32_t* d_cand_len, const double* d_cand_stats,
                   int32_t* d_pop_cells, int32_t* d_pop_len, double* d_pop_stats);
+
+/* ---- device self-tests (used by tests/ to pin device arithmetic) ----- */
+/* out[i] = device sqrt((double)in[i]) -- must equal libm sqrt bit for bit
+ * (heuristic astar.py:90 / helper.py:12). */
+int pf_selftest_sqrt(pf_handle* h, int32_t n, const int64_t* d_in, double* d_out);
+/* device keyed RNG + CPython derivations for key (seed,dom,it,agent):
+ * d_u64[8] next64; d_f64[0..8) random(), [8..28) normalvariate (16 x (0,1),
+ * 4 x (0,0.7)), [28..36) uniform(0,2pi); d_i64[0..24) randint as in
+ * oracle/capture_golden.py cap_rng, [24..34) randbelow(n) for the same n
+ * list, [34..37) draw counters after the randint / normal / choice runs. */
+int pf_selftest_rng(pf_handle* h, uint64_t seed, uint64_t dom, uint64_t it, uint64_t agent, uint64_t* d_u64,
+                    double* d_f64, int64_t* d_i64);
 
 #ifdef __cplusplus
 }

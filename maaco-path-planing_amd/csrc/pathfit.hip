@@ -1,0 +1,1291 @@
+// pathfit.hip -- kernels K0..K7 and the C-ABI of libpathfit.so (gfx950 / MI355X).
+// See include/pathfit.h for the boundary and DESIGN.md for the data layout.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/pathfit.h"
+#include "pf_astar.h"
+#include "pf_device.h"
+#include "pf_score.h"
+
+using namespace pf;
+
+#define DOM_MAACO 1
+#define DOM_MPA 2
+#define DOM_PSO 3
+#define DOM_MPA_FADS 5
+
+// ===========================================================================
+// device-side launch parameter blocks
+// ===========================================================================
+struct DevCounters {
+  unsigned long long pops, pushes, nbr, path_cells, steps, candidates, stale, overflow;
+};
+
+struct Common {
+  Grid G;
+  Rec* rec;              // [nslots][RC]
+  uint32_t* slot_state;  // [nslots][2] = {tag, avoid_ep}
+  int* work;             // dynamic work counter
+  DevCounters* cnt;
+  int S;                 // LDS bin capacity
+  int retry;             // only agents whose status == 3
+};
+
+PF_DEV Open make_open(char* smem, int S) {
+  Open O;
+  O.lf = (double*)smem;
+  O.lg = O.lf + 64 * S;
+  O.sf = O.lg + 64 * S;
+  O.sg = O.sf + 8;
+  O.lc = (int*)(O.sg + 8);
+  O.sc = O.lc + 64 * S;
+  O.S = S;
+  return O;
+}
+static size_t open_bytes(int S) { return (size_t)64 * S * 20 + 8 * 20; }
+
+PF_DEV Slot slot_load(const Common& c, int RC) {
+  Slot s;
+  s.rec = c.rec + (size_t)blockIdx.x * RC;
+  s.tag = c.slot_state[2 * blockIdx.x];
+  s.avoid_ep = c.slot_state[2 * blockIdx.x + 1];
+  return s;
+}
+PF_DEV void slot_store(const Common& c, const Slot& s, int lane) {
+  if (lane == 0) { c.slot_state[2 * blockIdx.x] = s.tag; c.slot_state[2 * blockIdx.x + 1] = s.avoid_ep; }
+}
+// new agent evaluation: fresh avoid epoch; wipe the slot before an epoch can wrap
+PF_DEV void slot_begin_eval(Slot& s, int RC, int lane) {
+  s.avoid_ep += 1;
+  if (s.avoid_ep >= 0xFFFFF0u || s.tag >= 0xFFFFFF00u) {
+    for (int i = lane; i < RC; i += 64) { Rec z; z.g = 0.0; z.tag = 0; z.meta = 0; s.rec[i] = z; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    s.avoid_ep = 1; s.tag = 1;
+  }
+}
+PF_DEV int next_work(int* work, int lane) {
+  int a = 0;
+  if (lane == 0) a = atomicAdd(work, 1);
+  return first_i(a);
+}
+PF_DEV void flush_counters(DevCounters* c, const AStat& st, unsigned long long cells, unsigned long long ovf, int lane) {
+  if (lane == 0) {
+    atomicAdd(&c->pops, st.pops); atomicAdd(&c->pushes, st.pushes); atomicAdd(&c->nbr, st.nbr);
+    atomicAdd(&c->stale, st.stale); atomicAdd(&c->path_cells, cells); atomicAdd(&c->overflow, ovf);
+  }
+}
+
+// ===========================================================================
+// K0: grid preparation
+// ===========================================================================
+// static move masks (helper.py:38-52 order) for restrict on/off, and the clipped
+// squared distance to the nearest obstacle inside a radius-7 window.
+__global__ void k_grid_prep(const uint8_t* occ, int R, int C, uint8_t* mm_r1, uint8_t* mm_r0, uint8_t* d2near) {
+  int cell = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= R * C) return;
+  int r = cell / C, c = cell % C;
+  unsigned m1 = 0, m0 = 0;
+  for (int m = 0; m < 8; ++m) {
+    int nr = r + HM_DR[m], nc = c + HM_DC[m];
+    if (nr < 0 || nr >= R || nc < 0 || nc >= C || occ[nr * C + nc] == 1) continue;
+    m0 |= 1u << m;
+    if (m >= 4 && (occ[nr * C + c] == 1 || occ[r * C + nc] == 1)) continue;   // corner cells are in bounds here
+    m1 |= 1u << m;
+  }
+  mm_r1[cell] = (uint8_t)m1; mm_r0[cell] = (uint8_t)m0;
+  int best = 255;
+  for (int dr = -7; dr <= 7; ++dr) for (int dc = -7; dc <= 7; ++dc) {
+    int rr = r + dr, cc = c + dc;
+    if (rr < 0 || rr >= R || cc < 0 || cc >= C || occ[rr * C + cc] != 1) continue;
+    int d2 = dr * dr + dc * dc;
+    if (d2 < best) best = d2;
+  }
+  d2near[cell] = (uint8_t)best;
+}
+
+// ===========================================================================
+// K2: A* connector batch
+// ===========================================================================
+struct AstarArgs {
+  Common c;
+  int n, path_cap;
+  const int* start; const int* target;
+  const long long* avoid_off; const int* avoid_cells;
+  int* cells; int* len; int* status; long long* counters;
+};
+
+template <int VARIANT>
+__global__ __launch_bounds__(64) void k_astar_batch(AstarArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = lane_id();
+  const int RC = p.c.G.R * p.c.G.C;
+  Open O = make_open(smem, p.c.S);
+  Slot s = slot_load(p.c, RC);
+  AStat tot = {0, 0, 0, 0, 0};
+  unsigned long long cells = 0, ovf = 0;
+  for (;;) {
+    const int a = next_work(p.c.work, lane);
+    if (a >= p.n) break;
+    if (p.c.retry && p.status[a] != 3) continue;
+    slot_begin_eval(s, RC, lane);
+    if (p.avoid_off) {
+      const long long b = p.avoid_off[a], e = p.avoid_off[a + 1];
+      mark_avoid(s, p.avoid_cells + b, (int)(e - b), lane);
+    }
+    AStat st = {0, 0, 0, 0, 0};
+    int n = 0;
+    const int rc = astar<VARIANT>(p.c.G, s, O, p.start[a], p.target[a], p.cells + (size_t)a * p.path_cap,
+                                  p.path_cap, n, st, lane);
+    if (lane == 0) {
+      p.len[a] = rc == 0 ? n : 0;
+      p.status[a] = rc;
+      if (p.counters) {
+        p.counters[4 * a] = (long long)st.pops; p.counters[4 * a + 1] = (long long)st.pushes;
+        p.counters[4 * a + 2] = st.max_open; p.counters[4 * a + 3] = (long long)st.nbr;
+      }
+    }
+    tot.pops += st.pops; tot.pushes += st.pushes; tot.nbr += st.nbr; tot.stale += st.stale;
+    cells += rc == 0 ? n : 0; ovf += rc == 3;
+  }
+  slot_store(p.c, s, lane);
+  flush_counters(p.c.cnt, tot, cells, ovf, lane);
+}
+
+// ===========================================================================
+// K1: scoring batch
+// ===========================================================================
+struct ScoreArgs {
+  Grid G; ScoreP sp; int n, path_cap;
+  const int* cells; const int* len; double* stats;
+};
+__global__ __launch_bounds__(64) void k_score_batch(ScoreArgs p) {
+  const int lane = lane_id();
+  for (int a = blockIdx.x; a < p.n; a += gridDim.x) {
+    double out[5];
+    score_path(p.G, p.sp, p.cells + (size_t)a * p.path_cap, p.len[a], lane, out);
+    if (lane < 5) p.stats[(size_t)a * 5 + lane] = out[lane];
+  }
+}
+
+// ===========================================================================
+// K3: chained waypoint decode (+ K1)
+// ===========================================================================
+struct DecodeArgs {
+  Common c; ScoreP sp; int do_score;
+  int n, W, path_cap, start, target;
+  const int* wp_cells; const double* wp_pos;
+  int* cells; int* len; int* status; double* stats;
+};
+__global__ __launch_bounds__(64) void k_decode_batch(DecodeArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = lane_id();
+  const Grid& G = p.c.G;
+  const int RC = G.R * G.C;
+  Open O = make_open(smem, p.c.S);
+  Slot s = slot_load(p.c, RC);
+  AStat tot = {0, 0, 0, 0, 0};
+  unsigned long long cells = 0, ovf = 0;
+  for (;;) {
+    const int a = next_work(p.c.work, lane);
+    if (a >= p.n) break;
+    if (p.c.retry && p.status[a] != 3) continue;
+    slot_begin_eval(s, RC, lane);
+    int* out = p.cells + (size_t)a * p.path_cap;
+    int n = 1, cur = p.start, rc = 0;
+    if (lane == 0) { out[0] = p.start; s.rec[p.start].meta = s.avoid_ep << PF_AVOID_SHIFT; }   // ga_solver.py:63-65
+    for (int k = 0; k <= p.W && rc == 0; ++k) {
+      int goal = p.target;
+      if (k < p.W) {
+        if (p.wp_cells) goal = p.wp_cells[(size_t)a * p.W + k];
+        else {                                                   // pso.py:61,69-70: round-half-even then clamp
+          double x = p.wp_pos[((size_t)a * p.W + k) * 2], y = p.wp_pos[((size_t)a * p.W + k) * 2 + 1];
+          long r = (long)__builtin_rint(x), c = (long)__builtin_rint(y);
+          r = r < 0 ? 0 : (r > G.R - 1 ? G.R - 1 : r);
+          c = c < 0 ? 0 : (c > G.C - 1 ? G.C - 1 : c);
+          goal = (int)(r * G.C + c);
+        }
+      }
+      int m = 0;
+      rc = astar<0>(G, s, O, cur, goal, out + n - 1, p.path_cap - (n - 1), m, tot, lane);   // ga_solver.py:68-72
+      if (rc != 0) break;                                        // :74 / :85 -> []
+      mark_avoid(s, out + n, m - 1, lane);                       // :76 nodes_in_path_so_far.update
+      n += m - 1;
+      cur = goal;
+    }
+    // ga_solver.py:90-93 (drop consecutive duplicates) is a no-op here: a segment's tail never starts with its head
+    if (rc != 0) n = 0;
+    double sc[5];
+    if (p.do_score) score_path(G, p.sp, out, n, lane, sc);
+    if (lane == 0) { p.len[a] = n; p.status[a] = rc; }
+    if (p.do_score && lane < 5) p.stats[(size_t)a * 5 + lane] = sc[lane];
+    cells += n; ovf += rc == 3;
+  }
+  slot_store(p.c, s, lane);
+  flush_counters(p.c.cnt, tot, cells, ovf, lane);
+}
+
+// ===========================================================================
+// K6: PSO update + pbest
+// ===========================================================================
+struct PsoArgs {
+  int n, W, R, C; double w, c1, c2, max_vel;
+  double* pos; double* vel; const double* pbest; const double* gbest;
+  unsigned long long seed, iter, agent0;
+};
+// one thread per (particle, waypoint): the counter RNG is random access, so
+// waypoint d starts at draw 4*d of the particle's stream (pso.py:186-190 order).
+__global__ void k_pso_update(PsoArgs p) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= p.n * p.W) return;
+  const int part = t / p.W, d = t - part * p.W;
+  Rng g; g.init(p.seed, DOM_PSO, p.iter, p.agent0 + (unsigned long long)part);
+  g.ctr = 4ull * (unsigned long long)d;
+  for (int ax = 0; ax < 2; ++ax) {
+    const size_t i = ((size_t)part * p.W + d) * 2 + ax;
+    const double hi = ax == 0 ? (double)(p.R - 1) : (double)(p.C - 1);
+    const double r1 = g.random(), r2 = g.random();
+    const double x = p.pos[i];
+    double v = p.w * p.vel[i] + p.c1 * r1 * (p.pbest[i] - x) + p.c2 * r2 * (p.gbest[d * 2 + ax] - x);
+    v = fmin(fmax(v, -p.max_vel), p.max_vel);                     // np.clip pso.py:192-193
+    double nx = x + v;
+    nx = fmin(fmax(nx, 0.0), hi);                                 // np.clip pso.py:201-202
+    p.vel[i] = v; p.pos[i] = nx;
+  }
+}
+__global__ void k_pso_pbest(int n, int W, const double* pos, const double* stats, const int* len, double* pbest,
+                            double* pbest_fit, int* improved) {
+  const int a = blockIdx.x;
+  if (a >= n) return;
+  const bool better = len[a] > 0 && stats[(size_t)a * 5 + 4] < pbest_fit[a];   // pso.py:210,216
+  for (int i = threadIdx.x; i < W * 2; i += blockDim.x)
+    if (better) pbest[(size_t)a * W * 2 + i] = pos[(size_t)a * W * 2 + i];
+  __syncthreads();
+  if (threadIdx.x == 0) { improved[a] = better; if (better) pbest_fit[a] = stats[(size_t)a * 5 + 4]; }
+}
+
+// ===========================================================================
+// K4: MAACO ant walk
+// ===========================================================================
+struct MaacoArgs {
+  Grid G;
+  const double* tau;      // tau^alpha when alpha != 1 (host-refreshed), else tau
+  const double* eta;      // [RC][2]  eta'^beta for (no turn, turn)
+  unsigned* visit;        // [nslots][RC] tabu epoch stamps
+  unsigned* slot_epoch;   // [nslots]
+  int* work; DevCounters* cnt;
+  int start, target, iter, num_iterations; double q0;
+  unsigned long long seed; int ant0, n, path_cap;
+  int* cells; int* len; double* plen; int* turns; int* status;
+};
+
+__global__ __launch_bounds__(64) void k_maaco_walk(MaacoArgs p) {
+  const int lane = lane_id();
+  const Grid& G = p.G;
+  const int R = G.R, C = G.C, RC = R * C;
+  unsigned* visit = p.visit + (size_t)blockIdx.x * RC;
+  unsigned epoch = p.slot_epoch[blockIdx.x];
+  const int k = lane & 7;
+  const int mdr = AM_DR[k], mdc = AM_DC[k];
+  const unsigned hbit = 1u << AM_TO_HM[k];
+  const int sr = row_of(G, p.start), sc = p.start - sr * C;
+  const int tr = row_of(G, p.target), tc = p.target - tr * C;
+  // MAACO.py:147-150 start->target orientation: static per move
+  const int vrS = tr - sr, vcS = tc - sc;
+  const bool o1 = !((vcS > 0 && mdc < 0) || (vcS < 0 && mdc > 0) || (vrS > 0 && mdr < 0) || (vrS < 0 && mdr > 0));
+  const unsigned O1 = (unsigned)(__ballot(o1 && lane < 8) & 0xFF);
+  const double mcost = (mdr != 0 && mdc != 0) ? PF_SQRT2 : 1.0;
+  unsigned long long steps_tot = 0, cand_tot = 0, cells_tot = 0;
+  for (;;) {
+    const int a = next_work(p.work, lane);
+    if (a >= p.n) break;
+    epoch += 1;
+    if (epoch >= 0xFFFFFFF0u) {
+      for (int i = lane; i < RC; i += 64) visit[i] = 0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      epoch = 1;
+    }
+    Rng g; g.init(p.seed, DOM_MAACO, (unsigned long long)p.iter, (unsigned long long)(p.ant0 + a));
+    int* out = p.cells + (size_t)a * p.path_cap;
+    int cr = sr, cc = sc, n = 1, prev_k = -1, nturn = 0, rc = 0;
+    double plen = 0.0;
+    if (lane == 0) { out[0] = p.start; visit[p.start] = epoch; }
+    const long long max_steps = (long long)RC * 2;                 // MAACO.py:283
+    long long steps = 0;
+    while (!(cr == tr && cc == tc) && steps < max_steps) {
+      const int cur = cr * C + cc;
+      const int nr = cr + mdr, nc = cc + mdc;
+      const bool inb = lane < 8 && nr >= 0 && nr < R && nc >= 0 && nc < C;
+      const int nidx = nr * C + nc;
+      const int turn = (prev_k >= 0 && k != prev_k) ? 1 : 0;     // MAACO.py:184-195
+      unsigned vst = 0, mmask = 0; double tv = 0.0, ev = 0.0;
+      if (inb) { vst = visit[nidx]; tv = p.tau[nidx]; ev = p.eta[(size_t)nidx * 2 + turn]; }
+      else if (lane == 9) mmask = G.mm[cur];
+      const unsigned M = (unsigned)bcast_i((int)mmask, 9);
+      const bool ok = inb && (M & hbit) && vst != epoch;         // valid, not tabu, no corner cut (:93-95,:100-120)
+      const unsigned mall = (unsigned)(__ballot(ok) & 0xFF);
+      // strategy 2 orientation: current -> target (:152-157)
+      const int vr = tr - cr, vc = tc - cc;
+      const bool o2 = !((vc > 0 && mdc < 0) || (vc < 0 && mdc > 0) || (vr > 0 && mdr < 0) || (vr < 0 && mdr > 0));
+      const unsigned O2 = (unsigned)(__ballot(o2 && lane < 8) & 0xFF);
+      unsigned cand = mall & O1;                                  // :165
+      if (!cand) cand = mall & O2;                                // :168-169
+      if (!cand) cand = mall;                                     // :172-180
+      if (!cand) { rc = 1; break; }                               // :287-288
+      const int ncand = __builtin_popcount(cand);
+      cand_tot += ncand;
+      const double q = g.random();                                // :232 (drawn even for one candidate)
+      const double attr = tv * ev;                                // :238 tau^alpha * eta'^beta
+      int pick;
+      if (q <= p.q0) {                                            // :241-250 running max with absolute tolerance
+        double mx = -1.0; unsigned bm = 0;
+        for (unsigned c2 = cand; c2; c2 &= c2 - 1) {
+          const int j = __builtin_ctz(c2);
+          const double aj = bcast_d(attr, j);
+          if (aj > mx) { mx = aj; bm = 1u << j; }
+          else if (fabs(aj - mx) < 1e-9) bm |= 1u << j;
+        }
+        if (!bm) { rc = 1; break; }
+        pick = nth_set_bit(bm, (int)g.randbelow((unsigned long long)__builtin_popcount(bm)));   // random.choice
+      } else {
+        double sum = 0.0;                                         // :252 sum() in candidate order
+        for (unsigned c2 = cand; c2; c2 &= c2 - 1) sum = sum + bcast_d(attr, __builtin_ctz(c2));
+        if (sum < 1e-9) pick = nth_set_bit(cand, (int)g.randbelow((unsigned long long)ncand));   // :253-254
+        else {
+          double ps = 0.0;                                        // :255-258
+          for (unsigned c2 = cand; c2; c2 &= c2 - 1) ps = ps + bcast_d(attr, __builtin_ctz(c2)) / sum;
+          const bool renorm = fabs(ps - 1.0) > 1e-6;
+          const double u = g.random();                            // :259 np.random.choice -> one random_sample
+          double last = 0.0; bool first = true;                   // cdf = cumsum(p); cdf /= cdf[-1]
+          for (unsigned c2 = cand; c2; c2 &= c2 - 1) {
+            double pj = bcast_d(attr, __builtin_ctz(c2)) / sum; if (renorm) pj = pj / ps;
+            last = first ? pj : last + pj; first = false;
+          }
+          double acc = 0.0; first = true; int idx = 0, seen = 0;
+          for (unsigned c2 = cand; c2; c2 &= c2 - 1) {            // searchsorted(cdf, u, side='right')
+            double pj = bcast_d(attr, __builtin_ctz(c2)) / sum; if (renorm) pj = pj / ps;
+            acc = first ? pj : acc + pj; first = false;
+            seen += 1;
+            if (acc / last <= u) idx = seen;
+          }
+          if (idx > ncand - 1) idx = ncand - 1;
+          pick = nth_set_bit(cand, idx);
+        }
+      }
+      plen += bcast_d(mcost, pick);                               // :293
+      if (prev_k >= 0 && pick != prev_k) nturn += 1;              // :264-276 counted on the fly
+      prev_k = pick;
+      cr += bcast_i(mdr, pick); cc += bcast_i(mdc, pick);
+      if (n >= p.path_cap) { rc = 3; break; }
+      if (lane == 0) { out[n] = cr * C + cc; visit[cr * C + cc] = epoch; }
+      n += 1; steps += 1;
+    }
+    if (rc == 0 && !(cr == tr && cc == tc)) rc = 2;               // :301-302 step cap
+    steps_tot += (unsigned long long)steps;
+    if (lane == 0) {
+      p.len[a] = rc == 0 ? n : 0;
+      p.plen[a] = rc == 0 ? plen : PF_INF;
+      p.turns[a] = rc == 0 ? nturn : -1;
+      p.status[a] = rc;
+    }
+    cells_tot += rc == 0 ? n : 0;
+  }
+  if (lane == 0) {
+    p.slot_epoch[blockIdx.x] = epoch;
+    atomicAdd(&p.cnt->steps, steps_tot); atomicAdd(&p.cnt->candidates, cand_tot); atomicAdd(&p.cnt->path_cells, cells_tot);
+  }
+}
+
+// ===========================================================================
+// K5: pheromone update (evaporate / ordered deposit / clip)
+// ===========================================================================
+__global__ void k_tau_evaporate(double* tau, int RC, double keep) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < RC) tau[i] = tau[i] * keep;                             // MAACO.py:305
+}
+// visit bit matrix [word][cell]: bit (a & 63) of word a >> 6 set iff successful ant a visited cell
+__global__ __launch_bounds__(64) void k_visit_bits(int n, int path_cap, const int* cells, const int* len, const double* plen,
+                                                   double Q, unsigned long long* bits, int RC, double* dep) {
+  const int a = blockIdx.x;
+  const int L = len[a];
+  const bool good = L > 0 && plen[a] != PF_INF && plen[a] > 1e-6;   // MAACO.py:307
+  if (threadIdx.x == 0) dep[a] = good ? Q / plen[a] : 0.0;          // :308
+  if (!good) return;
+  unsigned long long* w = bits + (size_t)(a >> 6) * RC;
+  const unsigned long long bit = 1ull << (a & 63);
+  for (int i = threadIdx.x; i < L; i += blockDim.x) atomicOr(&w[cells[(size_t)a * path_cap + i]], bit);
+}
+// per cell: add the deposits of the ants that visited it, in ant order (MAACO.py:306-311
+// is sequential over ants; a cell is visited at most once per ant because of the tabu set)
+__global__ void k_tau_deposit(double* tau, const uint8_t* occ, int RC, const unsigned long long* bits, int nwords,
+                              const double* dep) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= RC) return;
+  double t = tau[i];
+  bool touched = false;
+  for (int w = 0; w < nwords; ++w) {
+    unsigned long long b = bits[(size_t)w * RC + i];
+    while (b) {
+      const int j = __builtin_ctzll(b); b &= b - 1;
+      t += dep[w * 64 + j]; touched = true;
+    }
+  }
+  if (touched && occ[i] != 1) tau[i] = t;
+}
+__global__ void k_tau_clip(double* tau, const uint8_t* occ, int RC, double tmin, double tmax) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= RC) return;
+  tau[i] = occ[i] == 1 ? 1e-9 : fmin(fmax(tau[i], tmin), tmax);   // MAACO.py:326-332
+}
+
+// ===========================================================================
+// K7 + K2b + K1: MPA
+// ===========================================================================
+struct MpaDev {
+  double P, levy_beta, sigma, fads;
+  int N, start, target;
+};
+PF_DEV long py_round(double x) { return (long)__builtin_rint(x); }
+PF_DEV int clampi(long v, int lo, int hi) { return (int)(v < lo ? lo : (v > hi ? hi : v)); }
+
+// MPA._get_levy_target_node, MPA.py:250-264
+PF_DEV int levy_target(Rng& g, const Grid& G, int cur, double scale, double beta, double sigma) {
+  const double u = g.normalvariate(0.0, sigma);
+  double v = g.normalvariate(0.0, 1.0);
+  if (fabs(v) < 1e-9) v = 1e-9;
+  double step = 0.05 * u / pow(fabs(v), 1.0 / beta) * scale;
+  const double mx = (double)(G.R > G.C ? G.R : G.C) * 0.5;
+  step = fmin(fmax(step, -mx), mx);
+  const double ang = g.uniform(0.0, 2.0 * 3.141592653589793);
+  const long dr = py_round(step * sin(ang)), dc = py_round(step * cos(ang));
+  const int r = row_of(G, cur), c = cur - r * G.C;
+  return clampi(r + dr, 0, G.R - 1) * G.C + clampi(c + dc, 0, G.C - 1);
+}
+// MPA._get_brownian_target_node, MPA.py:266-282 (elite < 0 == None)
+PF_DEV int brownian_target(Rng& g, const Grid& G, int cur, int elite, double scale) {
+  const int cr = row_of(G, cur), cc = cur - cr * G.C;
+  long tr_, tc_;
+  if (g.random() < 0.7 && elite >= 0) {
+    const int er = row_of(G, elite), ec = elite - er * G.C;
+    const int dr = er - cr, dc = ec - cc;
+    const double dist = __builtin_sqrt((double)((long)dr * dr + (long)dc * dc));
+    if (dist > 1e-6) {
+      const double fac = fabs(g.normalvariate(0.0, 1.0));
+      long kk = py_round(scale * fac * 5.0); if (kk < 1) kk = 1;
+      const double ms = dist < (double)kk ? dist : (double)kk;
+      tr_ = cr + py_round((double)dr / dist * ms);
+      tc_ = cc + py_round((double)dc / dist * ms);
+    } else return elite;
+  } else {
+    long m = py_round((double)(G.R > G.C ? G.R : G.C) * 0.1 * scale * fabs(g.normalvariate(0.0, 1.0)));
+    if (m < 1) m = 1;
+    const long dr = g.randint(-m, m);
+    const long dc = g.randint(-m, m);
+    tr_ = cr + dr; tc_ = cc + dc;
+  }
+  return clampi(tr_, 0, G.R - 1) * G.C + clampi(tc_, 0, G.C - 1);
+}
+
+PF_DEV void copy_path(int* dst, const int* src, int n, int lane) {
+  for (int i = lane; i < n; i += 64) dst[i] = src[i];
+}
+
+struct MpaPhaseArgs {
+  Common c; ScoreP sp; MpaDev m;
+  int phase, iter; double CF; unsigned long long seed;
+  int agent0, n, path_cap;
+  const int* pop_cells; const int* pop_len; const double* pop_stats; const int* order;
+  const int* elite_cells; int elite_len; const double* elite_stats;   // device double[5]
+  int* out_cells; int* out_len; double* out_stats; int* status;
+  // explicit mode (pf_mpa_rebuild_batch): no idx/gate draws
+  const int* ex_idx; const int* ex_levy; const double* ex_scale; const int* ex_agent;
+};
+
+// One predator of one phase sweep, MPA.py:339-377 + _reconstruct_path_segment :284-318.
+__global__ __launch_bounds__(64) void k_mpa_phase(MpaPhaseArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = lane_id();
+  const Grid& G = p.c.G;
+  const int RC = G.R * G.C;
+  Open O = make_open(smem, p.c.S);
+  Slot s = slot_load(p.c, RC);
+  AStat tot = {0, 0, 0, 0, 0};
+  unsigned long long cells = 0, ovf = 0;
+  for (;;) {
+    const int a = next_work(p.c.work, lane);
+    if (a >= p.n) break;
+    if (p.c.retry && p.status[a] != 3) continue;
+    const int gi = p.ex_idx ? p.ex_agent[a] : p.agent0 + a;      // index in the fitness-sorted population
+    const int slot = p.ex_idx ? a : p.order[gi];
+    const int* prey = p.pop_cells + (size_t)slot * p.path_cap;
+    const int preyL = p.pop_len[slot];
+    const double* prey_stats = p.pop_stats + (size_t)slot * 5;
+    int* out = p.out_cells + (size_t)a * p.path_cap;
+    // which path is modified / which one is the elite-node reference
+    bool is_levy; double scale; const int* mod; int modL; const double* mod_stats; const int* ref; int refL;
+    if (p.ex_idx) { is_levy = p.ex_levy[a] != 0; scale = p.ex_scale[a]; mod = prey; modL = preyL; mod_stats = prey_stats; ref = p.elite_cells; refL = p.elite_len; }
+    else if (p.phase == 1) { is_levy = false; scale = p.m.P; mod = prey; modL = preyL; mod_stats = prey_stats; ref = p.elite_cells; refL = p.elite_len; }
+    else if (p.phase == 2) {
+      is_levy = gi < p.m.N / 2;                                   // :351
+      scale = is_levy ? p.m.P : p.m.P * p.CF;                     // :354
+      mod = is_levy ? prey : p.elite_cells; modL = is_levy ? preyL : p.elite_len;
+      mod_stats = is_levy ? prey_stats : p.elite_stats;
+      ref = is_levy ? p.elite_cells : prey; refL = is_levy ? p.elite_len : preyL;
+    } else { is_levy = true; scale = p.m.P * p.CF; mod = p.elite_cells; modL = p.elite_len; mod_stats = p.elite_stats; ref = prey; refL = preyL; }
+    const double gate_p = p.phase == 1 ? p.m.P : scale;           // :344 / :359 / :372
+    int rc = 4, n = modL;                                         // default: the unmodified path + its stats
+    bool rebuilt = false;
+    Rng g; g.init(p.seed, DOM_MPA, (unsigned long long)p.iter, (unsigned long long)gi);
+    if (p.ex_idx ? (modL > 0 && p.ex_idx[a] < modL - 1) : (modL > 1)) {   // explicit: the :286 early return
+      const int idx = p.ex_idx ? p.ex_idx[a] : (int)g.randint(0, modL - 2);   // :343 / :358 / :371
+      if (p.ex_idx || g.random() < gate_p) {
+        // ---- _reconstruct_path_segment(mod, ref, idx, is_levy, scale) ----
+        // (idx <= modL-2 so the :286 early return cannot trigger)
+        slot_begin_eval(s, RC, lane);
+        const int cur = mod[idx];
+        mark_avoid(s, mod, idx, lane);                            // set(prefix[:-1]) :290
+        int inter;
+        if (is_levy) inter = levy_target(g, G, cur, scale, p.m.levy_beta, p.m.sigma);
+        else {
+          int en = -1;
+          if (refL > 0) en = ref[(int)g.randbelow((unsigned long long)refL)];   // random.choice :248
+          inter = brownian_target(g, G, cur, en, scale);
+        }
+        if (idx + 1 > p.path_cap) rc = 3;
+        else {
+          copy_path(out, mod, idx + 1, lane);                     // :296
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          n = idx + 1;
+          int astart = cur; rc = 0;
+          for (int seg = 0; seg < 2 && rc != 3; ++seg) {
+            int goal;
+            if (seg == 0) { if (!(G.occ[inter] != 1 && inter != astart)) continue; goal = inter; }   // :298
+            else { if (astart == p.m.target) continue; goal = p.m.target; }                           // :306
+            int mlen = 0;
+            const int r2 = astar<1>(G, s, O, astart, goal, out + n - 1, p.path_cap - (n - 1), mlen, tot, lane);
+            if (r2 == 3) { rc = 3; break; }
+            if (r2 == 0 && mlen > 1) {                            // :300-305 / :308-309
+              if (seg == 0) { mark_avoid(s, out + n, mlen - 1, lane); astart = inter; }
+              n += mlen - 1;
+            }
+          }
+          if (rc != 3) {
+            // :310-315 dedup is a no-op (see k_decode_batch); :316-317 endpoint check
+            const int first = out[0], last = out[n - 1];
+            if (first != p.m.start || last != p.m.target) rc = 4; else { rc = 0; rebuilt = true; }
+          }
+        }
+      }
+    }
+    double sc[5];
+    if (rebuilt) score_path(G, p.sp, out, n, lane, sc);
+    else if (rc != 3) {
+      // no move: phase 1 keeps the prey (:342,:347); phases 2/3 re-score path_to_modify (:356,:363,:369,:376),
+      // whose stats are the stored ones (same function, same path)
+      n = modL;
+      copy_path(out, mod, modL, lane);
+      for (int i = 0; i < 5; ++i) sc[i] = mod_stats[i];
+      if (modL == 0) { sc[0] = PF_INF; sc[1] = 0; sc[2] = 0; sc[3] = 0; sc[4] = PF_INF; }
+    } else n = 0;
+    if (lane == 0) { p.out_len[a] = n; p.status[a] = rc; }
+    if (rc != 3 && lane < 5) p.out_stats[(size_t)a * 5 + lane] = sc[lane];
+    cells += n; ovf += rc == 3;
+  }
+  slot_store(p.c, s, lane);
+  flush_counters(p.c.cnt, tot, cells, ovf, lane);
+}
+
+struct MpaFadsArgs {
+  Common c; ScoreP sp; MpaDev m;
+  int iter; double CF; unsigned long long seed;
+  int agent0, n, path_cap;
+  int* pop_cells; int* pop_len; double* pop_stats; const int* order;
+  int* tmp_cells;   // [nslots][path_cap]
+  int* status;
+};
+// FADs sweep MPA.py:387-410, in place on the post-memory population.
+__global__ __launch_bounds__(64) void k_mpa_fads(MpaFadsArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = lane_id();
+  const Grid& G = p.c.G;
+  const int RC = G.R * G.C;
+  Open O = make_open(smem, p.c.S);
+  Slot s = slot_load(p.c, RC);
+  AStat tot = {0, 0, 0, 0, 0};
+  unsigned long long cells = 0, ovf = 0;
+  int* tmp = p.tmp_cells + (size_t)blockIdx.x * p.path_cap;
+  for (;;) {
+    const int a = next_work(p.c.work, lane);
+    if (a >= p.n) break;
+    if (p.c.retry && p.status[a] != 3) continue;
+    const int gi = p.agent0 + a;
+    const int slot = p.order ? p.order[gi] : gi;
+    int rc = 4, n = 0;
+    bool have = false;
+    Rng g; g.init(p.seed, DOM_MPA_FADS, (unsigned long long)p.iter, (unsigned long long)gi);
+    if (g.random() < p.m.fads) {                                   // :389
+      slot_begin_eval(s, RC, lane);
+      if (g.random() < p.CF) {                                     // :390
+        const int rr_ = (int)g.randint(0, G.R - 1);                // :391
+        const int rc_ = (int)g.randint(0, G.C - 1);
+        const int node = rr_ * G.C + rc_;
+        if (G.occ[node] != 1) {                                    // :393
+          int m1 = 0;
+          int r1 = astar<1>(G, s, O, p.m.start, node, tmp, p.path_cap, m1, tot, lane);   // :394
+          if (r1 == 3) rc = 3;
+          else if (r1 == 0 && m1 > 0) {
+            mark_avoid(s, tmp, m1 - 1, lane);                      // set(p1[:-1]) :396
+            int m2 = 0;
+            int r2 = astar<1>(G, s, O, node, p.m.target, tmp + m1 - 1, p.path_cap - (m1 - 1), m2, tot, lane);
+            if (r2 == 3) rc = 3;
+            else if (r2 == 0 && m2 > 0) { n = m1 + m2 - 1; have = true; }   // :398-400 (last is the target by construction)
+          }
+        }
+      } else {
+        int m1 = 0;
+        int r1 = astar<1>(G, s, O, p.m.start, p.m.target, tmp, p.path_cap, m1, tot, lane);   // :405
+        if (r1 == 3) rc = 3;
+        else if (r1 == 0 && m1 > 0) { n = m1; have = true; }
+      }
+    }
+    if (have) {
+      double sc[5];
+      score_path(G, p.sp, tmp, n, lane, sc);
+      const double curfit = p.pop_stats[(size_t)slot * 5 + 4];
+      if (sc[4] < curfit) {                                        // :402 / :408
+        copy_path(p.pop_cells + (size_t)slot * p.path_cap, tmp, n, lane);
+        if (lane == 0) p.pop_len[slot] = n;
+        if (lane < 5) p.pop_stats[(size_t)slot * 5 + lane] = sc[lane];
+        rc = 0;
+      }
+    }
+    if (lane == 0) p.status[a] = rc;
+    cells += n; ovf += rc == 3;
+  }
+  slot_store(p.c, s, lane);
+  flush_counters(p.c.cnt, tot, cells, ovf, lane);
+}
+
+// memory step MPA.py:381-384
+__global__ __launch_bounds__(64) void k_mpa_memory(int n, int path_cap, const int* order, int agent0, const int* cand_cells,
+                                                   const int* cand_len, const double* cand_stats, int* pop_cells,
+                                                   int* pop_len, double* pop_stats) {
+  const int a = blockIdx.x;
+  if (a >= n) return;
+  const int slot = order[agent0 + a];
+  if (!(cand_stats[(size_t)a * 5 + 4] < pop_stats[(size_t)slot * 5 + 4])) return;
+  const int L = cand_len[a];
+  for (int i = threadIdx.x; i < L; i += blockDim.x) pop_cells[(size_t)slot * path_cap + i] = cand_cells[(size_t)a * path_cap + i];
+  if (threadIdx.x < 5) pop_stats[(size_t)slot * 5 + threadIdx.x] = cand_stats[(size_t)a * 5 + threadIdx.x];
+  if (threadIdx.x == 0) pop_len[slot] = L;
+}
+
+// ===========================================================================
+// device self-tests
+// ===========================================================================
+__global__ void k_selftest_sqrt(int n, const long long* in, double* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = __builtin_sqrt((double)in[i]);
+}
+__global__ void k_selftest_rng(unsigned long long seed, unsigned long long dom, unsigned long long it,
+                               unsigned long long agent, unsigned long long* u64, double* f64, long long* i64) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  Rng g;
+  g.init(seed, dom, it, agent); for (int i = 0; i < 8; ++i) u64[i] = g.next64();
+  g.init(seed, dom, it, agent); for (int i = 0; i < 8; ++i) f64[i] = g.random();
+  g.init(seed, dom, it, agent);
+  for (int i = 0; i < 16; ++i) i64[i] = g.randint(-5, 17);
+  for (int i = 0; i < 4; ++i) i64[16 + i] = g.randint(0, 0);
+  for (int i = 0; i < 4; ++i) i64[20 + i] = g.randint(0, 1ll << 40);
+  i64[34] = (long long)g.ctr;
+  g.init(seed, dom, it, agent);
+  for (int i = 0; i < 16; ++i) f64[8 + i] = g.normalvariate(0.0, 1.0);
+  for (int i = 0; i < 4; ++i) f64[24 + i] = g.normalvariate(0.0, 0.7);
+  i64[35] = (long long)g.ctr;
+  g.init(seed, dom, it, agent); for (int i = 0; i < 8; ++i) f64[28 + i] = g.uniform(0.0, 2.0 * 3.141592653589793);
+  g.init(seed, dom, it, agent);
+  const unsigned long long ns[10] = {1, 2, 3, 5, 8, 100, 1000, 7, 1, 1};
+  for (int i = 0; i < 10; ++i) i64[24 + i] = (long long)g.randbelow(ns[i]);
+  i64[36] = (long long)g.ctr;
+}
+
+// ===========================================================================
+// host side
+// ===========================================================================
+struct pf_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int R = 0, C = 0, RC = 0;
+  uint8_t *d_occ = nullptr, *d_mm_r1 = nullptr, *d_mm_r0 = nullptr, *d_mm_r1_nd = nullptr, *d_mm_r0_nd = nullptr,
+          *d_d2near = nullptr;
+  std::vector<uint8_t> h_occ;
+  int nslots = 0;
+  Rec* d_rec = nullptr;
+  uint32_t* d_slot_state = nullptr;
+  int* d_work = nullptr;
+  DevCounters* d_cnt = nullptr;
+  pf_counters last = {};
+  double* d_pen = nullptr;
+  double pen_min_safe = -1.0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float last_ms = 0.f;
+  std::string err;
+  // MAACO
+  bool maaco_ready = false;
+  pf_maaco_params mp = {};
+  double *d_tau = nullptr, *d_taua = nullptr, *d_eta = nullptr, *d_dep = nullptr;
+  unsigned* d_visit = nullptr; unsigned* d_visit_epoch = nullptr;
+  unsigned long long* d_bits = nullptr; size_t bits_words = 0; int dep_cap = 0;
+  // MPA
+  bool mpa_ready = false;
+  pf_mpa_params mpp = {};
+  pf_score_params mps = {};
+  int* d_tmp = nullptr; int tmp_cap = 0;
+  double* d_elite_stats = nullptr;
+};
+
+static std::string g_create_err;
+static int fail(pf_handle* h, const char* what, hipError_t e) {
+  std::string m = std::string(what) + ": " + hipGetErrorString(e);
+  if (h) h->err = m; else g_create_err = m;
+  return -1;
+}
+static int failmsg(pf_handle* h, const std::string& m) { if (h) h->err = m; else g_create_err = m; return -2; }
+#define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(h, #call, e_); } while (0)
+
+static Grid make_grid(pf_handle* h, int allow_diag, int restrict_corner) {
+  Grid G;
+  G.occ = h->d_occ;
+  G.mm = allow_diag ? (restrict_corner ? h->d_mm_r1 : h->d_mm_r0) : (restrict_corner ? h->d_mm_r1_nd : h->d_mm_r0_nd);
+  G.d2near = h->d_d2near; G.R = h->R; G.C = h->C;
+  G.magicC = ((1ull << 40) / (uint64_t)h->C) + 1;
+  return G;
+}
+
+extern "C" {
+
+const char* pf_version(void) { return "pathfit 0.1 (gfx950)"; }
+int pf_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+const char* pf_last_error(pf_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+void* pf_stream(pf_handle* h) { return (void*)h->stream; }
+int pf_sync(pf_handle* h) { CK(hipStreamSynchronize(h->stream)); return 0; }
+
+__global__ void k_and_mask(uint8_t* dst, const uint8_t* src, int n, unsigned m) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i] & m;
+}
+
+int pf_create(const uint8_t* grid, int32_t R, int32_t C, int32_t device, pf_handle** out) {
+  pf_handle* h = nullptr;
+  if (!grid || !out || R < 1 || C < 1 || R > 4096 || C > 4096) return failmsg(nullptr, "pf_create: bad arguments (1 <= R,C <= 4096)");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) return failmsg(nullptr, "pf_create: no HIP device available (this engine has no CPU fallback)");
+  if (device < 0 || device >= ndev) return failmsg(nullptr, "pf_create: device ordinal out of range");
+  h = new pf_handle();
+  h->device = device; h->R = R; h->C = C; h->RC = R * C;
+  #define CKC(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fail(nullptr, #call, e_); pf_destroy(h); return -1; } } while (0)
+  CKC(hipSetDevice(device));
+  CKC(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  CKC(hipEventCreate(&h->ev0)); CKC(hipEventCreate(&h->ev1));
+  h->h_occ.resize(h->RC);
+  for (int i = 0; i < h->RC; ++i) h->h_occ[i] = grid[i] == 1 ? 1 : 0;
+  CKC(hipMalloc(&h->d_occ, h->RC)); CKC(hipMalloc(&h->d_mm_r1, h->RC)); CKC(hipMalloc(&h->d_mm_r0, h->RC));
+  CKC(hipMalloc(&h->d_mm_r1_nd, h->RC)); CKC(hipMalloc(&h->d_mm_r0_nd, h->RC)); CKC(hipMalloc(&h->d_d2near, h->RC));
+  CKC(hipMemcpyAsync(h->d_occ, h->h_occ.data(), h->RC, hipMemcpyHostToDevice, h->stream));
+  const int nb = (h->RC + 255) / 256;
+  k_grid_prep<<<nb, 256, 0, h->stream>>>(h->d_occ, R, C, h->d_mm_r1, h->d_mm_r0, h->d_d2near);
+  k_and_mask<<<nb, 256, 0, h->stream>>>(h->d_mm_r1_nd, h->d_mm_r1, h->RC, 0x0Fu);
+  k_and_mask<<<nb, 256, 0, h->stream>>>(h->d_mm_r0_nd, h->d_mm_r0, h->RC, 0x0Fu);
+  CKC(hipMalloc(&h->d_work, sizeof(int)));
+  CKC(hipMalloc(&h->d_cnt, sizeof(DevCounters)));
+  CKC(hipMalloc(&h->d_pen, 256 * sizeof(double)));
+  CKC(hipMalloc(&h->d_elite_stats, 5 * sizeof(double)));
+  CKC(hipStreamSynchronize(h->stream));
+  #undef CKC
+  *out = h;
+  return 0;
+}
+
+void pf_destroy(pf_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  void* ptrs[] = {h->d_occ, h->d_mm_r1, h->d_mm_r0, h->d_mm_r1_nd, h->d_mm_r0_nd, h->d_d2near, h->d_rec, h->d_slot_state,
+                  h->d_work, h->d_cnt, h->d_pen, h->d_tau, h->d_taua, h->d_eta, h->d_dep, h->d_visit, h->d_visit_epoch,
+                  h->d_bits, h->d_tmp, h->d_elite_stats};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int pf_dev_alloc(pf_handle* h, int64_t bytes, void** d_out) { CK(hipSetDevice(h->device)); CK(hipMalloc(d_out, (size_t)(bytes > 0 ? bytes : 1))); return 0; }
+int pf_dev_free(pf_handle* h, void* p) { CK(hipSetDevice(h->device)); CK(hipFree(p)); return 0; }
+int pf_h2d(pf_handle* h, void* d, const void* s, int64_t n) { CK(hipMemcpyAsync(d, s, (size_t)n, hipMemcpyHostToDevice, h->stream)); CK(hipStreamSynchronize(h->stream)); return 0; }
+int pf_d2h(pf_handle* h, void* d, const void* s, int64_t n) { CK(hipMemcpyAsync(d, s, (size_t)n, hipMemcpyDeviceToHost, h->stream)); CK(hipStreamSynchronize(h->stream)); return 0; }
+int pf_memset(pf_handle* h, void* d, int32_t b, int64_t n) { CK(hipMemsetAsync(d, b, (size_t)n, h->stream)); CK(hipStreamSynchronize(h->stream)); return 0; }
+int pf_get_counters(pf_handle* h, pf_counters* out) { *out = h->last; return 0; }
+float pf_last_kernel_ms(pf_handle* h) { return h->last_ms; }
+
+}  // extern "C"
+
+// ---- scratch / launch helpers ----------------------------------------------
+static const int kSlotsPerCU = 8;
+static int ensure_slots(pf_handle* h) {
+  if (h->d_rec) return 0;
+  CK(hipSetDevice(h->device));
+  hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, h->device));
+  int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  h->nslots = cus * kSlotsPerCU;
+  size_t bytes = (size_t)h->nslots * h->RC * sizeof(Rec);
+  // keep the search scratch under ~64 GiB of the 288 GB HBM
+  while (bytes > (64ull << 30) && h->nslots > cus) { h->nslots /= 2; bytes = (size_t)h->nslots * h->RC * sizeof(Rec); }
+  CK(hipMalloc(&h->d_rec, bytes));
+  CK(hipMemsetAsync(h->d_rec, 0, bytes, h->stream));
+  CK(hipMalloc(&h->d_slot_state, sizeof(uint32_t) * 2 * h->nslots));
+  std::vector<uint32_t> init(2 * h->nslots, 1u);
+  CK(hipMemcpyAsync(h->d_slot_state, init.data(), sizeof(uint32_t) * init.size(), hipMemcpyHostToDevice, h->stream));
+  CK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+static Common make_common(pf_handle* h, int allow_diag, int restrict_corner, int S, int retry) {
+  Common c;
+  c.G = make_grid(h, allow_diag, restrict_corner);
+  c.rec = h->d_rec; c.slot_state = h->d_slot_state; c.work = h->d_work; c.cnt = h->d_cnt; c.S = S; c.retry = retry;
+  return c;
+}
+static int begin_batch(pf_handle* h) {
+  CK(hipSetDevice(h->device));
+  CK(hipMemsetAsync(h->d_cnt, 0, sizeof(DevCounters), h->stream));
+  return 0;
+}
+static int end_batch(pf_handle* h, DevCounters* dc) {
+  CK(hipMemcpyAsync(dc, h->d_cnt, sizeof(DevCounters), hipMemcpyDeviceToHost, h->stream));
+  CK(hipStreamSynchronize(h->stream));
+  h->last.pops = dc->pops; h->last.pushes = dc->pushes; h->last.nbr_examined = dc->nbr; h->last.path_cells = dc->path_cells;
+  h->last.steps = dc->steps; h->last.candidates = dc->candidates; h->last.stale_pops = dc->stale; h->last.overflow_agents = dc->overflow;
+  return 0;
+}
+// LDS bin capacities tried in order; a retry pass re-runs only agents that overflowed
+static const int kS[] = {16, 32, 64};
+
+template <typename KArgs, typename Kern>
+static int launch_with_retry(pf_handle* h, Kern kern, KArgs& args, int n) {
+  if (n <= 0) return 0;
+  DevCounters total = {}; float ms_total = 0.f;
+  for (int pass = 0; pass < 3; ++pass) {
+    const int S = kS[pass];
+    args.c.S = S; args.c.retry = pass > 0;
+    const size_t lds = open_bytes(S);
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = (int)((160 * 1024) / lds); if (per_cu > kSlotsPerCU) per_cu = kSlotsPerCU; if (per_cu < 1) per_cu = 1;
+    int grid = (h->nslots / kSlotsPerCU) * per_cu; if (grid > n) grid = n; if (grid > h->nslots) grid = h->nslots;
+    CK(hipMemsetAsync(h->d_work, 0, sizeof(int), h->stream));
+    CK(hipMemsetAsync(h->d_cnt, 0, sizeof(DevCounters), h->stream));
+    CK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, h->stream, args);
+    CK(hipGetLastError());
+    CK(hipEventRecord(h->ev1, h->stream));
+    DevCounters dc;
+    if (end_batch(h, &dc)) return -1;
+    float ms = 0.f; CK(hipEventElapsedTime(&ms, h->ev0, h->ev1)); ms_total += ms;
+    total.pops += dc.pops; total.pushes += dc.pushes; total.nbr += dc.nbr; total.path_cells += dc.path_cells;
+    total.stale += dc.stale; total.overflow = dc.overflow;
+    if (dc.overflow == 0) break;
+  }
+  h->last.pops = total.pops; h->last.pushes = total.pushes; h->last.nbr_examined = total.nbr; h->last.path_cells = total.path_cells;
+  h->last.stale_pops = total.stale; h->last.overflow_agents = total.overflow; h->last.steps = 0; h->last.candidates = 0;
+  h->last_ms = ms_total;
+  return 0;
+}
+
+static int ensure_pen(pf_handle* h, double min_safe) {
+  if (min_safe > 7.0) return failmsg(h, "min_safe_distance > 7 is not supported (obstacle-distance window radius is 7)");
+  if (h->pen_min_safe == min_safe) return 0;
+  double pen[256];
+  for (int d2 = 0; d2 < 256; ++d2) {
+    double d = sqrt((double)d2);                                   // helper.py:76
+    pen[d2] = (d2 < 255 && d < min_safe) ? pow(min_safe - d, 2.0) : 0.0;   // helper.py:77-78 (float ** 2 -> libm pow)
+  }
+  CK(hipMemcpyAsync(h->d_pen, pen, sizeof(pen), hipMemcpyHostToDevice, h->stream));
+  CK(hipStreamSynchronize(h->stream));
+  h->pen_min_safe = min_safe;
+  return 0;
+}
+static int make_scorep(pf_handle* h, const pf_score_params* sp, ScoreP* out) {
+  if (sp->variant == 0) { if (ensure_pen(h, sp->min_safe)) return -1; }
+  else if (h->pen_min_safe < 0) { if (ensure_pen(h, 0.0)) return -1; }
+  out->variant = sp->variant; out->restrict_policy = sp->restrict_policy; out->w_turn = sp->w_turn; out->w_safe = sp->w_safe;
+  out->diag_pen = sp->diag_pen; out->pen = h->d_pen;
+  return 0;
+}
+
+extern "C" {
+
+int pf_astar_batch(pf_handle* h, int32_t variant, int32_t allow_diag, int32_t restrict_corner, int32_t n,
+                   const int32_t* d_start, const int32_t* d_target, const int64_t* d_avoid_off,
+                   const int32_t* d_avoid_cells, int32_t path_cap, int32_t* d_cells, int32_t* d_len,
+                   int32_t* d_status, int64_t* d_counters) {
+  if (!h) return -2;
+  if (n < 0 || path_cap < 1 || !d_start || !d_target || !d_cells || !d_len || !d_status) return failmsg(h, "pf_astar_batch: bad arguments");
+  if (ensure_slots(h)) return -1;
+  AstarArgs a;
+  a.c = make_common(h, allow_diag, restrict_corner, 16, 0);
+  a.n = n; a.path_cap = path_cap; a.start = d_start; a.target = d_target;
+  a.avoid_off = (const long long*)d_avoid_off; a.avoid_cells = d_avoid_cells;
+  a.cells = d_cells; a.len = d_len; a.status = d_status; a.counters = (long long*)d_counters;
+  if (variant == PF_ASTAR_REF) return launch_with_retry(h, k_astar_batch<0>, a, n);
+  if (variant == PF_ASTAR_MPA) return launch_with_retry(h, k_astar_batch<1>, a, n);
+  return failmsg(h, "pf_astar_batch: unknown variant");
+}
+
+int pf_score_batch(pf_handle* h, const pf_score_params* sp, int32_t n, int32_t path_cap, const int32_t* d_cells,
+                   const int32_t* d_len, double* d_stats) {
+  if (!h) return -2;
+  if (!sp || n < 0 || !d_cells || !d_len || !d_stats) return failmsg(h, "pf_score_batch: bad arguments");
+  if (n == 0) return 0;
+  ScoreArgs a;
+  a.G = make_grid(h, 1, 1);
+  if (make_scorep(h, sp, &a.sp)) return -1;
+  a.n = n; a.path_cap = path_cap; a.cells = d_cells; a.len = d_len; a.stats = d_stats;
+  CK(hipSetDevice(h->device));
+  int grid = n < 16384 ? n : 16384;
+  CK(hipEventRecord(h->ev0, h->stream));
+  hipLaunchKernelGGL(k_score_batch, dim3(grid), dim3(64), 0, h->stream, a);
+  CK(hipGetLastError());
+  CK(hipEventRecord(h->ev1, h->stream));
+  CK(hipStreamSynchronize(h->stream));
+  CK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  return 0;
+}
+
+int pf_decode_batch(pf_handle* h, int32_t allow_diag, int32_t restrict_corner, int32_t n, int32_t W,
+                    const int32_t* d_wp_cells, const double* d_wp_pos, int32_t start, int32_t target,
+                    int32_t path_cap, int32_t* d_cells, int32_t* d_len, int32_t* d_status,
+                    const pf_score_params* sp, double* d_stats) {
+  if (!h) return -2;
+  if (n < 0 || W < 0 || path_cap < 1 || (!d_wp_cells && !d_wp_pos && W > 0) || !d_cells || !d_len || !d_status ||
+      start < 0 || start >= h->RC || target < 0 || target >= h->RC || (sp && !d_stats))
+    return failmsg(h, "pf_decode_batch: bad arguments");
+  if (ensure_slots(h)) return -1;
+  DecodeArgs a;
+  a.c = make_common(h, allow_diag, restrict_corner, 16, 0);
+  a.do_score = sp != nullptr;
+  if (sp) { if (make_scorep(h, sp, &a.sp)) return -1; } else memset(&a.sp, 0, sizeof(a.sp));
+  a.n = n; a.W = W; a.path_cap = path_cap; a.start = start; a.target = target;
+  a.wp_cells = d_wp_cells; a.wp_pos = d_wp_pos; a.cells = d_cells; a.len = d_len; a.status = d_status; a.stats = d_stats;
+  return launch_with_retry(h, k_decode_batch, a, n);
+}
+
+int pf_pso_update(pf_handle* h, int32_t n, int32_t W, double w, double c1, double c2, double max_vel, double* d_pos,
+                  double* d_vel, const double* d_pbest, const double* d_gbest, uint64_t seed, uint64_t iter,
+                  uint64_t agent0) {
+  if (!h) return -2;
+  if (n < 0 || W < 1 || !d_pos || !d_vel || !d_pbest || !d_gbest) return failmsg(h, "pf_pso_update: bad arguments");
+  if (n == 0) return 0;
+  CK(hipSetDevice(h->device));
+  PsoArgs a{n, W, h->R, h->C, w, c1, c2, max_vel, d_pos, d_vel, d_pbest, d_gbest, seed, iter, agent0};
+  const int threads = 256, blocks = (n * W + threads - 1) / threads;
+  CK(hipEventRecord(h->ev0, h->stream));
+  hipLaunchKernelGGL(k_pso_update, dim3(blocks), dim3(threads), 0, h->stream, a);
+  CK(hipGetLastError());
+  CK(hipEventRecord(h->ev1, h->stream));
+  CK(hipStreamSynchronize(h->stream));
+  CK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  return 0;
+}
+
+int pf_pso_pbest(pf_handle* h, int32_t n, int32_t W, const double* d_pos, const double* d_stats, const int32_t* d_len,
+                 double* d_pbest, double* d_pbest_fit, int32_t* d_improved) {
+  if (!h) return -2;
+  if (n <= 0) return 0;
+  CK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(k_pso_pbest, dim3(n), dim3(64), 0, h->stream, n, W, d_pos, d_stats, d_len, d_pbest, d_pbest_fit, d_improved);
+  CK(hipGetLastError());
+  CK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int pf_selftest_sqrt(pf_handle* h, int32_t n, const int64_t* d_in, double* d_out) {
+  if (!h || n < 0 || !d_in || !d_out) return failmsg(h, "pf_selftest_sqrt: bad arguments");
+  if (n == 0) return 0;
+  CK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(k_selftest_sqrt, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, (const long long*)d_in, d_out);
+  CK(hipGetLastError()); CK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+int pf_selftest_rng(pf_handle* h, uint64_t seed, uint64_t dom, uint64_t it, uint64_t agent, uint64_t* d_u64,
+                    double* d_f64, int64_t* d_i64) {
+  if (!h || !d_u64 || !d_f64 || !d_i64) return failmsg(h, "pf_selftest_rng: bad arguments");
+  CK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(k_selftest_rng, dim3(1), dim3(64), 0, h->stream, seed, dom, it, agent, (unsigned long long*)d_u64, d_f64, (long long*)d_i64);
+  CK(hipGetLastError()); CK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// MAACO host side
+// ---------------------------------------------------------------------------
+static double hdist(int r1, int c1, int r2, int c2) { long dr = r1 - r2, dc = c1 - c2; return sqrt((double)(dr * dr + dc * dc)); }
+
+static int maaco_refresh_taua(pf_handle* h) {
+  // alpha != 1: tau^alpha must be libm pow to match the reference (MAACO.py:238); refreshed on the host
+  if (h->mp.alpha == 1.0) return 0;
+  std::vector<double> t(h->RC);
+  CK(hipMemcpyAsync(t.data(), h->d_tau, sizeof(double) * h->RC, hipMemcpyDeviceToHost, h->stream));
+  CK(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < h->RC; ++i) t[i] = pow(t[i], h->mp.alpha);
+  CK(hipMemcpyAsync(h->d_taua, t.data(), sizeof(double) * h->RC, hipMemcpyHostToDevice, h->stream));
+  CK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int pf_maaco_setup(pf_handle* h, const pf_maaco_params* p) {
+  if (!h) return -2;
+  if (!p || p->start < 0 || p->start >= h->RC || p->target < 0 || p->target >= h->RC) return failmsg(h, "pf_maaco_setup: bad arguments");
+  CK(hipSetDevice(h->device));
+  h->mp = *p;
+  const int R = h->R, C = h->C, RC = h->RC;
+  const int sr = p->start / C, sc = p->start % C, tr = p->target / C, tc = p->target % C;
+  double dsT = hdist(sr, sc, tr, tc); if (dsT < 1e-9) dsT = 1e-9;                   // MAACO.py:43-45
+  std::vector<double> tau(RC), eta((size_t)RC * 2);
+  for (int r = 0; r < R; ++r) for (int c = 0; c < C; ++c) {
+    const int i = r * C + c;
+    // pheromone init MAACO.py:58-84
+    if (h->h_occ[i] == 1) tau[i] = 1e-9;
+    else {
+      double dsi = hdist(sr, sc, r, c), diT = hdist(r, c, tr, tc), den = dsi + diT, factor;
+      if (den < 1e-9) factor = (hdist(r, c, sr, sc) < 1e-6 || hdist(r, c, tr, tc) < 1e-6) ? 1.0 : 0.1;
+      else factor = dsT / den;
+      double t = factor * p->C0_initial_pheromone; if (t < 1e-9) t = 1e-9;
+      tau[i] = t;
+    }
+    // eta'^beta for both turn flags, MAACO.py:197-210 + :238 (host libm: identical to math.exp / pow)
+    double dsj = hdist(sr, sc, r, c), djT = hdist(r, c, tr, tc), hh;
+    if (dsT < 1e-9) hh = p->wh_min; else hh = p->wh_max - (p->wh_max - p->wh_min) * exp(-p->k_h_adaptive * djT / dsT);
+    double gg = 1.0 - hh;
+    for (int turn = 0; turn < 2; ++turn) {
+      double den = gg * dsj + hh * djT + p->a_turn_coef * (double)turn;
+      den = den > 1e-9 ? den : 1e-9;
+      eta[(size_t)i * 2 + turn] = pow(1.0 / den, p->beta);
+    }
+  }
+  if (!h->d_tau) { CK(hipMalloc(&h->d_tau, sizeof(double) * RC)); CK(hipMalloc(&h->d_taua, sizeof(double) * RC)); CK(hipMalloc(&h->d_eta, sizeof(double) * RC * 2)); }
+  CK(hipMemcpyAsync(h->d_tau, tau.data(), sizeof(double) * RC, hipMemcpyHostToDevice, h->stream));
+  CK(hipMemcpyAsync(h->d_eta, eta.data(), sizeof(double) * RC * 2, hipMemcpyHostToDevice, h->stream));
+  CK(hipStreamSynchronize(h->stream));
+  if (!h->d_visit) {
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, h->device));
+    if (!h->nslots) { int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; h->nslots = cus * kSlotsPerCU; }
+    const int vs = h->nslots * 4;   // walk kernel has no LDS: up to 32 waves/CU resident
+    CK(hipMalloc(&h->d_visit, sizeof(unsigned) * (size_t)vs * RC));
+    CK(hipMemsetAsync(h->d_visit, 0, sizeof(unsigned) * (size_t)vs * RC, h->stream));
+    CK(hipMalloc(&h->d_visit_epoch, sizeof(unsigned) * vs));
+    CK(hipMemsetAsync(h->d_visit_epoch, 0, sizeof(unsigned) * vs, h->stream));
+    CK(hipStreamSynchronize(h->stream));
+  }
+  h->maaco_ready = true;
+  return maaco_refresh_taua(h);
+}
+
+static double maaco_q0(int it, int K, double q0_initial) {          // MAACO.py:212-226
+  double Kt = K, k = it, k0 = 0.7 * Kt, q;
+  if (k < k0) q = (fabs(Kt - k0) < 1e-6) ? q0_initial : ((Kt - k) / Kt) * q0_initial;
+  else {
+    double q_at = ((Kt - k0) / Kt) * q0_initial;
+    q = q_at + ((k - k0) / (Kt - k0 + 1e-9)) * (q0_initial * (1 - (Kt - k0) / Kt) / 2.0);
+  }
+  return fmin(fmax(q, 0.01), 0.99);
+}
+
+int pf_maaco_walk_batch(pf_handle* h, int32_t iter, uint64_t seed, int32_t ant0, int32_t n, int32_t path_cap,
+                        int32_t* d_cells, int32_t* d_len, double* d_plen, int32_t* d_turns, int32_t* d_status) {
+  if (!h) return -2;
+  if (!h->maaco_ready) return failmsg(h, "pf_maaco_walk_batch: call pf_maaco_setup first");
+  if (n < 0 || path_cap < 2 || !d_cells || !d_len || !d_plen || !d_turns || !d_status) return failmsg(h, "pf_maaco_walk_batch: bad arguments");
+  if (n == 0) return 0;
+  CK(hipSetDevice(h->device));
+  MaacoArgs a;
+  a.G = make_grid(h, 1, 1);
+  a.tau = h->mp.alpha == 1.0 ? h->d_tau : h->d_taua; a.eta = h->d_eta;
+  a.visit = h->d_visit; a.slot_epoch = h->d_visit_epoch; a.work = h->d_work; a.cnt = h->d_cnt;
+  a.start = h->mp.start; a.target = h->mp.target; a.iter = iter; a.num_iterations = h->mp.num_iterations;
+  a.q0 = maaco_q0(iter, h->mp.num_iterations, h->mp.q0_initial);
+  a.seed = seed; a.ant0 = ant0; a.n = n; a.path_cap = path_cap;
+  a.cells = d_cells; a.len = d_len; a.plen = d_plen; a.turns = d_turns; a.status = d_status;
+  int grid = h->nslots * 4; if (grid > n) grid = n;
+  CK(hipMemsetAsync(h->d_work, 0, sizeof(int), h->stream));
+  CK(hipMemsetAsync(h->d_cnt, 0, sizeof(DevCounters), h->stream));
+  CK(hipEventRecord(h->ev0, h->stream));
+  hipLaunchKernelGGL(k_maaco_walk, dim3(grid), dim3(64), 0, h->stream, a);
+  CK(hipGetLastError());
+  CK(hipEventRecord(h->ev1, h->stream));
+  DevCounters dc; if (end_batch(h, &dc)) return -1;
+  CK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  return 0;
+}
+
+int pf_maaco_evaporate(pf_handle* h) {
+  if (!h || !h->maaco_ready) return failmsg(h, "pf_maaco_evaporate: setup first");
+  CK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(k_tau_evaporate, dim3((h->RC + 255) / 256), dim3(256), 0, h->stream, h->d_tau, h->RC, 1.0 - h->mp.rho);
+  CK(hipGetLastError());
+  CK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int pf_maaco_deposit(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_cells, const int32_t* d_len,
+                     const double* d_plen) {
+  if (!h || !h->maaco_ready) return failmsg(h, "pf_maaco_deposit: setup first");
+  if (n <= 0) return 0;
+  CK(hipSetDevice(h->device));
+  const size_t words = (size_t)(n + 63) / 64;
+  if (words > h->bits_words) {
+    if (h->d_bits) CK(hipFree(h->d_bits));
+    CK(hipMalloc(&h->d_bits, words * h->RC * sizeof(unsigned long long)));
+    h->bits_words = words;
+  }
+  if (n > h->dep_cap) { if (h->d_dep) CK(hipFree(h->d_dep)); CK(hipMalloc(&h->d_dep, sizeof(double) * (size_t)words * 64)); h->dep_cap = (int)(words * 64); }
+  CK(hipMemsetAsync(h->d_bits, 0, words * h->RC * sizeof(unsigned long long), h->stream));
+  CK(hipMemsetAsync(h->d_dep, 0, sizeof(double) * words * 64, h->stream));
+  hipLaunchKernelGGL(k_visit_bits, dim3(n), dim3(64), 0, h->stream, n, path_cap, d_cells, d_len, d_plen, h->mp.Q, h->d_bits, h->RC, h->d_dep);
+  CK(hipGetLastError());
+  hipLaunchKernelGGL(k_tau_deposit, dim3((h->RC + 255) / 256), dim3(256), 0, h->stream, h->d_tau, h->d_occ, h->RC, h->d_bits, (int)words, h->d_dep);
+  CK(hipGetLastError());
+  CK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int pf_maaco_clip(pf_handle* h, double best_len_overall) {
+  if (!h || !h->maaco_ready) return failmsg(h, "pf_maaco_clip: setup first");
+  CK(hipSetDevice(h->device));
+  double bl = best_len_overall;                                     // MAACO.py:312-316
+  if (bl == INFINITY) bl = (double)(h->R + h->C);
+  if (bl < 1e-6) bl = 1e-6;
+  const double tmax = (1.0 / (1.0 - h->mp.rho)) * (1.0 / bl);       // :317
+  int mx = h->C > h->R ? h->C : h->R; if (mx < 1) mx = 1;
+  const double tmin = tmax / (2.0 * mx);                            // :323
+  hipLaunchKernelGGL(k_tau_clip, dim3((h->RC + 255) / 256), dim3(256), 0, h->stream, h->d_tau, h->d_occ, h->RC, tmin, tmax);
+  CK(hipGetLastError());
+  CK(hipStreamSynchronize(h->stream));
+  return maaco_refresh_taua(h);
+}
+
+int pf_maaco_get_pheromone(pf_handle* h, double* tau) {
+  if (!h || !h->maaco_ready) return failmsg(h, "pf_maaco_get_pheromone: setup first");
+  return pf_d2h(h, tau, h->d_tau, (int64_t)sizeof(double) * h->RC);
+}
+int pf_maaco_set_pheromone(pf_handle* h, const double* tau) {
+  if (!h || !h->maaco_ready) return failmsg(h, "pf_maaco_set_pheromone: setup first");
+  if (pf_h2d(h, h->d_tau, tau, (int64_t)sizeof(double) * h->RC)) return -1;
+  return maaco_refresh_taua(h);
+}
+void* pf_maaco_tau_dev(pf_handle* h) { return h ? (void*)h->d_tau : nullptr; }
+
+int pf_maaco_best_scan(int32_t n, const double* plen, const int32_t* turns, int32_t idx0, double* best_len,
+                       double* best_turns, int32_t* best_idx) {
+  // MAACO.py:343-349, sequential over ants (turns of a failed ant are +inf there)
+  for (int i = 0; i < n; ++i) {
+    const double L = plen[i];
+    const double T = turns[i] < 0 ? INFINITY : (double)turns[i];
+    if (L < *best_len) { *best_len = L; *best_idx = idx0 + i; *best_turns = T; }
+    else if (fabs(L - *best_len) < 1e-9 && T < *best_turns) { *best_idx = idx0 + i; *best_turns = T; }
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// MPA host side
+// ---------------------------------------------------------------------------
+int pf_mpa_setup(pf_handle* h, const pf_mpa_params* p, const pf_score_params* sp) {
+  if (!h) return -2;
+  if (!p || !sp || p->start < 0 || p->start >= h->RC || p->target < 0 || p->target >= h->RC) return failmsg(h, "pf_mpa_setup: bad arguments");
+  h->mpp = *p; h->mps = *sp; h->mpa_ready = true;
+  return ensure_slots(h);
+}
+static MpaDev mpa_dev(const pf_handle* h) {
+  MpaDev m; m.P = h->mpp.P_const; m.levy_beta = h->mpp.levy_beta; m.sigma = h->mpp.levy_sigma; m.fads = h->mpp.FADs_rate;
+  m.N = h->mpp.num_predators; m.start = h->mpp.start; m.target = h->mpp.target;
+  return m;
+}
+
+int pf_mpa_phase_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uint64_t seed, int32_t agent0, int32_t n,
+                       int32_t path_cap, const int32_t* d_pop_cells, const int32_t* d_pop_len,
+                       const double* d_pop_stats, const int32_t* d_order, const int32_t* d_elite_cells,
+                       int32_t elite_len, const double* d_elite_stats, int32_t* d_out_cells, int32_t* d_out_len,
+                       double* d_out_stats, int32_t* d_status) {
+  if (!h) return -2;
+  if (!h->mpa_ready) return failmsg(h, "pf_mpa_phase_batch: call pf_mpa_setup first");
+  if (phase < 1 || phase > 3 || n < 0 || path_cap < 2 || !d_pop_cells || !d_pop_len || !d_pop_stats || !d_order ||
+      !d_elite_cells || !d_elite_stats || !d_out_cells || !d_out_len || !d_out_stats || !d_status) return failmsg(h, "pf_mpa_phase_batch: bad arguments");
+  MpaPhaseArgs a;
+  a.c = make_common(h, h->mpp.allow_diag, h->mpp.restrict_corner, 16, 0);
+  if (make_scorep(h, &h->mps, &a.sp)) return -1;
+  a.m = mpa_dev(h); a.phase = phase; a.iter = iter; a.CF = CF; a.seed = seed; a.agent0 = agent0; a.n = n; a.path_cap = path_cap;
+  a.pop_cells = d_pop_cells; a.pop_len = d_pop_len; a.pop_stats = d_pop_stats; a.order = d_order;
+  a.elite_cells = d_elite_cells; a.elite_len = elite_len;
+  a.elite_stats = d_elite_stats;
+  a.out_cells = d_out_cells; a.out_len = d_out_len; a.out_stats = d_out_stats; a.status = d_status;
+  a.ex_idx = nullptr; a.ex_levy = nullptr; a.ex_scale = nullptr; a.ex_agent = nullptr;
+  return launch_with_retry(h, k_mpa_phase, a, n);
+}
+
+int pf_mpa_rebuild_batch(pf_handle* h, int32_t iter, uint64_t seed, int32_t n, int32_t path_cap,
+                         const int32_t* d_pop_cells, const int32_t* d_pop_len, const double* d_pop_stats,
+                         const int32_t* d_elite_cells, int32_t elite_len, const int32_t* d_idx,
+                         const int32_t* d_is_levy, const double* d_scale, const int32_t* d_agent,
+                         int32_t* d_out_cells, int32_t* d_out_len, double* d_out_stats, int32_t* d_status) {
+  if (!h) return -2;
+  if (!h->mpa_ready) return failmsg(h, "pf_mpa_rebuild_batch: call pf_mpa_setup first");
+  if (n < 0 || path_cap < 2 || !d_pop_cells || !d_pop_len || !d_pop_stats || !d_elite_cells || !d_idx || !d_is_levy ||
+      !d_scale || !d_agent || !d_out_cells || !d_out_len || !d_out_stats || !d_status) return failmsg(h, "pf_mpa_rebuild_batch: bad arguments");
+  MpaPhaseArgs a;
+  a.c = make_common(h, h->mpp.allow_diag, h->mpp.restrict_corner, 16, 0);
+  if (make_scorep(h, &h->mps, &a.sp)) return -1;
+  a.m = mpa_dev(h); a.phase = 0; a.iter = iter; a.CF = 0.0; a.seed = seed; a.agent0 = 0; a.n = n; a.path_cap = path_cap;
+  a.pop_cells = d_pop_cells; a.pop_len = d_pop_len; a.pop_stats = d_pop_stats; a.order = nullptr;
+  a.elite_cells = d_elite_cells; a.elite_len = elite_len; a.elite_stats = d_pop_stats;
+  a.out_cells = d_out_cells; a.out_len = d_out_len; a.out_stats = d_out_stats; a.status = d_status;
+  a.ex_idx = d_idx; a.ex_levy = d_is_levy; a.ex_scale = d_scale; a.ex_agent = d_agent;
+  return launch_with_retry(h, k_mpa_phase, a, n);
+}
+
+int pf_mpa_fads_batch(pf_handle* h, double CF, int32_t iter, uint64_t seed, int32_t agent0, int32_t n, int32_t path_cap,
+                      const int32_t* d_order, int32_t* d_pop_cells, int32_t* d_pop_len, double* d_pop_stats, int32_t* d_status) {
+  if (!h) return -2;
+  if (!h->mpa_ready) return failmsg(h, "pf_mpa_fads_batch: call pf_mpa_setup first");
+  if (n < 0 || path_cap < 2 || !d_pop_cells || !d_pop_len || !d_pop_stats || !d_status) return failmsg(h, "pf_mpa_fads_batch: bad arguments");
+  CK(hipSetDevice(h->device));
+  if (h->tmp_cap < path_cap) {
+    if (h->d_tmp) CK(hipFree(h->d_tmp));
+    CK(hipMalloc(&h->d_tmp, sizeof(int) * (size_t)h->nslots * path_cap));
+    h->tmp_cap = path_cap;
+  }
+  MpaFadsArgs a;
+  a.c = make_common(h, h->mpp.allow_diag, h->mpp.restrict_corner, 16, 0);
+  if (make_scorep(h, &h->mps, &a.sp)) return -1;
+  a.m = mpa_dev(h); a.iter = iter; a.CF = CF; a.seed = seed; a.agent0 = agent0; a.n = n; a.path_cap = path_cap;
+  a.pop_cells = d_pop_cells; a.pop_len = d_pop_len; a.pop_stats = d_pop_stats; a.order = d_order;
+  a.tmp_cells = h->d_tmp; a.status = d_status;
+  return launch_with_retry(h, k_mpa_fads, a, n);
+}
+
+int pf_mpa_memory(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_order, int32_t agent0,
+                  const int32_t* d_cand_cells, const int32_t* d_cand_len, const double* d_cand_stats,
+                  int32_t* d_pop_cells, int32_t* d_pop_len, double* d_pop_stats) {
+  if (!h) return -2;
+  if (n <= 0) return 0;
+  CK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(k_mpa_memory, dim3(n), dim3(64), 0, h->stream, n, path_cap, d_order, agent0, d_cand_cells, d_cand_len,
+                     d_cand_stats, d_pop_cells, d_pop_len, d_pop_stats);
+  CK(hipGetLastError());
+  CK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,254 @@
+"""Engine: one (device, grid) handle of libpathfit.so with numpy-friendly batch calls.
+
+Device buffers are explicit (``DevBuf``) so that populations stay resident in
+HBM between calls; the ``*_host`` conveniences stage numpy arrays for the
+facades and tests.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Counters, MaacoParams, MpaParams, PathfitError, ScoreParams
+
+INF = float("inf")
+ST_OK, ST_INFEASIBLE, ST_STEP_CAP, ST_OVERFLOW, ST_KEPT = 0, 1, 2, 3, 4
+
+
+class DevBuf:
+    """A typed device allocation owned by an Engine."""
+
+    def __init__(self, eng, shape, dtype):
+        self.eng = eng
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = C.c_void_p()
+        eng._ck(eng.L.pf_dev_alloc(eng.h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        a = np.ascontiguousarray(arr, self.dtype)
+        assert a.nbytes <= self.nbytes, (a.nbytes, self.nbytes)
+        if a.nbytes:
+            self.eng._ck(self.eng.L.pf_h2d(self.eng.h, self.ptr, a.ctypes.data, a.nbytes))
+        return self
+
+    def download(self, count=None):
+        out = np.empty(self.shape if count is None else (count,), self.dtype)
+        if out.nbytes:
+            self.eng._ck(self.eng.L.pf_d2h(self.eng.h, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def zero(self):
+        self.eng._ck(self.eng.L.pf_memset(self.eng.h, self.ptr, 0, self.nbytes))
+        return self
+
+    def at(self, elem_offset):
+        return self.ptr + int(elem_offset) * self.dtype.itemsize
+
+    def free(self):
+        if self.ptr:
+            self.eng.L.pf_dev_free(self.eng.h, self.ptr)
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def score_params(variant=0, restrict_policy=True, w_turn=0.1, w_safe=0.05, min_safe=1.5, diag_pen=1000.0):
+    return ScoreParams(int(variant), int(bool(restrict_policy)), float(w_turn), float(w_safe), float(min_safe),
+                       float(diag_pen))
+
+
+class Engine:
+    def __init__(self, grid, device=0):
+        g = np.ascontiguousarray(np.asarray(grid), dtype=np.int64)
+        if g.ndim != 2:
+            raise ValueError("grid must be 2-D")
+        self.R, self.C = (int(v) for v in g.shape)
+        self.grid_u8 = np.ascontiguousarray(np.clip(g, 0, 255).astype(np.uint8))
+        self.L = _lib.lib()
+        h = C.c_void_p()
+        rc = self.L.pf_create(self.grid_u8.ctypes.data, self.R, self.C, int(device), C.byref(h))
+        if rc != 0:
+            raise PathfitError(self.L.pf_last_error(None).decode())
+        self.h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise PathfitError(self.L.pf_last_error(self.h).decode())
+
+    def buf(self, shape, dtype):
+        return DevBuf(self, shape, dtype)
+
+    def put(self, arr, dtype=None):
+        a = np.ascontiguousarray(arr, dtype)
+        return DevBuf(self, a.shape if a.ndim else (1,), a.dtype).upload(a)
+
+    def counters(self):
+        c = Counters()
+        self._ck(self.L.pf_get_counters(self.h, C.byref(c)))
+        return {n: getattr(c, n) for n, _ in Counters._fields_}
+
+    def last_kernel_ms(self):
+        return float(self.L.pf_last_kernel_ms(self.h))
+
+    def default_path_cap(self):
+        return min(self.R * self.C, 8 * (self.R + self.C) + 64)
+
+    # ------------------------------------------------------------------ K2
+    def astar_batch(self, variant, d_start, d_target, n, path_cap, d_cells, d_len, d_status, d_avoid_off=None,
+                    d_avoid_cells=None, d_counters=None, allow_diag=True, restrict_corner=True):
+        self._ck(self.L.pf_astar_batch(self.h, variant, int(allow_diag), int(restrict_corner), n, d_start.ptr,
+                                       d_target.ptr, d_avoid_off.ptr if d_avoid_off else None,
+                                       d_avoid_cells.ptr if d_avoid_cells else None, path_cap, d_cells.ptr,
+                                       d_len.ptr, d_status.ptr, d_counters.ptr if d_counters else None))
+
+    def astar_host(self, variant, starts, targets, avoid_lists=None, path_cap=None, allow_diag=True,
+                   restrict_corner=True, want_counters=False):
+        """-> (list of path arrays, status array[, counters n x 4])."""
+        n = len(starts)
+        cap = int(path_cap or self.default_path_cap())
+        ds, dt = self.put(starts, np.int32), self.put(targets, np.int32)
+        dc, dl, dst = self.buf((max(n, 1), cap), np.int32), self.buf(max(n, 1), np.int32), self.buf(max(n, 1), np.int32)
+        doff = dav = None
+        if avoid_lists is not None:
+            off = np.zeros(n + 1, np.int64)
+            for i, a in enumerate(avoid_lists):
+                off[i + 1] = off[i] + (len(a) if a is not None else 0)
+            flat = np.concatenate([np.asarray(a, np.int32) for a in avoid_lists if a is not None and len(a)]) \
+                if off[-1] else np.zeros(1, np.int32)
+            doff, dav = self.put(off, np.int64), self.put(flat, np.int32)
+        dcnt = self.buf((max(n, 1), 4), np.int64) if want_counters else None
+        self.astar_batch(variant, ds, dt, n, cap, dc, dl, dst, doff, dav, dcnt, allow_diag, restrict_corner)
+        cells, lens, st = dc.download(), dl.download(), dst.download()
+        paths = [cells[i, :lens[i]].copy() for i in range(n)]
+        if want_counters:
+            return paths, st[:n], dcnt.download()[:n]
+        return paths, st[:n]
+
+    # ------------------------------------------------------------------ K1
+    def score_host(self, paths, sp):
+        n = len(paths)
+        cap = max([len(p) for p in paths] + [1])
+        cells = np.zeros((n, cap), np.int32)
+        lens = np.zeros(n, np.int32)
+        for i, p in enumerate(paths):
+            cells[i, :len(p)] = p
+            lens[i] = len(p)
+        dc, dl, ds = self.put(cells), self.put(lens), self.buf((n, 5), np.float64)
+        self._ck(self.L.pf_score_batch(self.h, C.byref(sp), n, cap, dc.ptr, dl.ptr, ds.ptr))
+        return ds.download()
+
+    # ------------------------------------------------------------------ K3
+    def decode_batch(self, n, W, start, target, path_cap, d_cells, d_len, d_status, d_wp_cells=None, d_wp_pos=None,
+                     sp=None, d_stats=None, allow_diag=True, restrict_corner=True):
+        self._ck(self.L.pf_decode_batch(self.h, int(allow_diag), int(restrict_corner), n, W,
+                                        d_wp_cells.ptr if d_wp_cells else None, d_wp_pos.ptr if d_wp_pos else None,
+                                        int(start), int(target), path_cap, d_cells.ptr, d_len.ptr, d_status.ptr,
+                                        C.byref(sp) if sp is not None else None, d_stats.ptr if d_stats else None))
+
+    def decode_host(self, start, target, wp_cells=None, wp_pos=None, sp=None, path_cap=None, allow_diag=True,
+                    restrict_corner=True):
+        """wp_cells int[n, W] or wp_pos float[n, W, 2] -> (paths, status, stats or None)."""
+        if wp_cells is not None:
+            wp = np.ascontiguousarray(wp_cells, np.int32)
+            n, W = wp.shape
+            dwc, dwp = self.put(wp.reshape(-1) if wp.size else np.zeros(1, np.int32)), None
+        else:
+            wp = np.ascontiguousarray(wp_pos, np.float64)
+            n, W = wp.shape[0], wp.shape[1]
+            dwc, dwp = None, self.put(wp.reshape(-1) if wp.size else np.zeros(1))
+        cap = int(path_cap or self.default_path_cap())
+        dc, dl, dst = self.buf((n, cap), np.int32), self.buf(n, np.int32), self.buf(n, np.int32)
+        dstat = self.buf((n, 5), np.float64) if sp is not None else None
+        self.decode_batch(n, W, start, target, cap, dc, dl, dst, dwc, dwp, sp, dstat, allow_diag, restrict_corner)
+        cells, lens, st = dc.download(), dl.download(), dst.download()
+        paths = [cells[i, :lens[i]].copy() for i in range(n)]
+        return paths, st, (dstat.download() if dstat is not None else None)
+
+    # ------------------------------------------------------------------ K6
+    def pso_update(self, n, W, w, c1, c2, max_vel, d_pos, d_vel, d_pbest, d_gbest, seed, it, agent0=0):
+        self._ck(self.L.pf_pso_update(self.h, n, W, w, c1, c2, max_vel, d_pos.ptr, d_vel.ptr, d_pbest.ptr,
+                                      d_gbest.ptr, int(seed), int(it), int(agent0)))
+
+    def pso_pbest(self, n, W, d_pos, d_stats, d_len, d_pbest, d_pbest_fit, d_improved):
+        self._ck(self.L.pf_pso_pbest(self.h, n, W, d_pos.ptr, d_stats.ptr, d_len.ptr, d_pbest.ptr, d_pbest_fit.ptr,
+                                     d_improved.ptr))
+
+    # ------------------------------------------------------------------ K4/K5
+    def maaco_setup(self, params):
+        self._mp = params
+        self._ck(self.L.pf_maaco_setup(self.h, C.byref(params)))
+
+    def maaco_walk(self, it, seed, ant0, n, path_cap, d_cells, d_len, d_plen, d_turns, d_status):
+        self._ck(self.L.pf_maaco_walk_batch(self.h, int(it), int(seed), int(ant0), n, path_cap, d_cells.ptr,
+                                            d_len.ptr, d_plen.ptr, d_turns.ptr, d_status.ptr))
+
+    def maaco_evaporate(self):
+        self._ck(self.L.pf_maaco_evaporate(self.h))
+
+    def maaco_deposit(self, n, path_cap, d_cells, d_len, d_plen):
+        self._ck(self.L.pf_maaco_deposit(self.h, n, path_cap, d_cells.ptr, d_len.ptr, d_plen.ptr))
+
+    def maaco_clip(self, best_len_overall):
+        self._ck(self.L.pf_maaco_clip(self.h, float(best_len_overall)))
+
+    def maaco_get_pheromone(self):
+        t = np.empty((self.R, self.C), np.float64)
+        self._ck(self.L.pf_maaco_get_pheromone(self.h, t.ctypes.data))
+        return t
+
+    def maaco_set_pheromone(self, tau):
+        t = np.ascontiguousarray(tau, np.float64)
+        assert t.size == self.R * self.C
+        self._ck(self.L.pf_maaco_set_pheromone(self.h, t.ctypes.data))
+
+    def maaco_tau_ptr(self):
+        return self.L.pf_maaco_tau_dev(self.h)
+
+    def maaco_best_scan(self, plen, turns, idx0, best_len, best_turns, best_idx):
+        plen = np.ascontiguousarray(plen, np.float64)
+        turns = np.ascontiguousarray(turns, np.int32)
+        bl, bt, bi = C.c_double(best_len), C.c_double(best_turns), C.c_int32(best_idx)
+        self._ck(self.L.pf_maaco_best_scan(len(plen), plen.ctypes.data, turns.ctypes.data, int(idx0), C.byref(bl),
+                                           C.byref(bt), C.byref(bi)))
+        return bl.value, bt.value, bi.value
+
+    # ------------------------------------------------------------------ K7
+    def mpa_setup(self, mp, sp):
+        self._ck(self.L.pf_mpa_setup(self.h, C.byref(mp), C.byref(sp)))
+
+    def mpa_phase(self, phase, CF, it, seed, agent0, n, path_cap, d_pop_cells, d_pop_len, d_pop_stats, d_order,
+                  elite_cells_ptr, elite_len, elite_stats_ptr, d_out_cells, d_out_len, d_out_stats, d_status):
+        self._ck(self.L.pf_mpa_phase_batch(self.h, int(phase), float(CF), int(it), int(seed), int(agent0), n,
+                                           path_cap, d_pop_cells.ptr, d_pop_len.ptr, d_pop_stats.ptr, d_order.ptr,
+                                           elite_cells_ptr, int(elite_len), elite_stats_ptr, d_out_cells.ptr,
+                                           d_out_len.ptr, d_out_stats.ptr, d_status.ptr))
+
+    def mpa_fads(self, CF, it, seed, agent0, n, path_cap, d_order, d_pop_cells, d_pop_len, d_pop_stats, d_status):
+        self._ck(self.L.pf_mpa_fads_batch(self.h, float(CF), int(it), int(seed), int(agent0), n, path_cap,
+                                          d_order.ptr if d_order else None, d_pop_cells.ptr, d_pop_len.ptr,
+                                          d_pop_stats.ptr, d_status.ptr))
+
+    def mpa_memory(self, n, path_cap, d_order, agent0, d_cand_cells, d_cand_len, d_cand_stats, d_pop_cells,
+                   d_pop_len, d_pop_stats):
+        self._ck(self.L.pf_mpa_memory(self.h, n, path_cap, d_order.ptr, int(agent0), d_cand_cells.ptr,
+                                      d_cand_len.ptr, d_cand_stats.ptr, d_pop_cells.ptr, d_pop_len.ptr,
+                                      d_pop_stats.ptr))

@@ -1,0 +1,234 @@
+"""HIP kernels (through the C-ABI) == CPU oracle == golden vectors of the
+unmodified reference.  Cell-index paths and fp64 stats are compared bit for bit
+(the north-star tolerance for fp32 fitness, 1e-5 relative, is met with zero
+error)."""
+import math
+
+import numpy as np
+import pytest
+
+import golden_io as gio
+
+pytestmark = pytest.mark.gpu
+
+_eng = {}
+
+
+def eng(name):
+    from pathfit.engine import Engine
+    import pf_oracle as po
+    if name not in _eng:
+        if name.startswith("up"):          # "up2:g256" -> np.kron upsample
+            k, base = name[2:].split(":")
+            g0, _, _ = gio.grid(base)
+            g = gio.upsample(g0, int(k))
+            s, t = 0, g.size - 1
+        else:
+            g, s, t = gio.grid(name)
+        _eng[name] = (Engine(g), po.Oracle(g), s, t, g)
+    return _eng[name]
+
+
+def test_device_sqrt_is_correctly_rounded():
+    e, _, _, _, _ = eng("fig7")
+    # every dr^2+dc^2 reachable on a 1024^2 grid is < 2^21; test all n <= 2^21 + large sample up to 2*4095^2
+    n1 = np.arange(0, 1 << 21, dtype=np.int64)
+    rng = np.random.default_rng(0)
+    n2 = rng.integers(0, 2 * 4095 ** 2, size=1 << 20, dtype=np.int64)
+    for arr in (n1, n2):
+        d_in, d_out = e.put(arr), e.buf(arr.size, np.float64)
+        e._ck(e.L.pf_selftest_sqrt(e.h, arr.size, d_in.ptr, d_out.ptr))
+        assert np.array_equal(d_out.download(), np.sqrt(arr.astype(np.float64)))
+
+
+def test_device_rng_matches_cpython():
+    e, _, _, _, _ = eng("fig7")
+    z = gio.load("rng")
+    for i, key in enumerate(z["keys"]):
+        k = [int(v) for v in key]
+        du, df, di = e.buf(8, np.uint64), e.buf(36, np.float64), e.buf(37, np.int64)
+        e._ck(e.L.pf_selftest_rng(e.h, k[0], k[1], k[2], k[3], du.ptr, df.ptr, di.ptr))
+        u, f, ii = du.download(), df.download(), di.download()
+        assert np.array_equal(u, z[f"k{i}_next64"])
+        assert np.array_equal(f[:8], z[f"k{i}_random"])
+        assert np.array_equal(f[8:28], z[f"k{i}_normal"])
+        assert np.array_equal(f[28:36], z[f"k{i}_uniform"])
+        assert np.array_equal(ii[:24], z[f"k{i}_randint"])
+        assert np.array_equal(ii[24:34], z[f"k{i}_choice"])
+        assert [int(ii[34]), int(ii[35]), int(ii[36])] == [int(z[f"k{i}_randint_draws"]), int(z[f"k{i}_normal_draws"]),
+                                                           int(z[f"k{i}_choice_draws"])]
+
+
+def test_astar_golden_both_variants():
+    z = gio.load("astar_cases")
+    names = [str(s) for s in z["grid_names"]]
+    for gid, gname in enumerate(names):
+        e, o, _, _, _ = eng(gname)
+        for variant in (0, 1):
+            idx = [i for i in range(len(z["start"])) if z["grid_id"][i] == gid and z["variant"][i] == variant]
+            avoid = [gio.csr_get(z["avoid_off"], z["avoid"], i) if z["has_avoid"][i] else None for i in idx]
+            paths, st, cnt = e.astar_host(variant, z["start"][idx], z["target"][idx], avoid, want_counters=True)
+            for j, i in enumerate(idx):
+                want = gio.csr_get(z["path_off"], z["path"], i)
+                assert st[j] != 3
+                assert np.array_equal(paths[j], want), (gname, variant, i)
+                if len(want) > 1:
+                    assert cnt[j, 0] == z["pops"][i], (gname, variant, i, cnt[j], z["pops"][i])
+                    # oracle cross-check of the counter definitions (pushes incl. decrease-key re-pushes)
+                    _, ost = o.astar(int(z["start"][i]), int(z["target"][i]), avoid[j], variant)
+                    assert cnt[j, 1] == ost[1] + (ost[3] if variant == 0 else 0)
+                    assert cnt[j, 3] == ost[4]
+
+
+def test_astar_random_512_vs_oracle():
+    e, o, s, t, g = eng("up2:g256")
+    rnd = np.random.default_rng(5)
+    free = np.flatnonzero(g.reshape(-1) != 1)
+    n = 48
+    starts = rnd.choice(free, n); targets = rnd.choice(free, n)
+    starts[0], targets[0] = s, t                       # corner to corner: 91 044 pops in the reference
+    avoid = [rnd.choice(free, 200) if i % 2 else None for i in range(n)]
+    for variant in (0, 1):
+        paths, st, cnt = e.astar_host(variant, starts, targets, avoid, path_cap=8192, want_counters=True)
+        for i in range(n):
+            want, ost = o.astar(int(starts[i]), int(targets[i]), avoid[i], variant)
+            assert st[i] != 3 and np.array_equal(paths[i], want), (variant, i)
+            if len(want) > 1:
+                assert cnt[i, 0] == ost[0]
+        if variant == 0:
+            assert cnt[0, 0] == 91044
+
+
+def test_decode_and_score_golden():
+    from pathfit.engine import score_params
+    z = gio.load("decode_cases")
+    names = [str(s) for s in z["grid_names"]]
+    for gid, gname in enumerate(names):
+        e, o, s, t, _ = eng(gname)
+        for wname, w in (("main", z["main_w"]), ("def", z["def_w"])):
+            sp = score_params(0, True, w[0], w[1], w[2], w[3])
+            for kind in (0, 1):
+                idx = [i for i in range(len(z["kind"])) if z["grid_id"][i] == gid and str(z["weights"][i]) == wname
+                       and z["kind"][i] == kind]
+                byW = {}
+                for i in idx:
+                    wp = gio.csr_get(z["wp_off"], z["wp"], i)
+                    byW.setdefault(len(wp) if kind == 0 else len(wp) // 2, []).append(i)
+                for W, ids in byW.items():
+                    if kind == 0:
+                        wp = np.array([gio.csr_get(z["wp_off"], z["wp"], i) for i in ids]).astype(np.int32)
+                        paths, st, stats = e.decode_host(s, t, wp_cells=wp, sp=sp)
+                    else:
+                        wp = np.array([gio.csr_get(z["wp_off"], z["wp"], i) for i in ids]).reshape(len(ids), W, 2)
+                        paths, st, stats = e.decode_host(s, t, wp_pos=wp, sp=sp)
+                    for j, i in enumerate(ids):
+                        want = gio.csr_get(z["path_off"], z["path"], i)
+                        assert st[j] != 3 and np.array_equal(paths[j], want), (gname, wname, kind, i)
+                        assert np.array_equal(stats[j], z["stats"][i]), (gname, i, stats[j], z["stats"][i])
+    # stand-alone scoring incl. the hand-built corner-cutting path
+    e, o, s, t, _ = eng("fig7")
+    i = int(np.flatnonzero(z["kind"] == 2)[0])
+    w = z["main_w"]
+    got = e.score_host([gio.csr_get(z["path_off"], z["path"], i), np.zeros(0, np.int32)],
+                       score_params(0, True, w[0], w[1], w[2], w[3]))
+    assert np.array_equal(got[0], z["stats"][i]) and got[0][3] > 0
+    assert got[1][0] == math.inf and got[1][4] == math.inf and got[1][1] == 0
+
+
+def test_decode_random_512_vs_oracle():
+    from pathfit.engine import score_params
+    e, o, s, t, g = eng("up2:g256")
+    rnd = np.random.default_rng(11)
+    free = np.flatnonzero(g.reshape(-1) != 1)
+    n, W = 24, 5
+    wp = rnd.choice(free, (n, W)).astype(np.int32)
+    sp = score_params(0, True, 0.3, 0.8, 1.8, 100.0)
+    paths, st, stats = e.decode_host(s, t, wp_cells=wp, sp=sp, path_cap=16384)
+    feas = 0
+    for i in range(n):
+        want, _ = o.decode(s, t, wp[i])
+        assert st[i] != 3 and np.array_equal(paths[i], want), i
+        assert np.array_equal(stats[i], o.score(want, 0, 0.3, 0.8, 1.8, True, 100.0)), i
+        feas += len(want) > 0
+    assert feas >= 3
+
+
+def test_pso_update_golden():
+    e, _, _, _, _ = eng("fig7")
+    z = gio.load("pso_update")
+    for i in range(len(z["seed"])):
+        w, c1, c2, mv = z["params"][i]
+        dp, dv = e.put(z["pos0"][i]), e.put(z["vel0"][i])
+        e.pso_update(1, 5, w, c1, c2, mv, dp, dv, e.put(z["pbest"][i]), e.put(z["gbest"][i]), int(z["seed"][i]),
+                     int(z["it"][i]), 0)
+        assert np.array_equal(dp.download(), z["pos1"][i]) and np.array_equal(dv.download(), z["vel1"][i]), i
+
+
+def test_maaco_golden_walks_and_pheromone():
+    from pathfit._lib import MaacoParams
+    z = gio.load("maaco_cases")
+    bp = z["base_params"]
+    for ri, gname in enumerate(z["runs_grid"]):
+        beta, n_ants, n_it, K, seed = z["runs_num"][ri]
+        n_ants, n_it, K, seed = int(n_ants), int(n_it), int(K), int(seed)
+        e, o, s, t, _ = eng(str(gname))
+        e.maaco_setup(MaacoParams(bp[0], beta, bp[1], bp[2], bp[3], bp[4], bp[5], bp[6], bp[7], bp[8], K, s, t))
+        assert np.array_equal(e.maaco_get_pheromone(), z[f"r{ri}_tau0"])
+        cap = 4 * (e.R + e.C) + 64 if e.R > 20 else 400
+        dc, dl, dp, dt, ds = e.buf((n_ants, cap), np.int32), e.buf(n_ants, np.int32), e.buf(n_ants, np.float64), \
+            e.buf(n_ants, np.int32), e.buf(n_ants, np.int32)
+        best, k = math.inf, 0
+        for it in range(1, n_it + 1):
+            e.maaco_walk(it, seed, 0, n_ants, cap, dc, dl, dp, dt, ds)
+            cells, lens, plen, turns, st = dc.download(), dl.download(), dp.download(), dt.download(), ds.download()
+            for ant in range(n_ants):
+                want = gio.csr_get(z[f"r{ri}_path_off"], z[f"r{ri}_path"], k)
+                assert st[ant] != 3 and np.array_equal(cells[ant, :lens[ant]], want), (ri, it, ant)
+                assert plen[ant] == z[f"r{ri}_len"][k] and turns[ant] == z[f"r{ri}_turns"][k], (ri, it, ant)
+                k += 1
+            best = min(best, plen.min())
+            e.maaco_evaporate(); e.maaco_deposit(n_ants, cap, dc, dl, dp); e.maaco_clip(best)
+            if f"r{ri}_tau" in z:
+                assert np.array_equal(e.maaco_get_pheromone(), z[f"r{ri}_tau"][it - 1]), (ri, it)
+        if f"r{ri}_tau_sum" in z:
+            m = e.maaco_get_pheromone()
+            assert np.array_equal(m[:4], z[f"r{ri}_tau_last_rows"])
+            assert np.array_equal(np.array([m.sum(), m.max(), m.min()]), z[f"r{ri}_tau_sum"])
+
+
+def test_mpa_rebuild_golden():
+    from pathfit._lib import MpaParams
+    from pathfit.engine import score_params
+    z = gio.load("mpa_cases")
+    names = [str(s) for s in z["grid_names"]]
+    seed, it = (int(v) for v in z["seed_it"])
+    for gid, gname in enumerate(names):
+        e, o, s, t, _ = eng(gname)
+        for bi, beta in enumerate((1.5, 2.0)):
+            ids = [i for i in range(len(z["idx"])) if z["grid_id"][i] == gid and z["beta"][i] == beta]
+            sp = score_params(1, True, 0.1, 0.05, 1.5, 1000.0)
+            e.mpa_setup(MpaParams(0.5, beta, float(z["sigma"][bi]), 0.2, len(ids), s, t, 1, 1), sp)
+            # group by elite path (the batch call takes one elite)
+            groups = {}
+            for i in ids:
+                groups.setdefault(gio.csr_get(z["el_off"], z["el_path"], i).tobytes(), []).append(i)
+            for _, gi in groups.items():
+                n = len(gi)
+                cap = 4 * (e.R + e.C) + 64 if e.R > 20 else 400
+                pop = np.zeros((n, cap), np.int32); plen = np.zeros(n, np.int32)
+                for j, i in enumerate(gi):
+                    p = gio.csr_get(z["in_off"], z["in_path"], i)
+                    pop[j, :len(p)] = p; plen[j] = len(p)
+                el = gio.csr_get(z["el_off"], z["el_path"], gi[0])
+                pstats = np.array([o.score(pop[j, :plen[j]], 1, 0.1, 0.05, 1.5, True, 1000.0) for j in range(n)])
+                dpop, dlen, dstats, del_ = e.put(pop), e.put(plen), e.put(pstats), e.put(el)
+                oc, ol, os_, ost = e.buf((n, cap), np.int32), e.buf(n, np.int32), e.buf((n, 5), np.float64), e.buf(n, np.int32)
+                e._ck(e.L.pf_mpa_rebuild_batch(e.h, it, seed, n, cap, dpop.ptr, dlen.ptr, dstats.ptr, del_.ptr, len(el),
+                                               e.put(z["idx"][gi], np.int32).ptr, e.put(z["is_levy"][gi], np.int32).ptr,
+                                               e.put(z["scale"][gi], np.float64).ptr, e.put(z["agent"][gi], np.int32).ptr,
+                                               oc.ptr, ol.ptr, os_.ptr, ost.ptr))
+                cells, lens, stats, st = oc.download(), ol.download(), os_.download(), ost.download()
+                for j, i in enumerate(gi):
+                    want = gio.csr_get(z["out_off"], z["out_path"], i)
+                    assert st[j] != 3 and np.array_equal(cells[j, :lens[j]], want), (gname, beta, i, st[j])
+                    assert np.array_equal(stats[j], z["stats"][i]), (gname, beta, i)
