@@ -72,7 +72,7 @@ typedef struct {
 
 /* per-launch counters (roofline numerators) */
 typedef struct {
-  int64_t pops, pushes, nbr_examined, path_cells, steps, candidates, stale_pops, overflow_agents;
+  int64_t pops, pushes, nbr_examined, path_cells, steps, candidates, decrease_keys, overflow_agents;
 } pf_counters;
 
 /* ---- lifecycle ---------------------------------------------------- */

@@ -23,7 +23,7 @@ using namespace pf;
 // device-side launch parameter blocks
 // ===========================================================================
 struct DevCounters {
-  unsigned long long pops, pushes, nbr, path_cells, steps, candidates, stale, overflow;
+  unsigned long long pops, pushes, nbr, path_cells, steps, candidates, deckey, overflow;
 };
 
 struct Common {
@@ -40,18 +40,16 @@ PF_DEV Open make_open(char* smem, int S) {
   Open O;
   O.lf = (double*)smem;
   O.lg = O.lf + 64 * S;
-  O.sf = O.lg + 64 * S;
-  O.sg = O.sf + 8;
-  O.lc = (int*)(O.sg + 8);
-  O.sc = O.lc + 64 * S;
+  O.lc = (int*)(O.lg + 64 * S);
   O.S = S;
   return O;
 }
-static size_t open_bytes(int S) { return (size_t)64 * S * 20 + 8 * 20; }
+static size_t open_bytes(int S) { return (size_t)64 * S * 20; }
 
 PF_DEV Slot slot_load(const Common& c, int RC) {
   Slot s;
   s.rec = c.rec + (size_t)blockIdx.x * RC;
+  s.mm = c.G.mm;
   s.tag = c.slot_state[2 * blockIdx.x];
   s.avoid_ep = c.slot_state[2 * blockIdx.x + 1];
   return s;
@@ -62,11 +60,7 @@ PF_DEV void slot_store(const Common& c, const Slot& s, int lane) {
 // new agent evaluation: fresh avoid epoch; wipe the slot before an epoch can wrap
 PF_DEV void slot_begin_eval(Slot& s, int RC, int lane) {
   s.avoid_ep += 1;
-  if (s.avoid_ep >= 0xFFFFF0u || s.tag >= 0xFFFFFF00u) {
-    for (int i = lane; i < RC; i += 64) { Rec z; z.g = 0.0; z.tag = 0; z.meta = 0; s.rec[i] = z; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    s.avoid_ep = 1; s.tag = 1;
-  }
+  if (s.avoid_ep >= 0x7FF0u || s.tag >= 0xFFFFF0u) slot_wipe(s, RC, lane);
 }
 PF_DEV int next_work(int* work, int lane) {
   int a = 0;
@@ -76,7 +70,7 @@ PF_DEV int next_work(int* work, int lane) {
 PF_DEV void flush_counters(DevCounters* c, const AStat& st, unsigned long long cells, unsigned long long ovf, int lane) {
   if (lane == 0) {
     atomicAdd(&c->pops, st.pops); atomicAdd(&c->pushes, st.pushes); atomicAdd(&c->nbr, st.nbr);
-    atomicAdd(&c->stale, st.stale); atomicAdd(&c->path_cells, cells); atomicAdd(&c->overflow, ovf);
+    atomicAdd(&c->deckey, st.deckey); atomicAdd(&c->path_cells, cells); atomicAdd(&c->overflow, ovf);
   }
 }
 
@@ -106,6 +100,13 @@ __global__ void k_grid_prep(const uint8_t* occ, int R, int C, uint8_t* mm_r1, ui
     if (d2 < best) best = d2;
   }
   d2near[cell] = (uint8_t)best;
+}
+
+// search scratch initialisation: every record carries its cell's static move mask
+__global__ void k_slot_init(Rec* rec, const uint8_t* mm, int RC, size_t total) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) { Rec z; z.g = 0.0; z.tagmm = mm[i % (size_t)RC]; z.meta = 0; rec[i] = z; }
 }
 
 // ===========================================================================
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(64) void k_astar_batch(AstarArgs p) {
         p.counters[4 * a + 2] = st.max_open; p.counters[4 * a + 3] = (long long)st.nbr;
       }
     }
-    tot.pops += st.pops; tot.pushes += st.pushes; tot.nbr += st.nbr; tot.stale += st.stale;
+    tot.pops += st.pops; tot.pushes += st.pushes; tot.nbr += st.nbr; tot.deckey += st.deckey;
     cells += rc == 0 ? n : 0; ovf += rc == 3;
   }
   slot_store(p.c, s, lane);
@@ -724,6 +725,7 @@ struct pf_handle {
           *d_d2near = nullptr;
   std::vector<uint8_t> h_occ;
   int nslots = 0;
+  int rec_policy = -1;   // which move-mask variant the search records currently carry
   Rec* d_rec = nullptr;
   uint32_t* d_slot_state = nullptr;
   int* d_work = nullptr;
@@ -836,21 +838,30 @@ float pf_last_kernel_ms(pf_handle* h) { return h->last_ms; }
 
 // ---- scratch / launch helpers ----------------------------------------------
 static const int kSlotsPerCU = 8;
-static int ensure_slots(pf_handle* h) {
-  if (h->d_rec) return 0;
+static int ensure_slots(pf_handle* h, int allow_diag = 1, int restrict_corner = 1) {
   CK(hipSetDevice(h->device));
-  hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, h->device));
-  int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  h->nslots = cus * kSlotsPerCU;
-  size_t bytes = (size_t)h->nslots * h->RC * sizeof(Rec);
-  // keep the search scratch under ~64 GiB of the 288 GB HBM
-  while (bytes > (64ull << 30) && h->nslots > cus) { h->nslots /= 2; bytes = (size_t)h->nslots * h->RC * sizeof(Rec); }
-  CK(hipMalloc(&h->d_rec, bytes));
-  CK(hipMemsetAsync(h->d_rec, 0, bytes, h->stream));
-  CK(hipMalloc(&h->d_slot_state, sizeof(uint32_t) * 2 * h->nslots));
-  std::vector<uint32_t> init(2 * h->nslots, 1u);
-  CK(hipMemcpyAsync(h->d_slot_state, init.data(), sizeof(uint32_t) * init.size(), hipMemcpyHostToDevice, h->stream));
-  CK(hipStreamSynchronize(h->stream));
+  if (!h->d_rec) {
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, h->device));
+    int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (!h->nslots) h->nslots = cus * kSlotsPerCU;
+    size_t bytes = (size_t)h->nslots * h->RC * sizeof(Rec);
+    // keep the search scratch under ~64 GiB of the 288 GB HBM
+    while (bytes > (64ull << 30) && h->nslots > cus) { h->nslots /= 2; bytes = (size_t)h->nslots * h->RC * sizeof(Rec); }
+    CK(hipMalloc(&h->d_rec, bytes));
+    CK(hipMalloc(&h->d_slot_state, sizeof(uint32_t) * 2 * h->nslots));
+  }
+  const int policy = (allow_diag ? 2 : 0) | (restrict_corner ? 1 : 0);
+  if (h->rec_policy != policy) {
+    // records embed the static move mask of this diagonal policy: (re)initialise all slots
+    Grid G = make_grid(h, allow_diag, restrict_corner);
+    const size_t total = (size_t)h->nslots * h->RC;
+    hipLaunchKernelGGL(k_slot_init, dim3(4096), dim3(256), 0, h->stream, h->d_rec, G.mm, h->RC, total);
+    CK(hipGetLastError());
+    std::vector<uint32_t> init(2 * h->nslots, 1u);
+    CK(hipMemcpyAsync(h->d_slot_state, init.data(), sizeof(uint32_t) * init.size(), hipMemcpyHostToDevice, h->stream));
+    CK(hipStreamSynchronize(h->stream));
+    h->rec_policy = policy;
+  }
   return 0;
 }
 static Common make_common(pf_handle* h, int allow_diag, int restrict_corner, int S, int retry) {
@@ -868,7 +879,7 @@ static int end_batch(pf_handle* h, DevCounters* dc) {
   CK(hipMemcpyAsync(dc, h->d_cnt, sizeof(DevCounters), hipMemcpyDeviceToHost, h->stream));
   CK(hipStreamSynchronize(h->stream));
   h->last.pops = dc->pops; h->last.pushes = dc->pushes; h->last.nbr_examined = dc->nbr; h->last.path_cells = dc->path_cells;
-  h->last.steps = dc->steps; h->last.candidates = dc->candidates; h->last.stale_pops = dc->stale; h->last.overflow_agents = dc->overflow;
+  h->last.steps = dc->steps; h->last.candidates = dc->candidates; h->last.decrease_keys = dc->deckey; h->last.overflow_agents = dc->overflow;
   return 0;
 }
 // LDS bin capacities tried in order; a retry pass re-runs only agents that overflowed
@@ -895,11 +906,11 @@ static int launch_with_retry(pf_handle* h, Kern kern, KArgs& args, int n) {
     if (end_batch(h, &dc)) return -1;
     float ms = 0.f; CK(hipEventElapsedTime(&ms, h->ev0, h->ev1)); ms_total += ms;
     total.pops += dc.pops; total.pushes += dc.pushes; total.nbr += dc.nbr; total.path_cells += dc.path_cells;
-    total.stale += dc.stale; total.overflow = dc.overflow;
+    total.deckey += dc.deckey; total.overflow = dc.overflow;
     if (dc.overflow == 0) break;
   }
   h->last.pops = total.pops; h->last.pushes = total.pushes; h->last.nbr_examined = total.nbr; h->last.path_cells = total.path_cells;
-  h->last.stale_pops = total.stale; h->last.overflow_agents = total.overflow; h->last.steps = 0; h->last.candidates = 0;
+  h->last.decrease_keys = total.deckey; h->last.overflow_agents = total.overflow; h->last.steps = 0; h->last.candidates = 0;
   h->last_ms = ms_total;
   return 0;
 }
@@ -933,7 +944,7 @@ int pf_astar_batch(pf_handle* h, int32_t variant, int32_t allow_diag, int32_t re
                    int32_t* d_status, int64_t* d_counters) {
   if (!h) return -2;
   if (n < 0 || path_cap < 1 || !d_start || !d_target || !d_cells || !d_len || !d_status) return failmsg(h, "pf_astar_batch: bad arguments");
-  if (ensure_slots(h)) return -1;
+  if (ensure_slots(h, allow_diag, restrict_corner)) return -1;
   AstarArgs a;
   a.c = make_common(h, allow_diag, restrict_corner, 16, 0);
   a.n = n; a.path_cap = path_cap; a.start = d_start; a.target = d_target;
@@ -972,7 +983,7 @@ int pf_decode_batch(pf_handle* h, int32_t allow_diag, int32_t restrict_corner, i
   if (n < 0 || W < 0 || path_cap < 1 || (!d_wp_cells && !d_wp_pos && W > 0) || !d_cells || !d_len || !d_status ||
       start < 0 || start >= h->RC || target < 0 || target >= h->RC || (sp && !d_stats))
     return failmsg(h, "pf_decode_batch: bad arguments");
-  if (ensure_slots(h)) return -1;
+  if (ensure_slots(h, allow_diag, restrict_corner)) return -1;
   DecodeArgs a;
   a.c = make_common(h, allow_diag, restrict_corner, 16, 0);
   a.do_score = sp != nullptr;
@@ -1206,7 +1217,7 @@ int pf_mpa_setup(pf_handle* h, const pf_mpa_params* p, const pf_score_params* sp
   if (!h) return -2;
   if (!p || !sp || p->start < 0 || p->start >= h->RC || p->target < 0 || p->target >= h->RC) return failmsg(h, "pf_mpa_setup: bad arguments");
   h->mpp = *p; h->mps = *sp; h->mpa_ready = true;
-  return ensure_slots(h);
+  return ensure_slots(h, p->allow_diag, p->restrict_corner);
 }
 static MpaDev mpa_dev(const pf_handle* h) {
   MpaDev m; m.P = h->mpp.P_const; m.levy_beta = h->mpp.levy_beta; m.sigma = h->mpp.levy_sigma; m.fads = h->mpp.FADs_rate;
@@ -1223,6 +1234,7 @@ int pf_mpa_phase_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uin
   if (!h->mpa_ready) return failmsg(h, "pf_mpa_phase_batch: call pf_mpa_setup first");
   if (phase < 1 || phase > 3 || n < 0 || path_cap < 2 || !d_pop_cells || !d_pop_len || !d_pop_stats || !d_order ||
       !d_elite_cells || !d_elite_stats || !d_out_cells || !d_out_len || !d_out_stats || !d_status) return failmsg(h, "pf_mpa_phase_batch: bad arguments");
+  if (ensure_slots(h, h->mpp.allow_diag, h->mpp.restrict_corner)) return -1;
   MpaPhaseArgs a;
   a.c = make_common(h, h->mpp.allow_diag, h->mpp.restrict_corner, 16, 0);
   if (make_scorep(h, &h->mps, &a.sp)) return -1;
@@ -1244,6 +1256,7 @@ int pf_mpa_rebuild_batch(pf_handle* h, int32_t iter, uint64_t seed, int32_t n, i
   if (!h->mpa_ready) return failmsg(h, "pf_mpa_rebuild_batch: call pf_mpa_setup first");
   if (n < 0 || path_cap < 2 || !d_pop_cells || !d_pop_len || !d_pop_stats || !d_elite_cells || !d_idx || !d_is_levy ||
       !d_scale || !d_agent || !d_out_cells || !d_out_len || !d_out_stats || !d_status) return failmsg(h, "pf_mpa_rebuild_batch: bad arguments");
+  if (ensure_slots(h, h->mpp.allow_diag, h->mpp.restrict_corner)) return -1;
   MpaPhaseArgs a;
   a.c = make_common(h, h->mpp.allow_diag, h->mpp.restrict_corner, 16, 0);
   if (make_scorep(h, &h->mps, &a.sp)) return -1;
@@ -1260,7 +1273,7 @@ int pf_mpa_fads_batch(pf_handle* h, double CF, int32_t iter, uint64_t seed, int3
   if (!h) return -2;
   if (!h->mpa_ready) return failmsg(h, "pf_mpa_fads_batch: call pf_mpa_setup first");
   if (n < 0 || path_cap < 2 || !d_pop_cells || !d_pop_len || !d_pop_stats || !d_status) return failmsg(h, "pf_mpa_fads_batch: bad arguments");
-  CK(hipSetDevice(h->device));
+  if (ensure_slots(h, h->mpp.allow_diag, h->mpp.restrict_corner)) return -1;
   if (h->tmp_cap < path_cap) {
     if (h->d_tmp) CK(hipFree(h->d_tmp));
     CK(hipMalloc(&h->d_tmp, sizeof(int) * (size_t)h->nslots * path_cap));

@@ -2,49 +2,53 @@
 //
 // Reference semantics (bit-exact pop order on the total order (f, g, (r,c))):
 //   VARIANT 0  AStarSolver.solve, astar.py:33-101  (closed set, decrease-key, cap 3RC)
-//   VARIANT 1  MPA._a_star,       MPA.py:106-151   (no closed set, stale (f,g) entries
-//              stay, popped nodes may be re-pushed, g from g_score, cap 2RC)
+//   VARIANT 1  MPA._a_star,       MPA.py:106-151   (no closed set, an open node keeps its
+//              old (f,g) entry when improved, popped nodes may be re-pushed,
+//              g from g_score, cap 2RC)
 //
-// Mapping.  The open list lives in LDS as 64 bins x S slots (SoA f/g/cell).
-// Lane b caches the lexicographic minimum of bin b in registers, so a pop is
-// one DPP min-reduction over the 64 cached f keys (ties resolved on g then
-// (r,c) by ballot), and only the winning bin is rescanned: one coalesced LDS
-// read of its <= S entries + one more reduction.  The 8 neighbours are
-// expanded by lanes 0..7 in parallel (the order of relaxations within one pop
-// cannot change the resulting open *set*), each with ONE 16-byte load of the
-// neighbour's record from this agent's HBM-resident scratch; lane 8 fetches the
-// popped cell's own record and lane 9 the static move mask in the same batch,
-// so every pop pays a single memory round trip.  Improved neighbours are pushed
-// round-robin into distinct bins through an 8-entry LDS staging area.
-//
-// VARIANT 0 uses lazy deletion: a decrease-key pushes a second entry; the
-// superseded one has a larger g than the record (or the cell is closed) when
-// it surfaces and is dropped without counting a step, which reproduces the
-// reference's in-place replace + heapify exactly (at most one *valid* entry
-// per node exists, and it always sorts before its stale twin).
+// Mapping (MI355X, wave64).  The open list lives in LDS as 64 bins x S slots
+// (SoA f/g/cell; a free slot holds f = +inf).  Lane b owns bin b: it keeps the
+// bin's occupancy bitmask and its lexicographic minimum in registers.
+//   pop     = min-reduction of the 64 cached f keys done as two passes of
+//             v_min_u32 with the DPP modifier (hi word, then lo word among the
+//             hi-ties) + ballot; ties on f are resolved on (g, (r,c)).  Only
+//             the winning bin is rescanned: one LDS read of its S slots by S
+//             lanes + one more (row-local when S == 16) reduction.
+//   expand  = the 8 neighbours are relaxed by 8 lanes in parallel (relaxations
+//             within one pop touch distinct nodes, so their order cannot change
+//             the open *set*).  Each lane issues ONE 16-byte load of its
+//             neighbour's record from this agent's HBM scratch; a ninth lane
+//             loads the popped cell's own record, whose tag word also carries
+//             the cell's static move mask (bounds / obstacle / corner-cut rule,
+//             helper.py:38-52) -- one memory round trip per pop.
+//   push    = the relaxing lanes rotate every pop (lane = (rr + move) & 63), so
+//             the lane that found an improvement inserts into ITS OWN bin: no
+//             cross-lane traffic, and pushes spread evenly over the bins.
+//   decrease-key (VARIANT 0, astar.py:96-100) = the record stores the entry's
+//             (bin, slot); the relaxing lane rewrites (f, g) in place and the
+//             owning lane refreshes its cached minimum.  Slots never move
+//             (tombstones), so positions stay valid.
 #pragma once
 #include "pf_device.h"
 
 namespace pf {
 
 struct Open {
-  double* lf;  // [64*S] bin-major
+  double* lf;  // [64*S] bin-major; +inf == free slot
   double* lg;
   int* lc;     // packed (r<<16)|c
-  double* sf;  // [8] push staging
-  double* sg;
-  int* sc;
   int S;
 };
 
 struct Slot {
   Rec* rec;
-  uint32_t tag;       // solve epoch
-  uint32_t avoid_ep;  // eval epoch (24 bit)
+  const uint8_t* mm;  // move masks the records were initialised from (for the wrap wipe)
+  uint32_t tag;       // solve epoch (24 bit)
+  uint32_t avoid_ep;  // eval epoch (15 bit)
 };
 
 struct AStat {
-  unsigned long long pops, pushes, nbr, stale;
+  unsigned long long pops, pushes, nbr, deckey;
   int max_open;
 };
 
@@ -75,6 +79,17 @@ PF_DEV void mark_avoid(const Slot& s, const int* cells, int n, int lane) {
   for (int i = lane; i < n; i += 64) s.rec[cells[i]].meta = s.avoid_ep << PF_AVOID_SHIFT;
 }
 
+// (re)initialise a slot: every record carries its cell's static move mask, epoch 0
+PF_DEV void slot_wipe(Slot& s, int RC, int lane) {
+  for (int i = lane; i < RC; i += 64) { Rec z; z.g = 0.0; z.tagmm = s.mm[i]; z.meta = 0; s.rec[i] = z; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  s.avoid_ep = 1; s.tag = 1;
+}
+
+// helper-order move deltas from the move index without a table lookup
+PF_DEV int move_dr(int d) { return (int)((0x0A25u >> (2 * d)) & 3u) - 1; }   // {0,0,1,-1,1,1,-1,-1} + 1 packed
+PF_DEV int move_dc(int d) { return (int)((0x2252u >> (2 * d)) & 3u) - 1; }   // {1,-1,0,0,1,-1,1,-1} + 1 packed
+
 // Returns status (PF_ST_*).  On PF_ST_OK, out[0..out_n) holds the path cells
 // (r*C+c) start..target.  out_cap is the room available at `out`.
 template <int VARIANT>
@@ -102,16 +117,14 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
   const uint32_t avm = s.avoid_ep;
   Rec* rec = s.rec;
   const int S = O.S;
+  const unsigned long long full = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
 
-  // per-lane constants: lanes 0..7 own one move each
-  const int d = lane & 7;
-  const int ddr = HM_DR[d], ddc = HM_DC[d];
-  const double cost = d < 4 ? 1.0 : PF_SQRT2;
-
-  // per-lane bin state
+  // all slots of this lane's bin free
+  for (int j = 0; j < S; ++j) O.lf[lane * S + j] = PF_INF;
+  unsigned long long occ = 0;
   double mf = PF_INF, mg = 0.0;
-  int mc = 0, ms = 0, cnt = 0;
-  int rr = 1;          // next bin for pushes
+  int mc = 0, ms = 0;
+  int rr = 1;          // lane of move 0 for the current pop (rotates)
   int n_open = 0;
 
   // seed: (h(start), 0, start) into bin 0; record g(start) = 0
@@ -120,9 +133,10 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
     double h0 = __builtin_sqrt((double)(dr0 * dr0 + dc0 * dc0));
     if (lane == 0) {
       O.lf[0] = h0; O.lg[0] = 0.0; O.lc[0] = (sr << 16) | sc_;
-      mf = h0; mg = 0.0; mc = (sr << 16) | sc_; ms = 0; cnt = 1;
+      mf = h0; mg = 0.0; mc = (sr << 16) | sc_; ms = 0; occ = 1;
       Rec r0 = rec[start];
-      Rec w; w.g = 0.0; w.tag = tag; w.meta = (r0.meta & ~0xFFu) | (VARIANT == 1 ? PF_M_INOPEN : 0u);
+      Rec w; w.g = 0.0; w.tagmm = (tag << PF_TAG_SHIFT) | (r0.tagmm & 0xFFu);
+      w.meta = (r0.meta & PF_AVOID_KEEP) | (VARIANT == 1 ? PF_M_INOPEN : 0u);   // position (0,0)
       rec[start] = w;
     }
     n_open = 1; st.pushes += 1;
@@ -133,131 +147,127 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
 
   for (;;) {
     if (steps >= max_steps) { status = n_open > 0 ? 2 : 1; break; }
-    // ---- pop: global min over the 64 cached bin minima ----
-    double fmin = wave_min_d(mf);
-    if (fmin == PF_INF) { status = 1; break; }               // open list empty
-    unsigned long long tie = __ballot(mf == fmin);
+    // ---- pop: argmin over the 64 cached bin minima ----
+    unsigned long long tie = argmin_mask_d<false>(mf);
     int w = __builtin_ctzll(tie);
+    if (bcast_d(mf, w) == PF_INF) { status = 1; break; }     // open list empty
     if (tie & (tie - 1)) w = resolve_tie(tie, mg, mc);
     const double pg = bcast_d(mg, w);
     const int pprc = bcast_i(mc, w);
     const int pslot = bcast_i(ms, w);
     const int pr = pprc >> 16, pc = pprc & 0xFFFF;
     const int cur = pr * C + pc;
-    // ---- issue this pop's memory batch (one round trip) ----
+    // ---- this pop's memory batch: one load instruction, one round trip ----
+    const int d = (lane - rr) & 63;                           // 0..7 = move index, 8 = the popped cell itself
+    const int ddr = move_dr(d & 7), ddc = move_dc(d & 7);
     const int nr = pr + ddr, nc = pc + ddc;
-    const bool inb = lane < 8 && nr >= 0 && nr < G.R && nc >= 0 && nc < C;
+    const bool inb = d < 8 && nr >= 0 && nr < G.R && nc >= 0 && nc < C;
     const int nidx = nr * C + nc;
-    Rec rn; rn.g = 0.0; rn.tag = 0; rn.meta = 0;
-    unsigned mmask = 0;
-    if (inb) rn = rec[nidx];
-    else if (lane == 8) rn = rec[cur];
-    else if (lane == 9) mmask = G.mm[cur];
-    // ---- remove the popped entry from bin w and rescan it (LDS, overlaps the loads) ----
-    const int wcnt = bcast_i(cnt, w) - 1;
-    if (lane == w) {
-      cnt = wcnt;
-      if (pslot != wcnt) {
-        const int a = w * S + pslot, b = w * S + wcnt;
-        O.lf[a] = O.lf[b]; O.lg[a] = O.lg[b]; O.lc[a] = O.lc[b];
-      }
-    }
+    Rec rn; rn.g = 0.0; rn.tagmm = 0; rn.meta = 0;
+    if (inb || d == 8) rn = rec[inb ? nidx : cur];
+    // ---- free the popped slot and rescan bin w (LDS; overlaps the load) ----
+    if (lane == w) { occ &= ~(1ull << pslot); O.lf[w * S + pslot] = PF_INF; }
     n_open -= 1;
     {
       double vf = PF_INF, vg = 0.0; int vc = 0;
-      if (lane < wcnt) { vf = O.lf[w * S + lane]; vg = O.lg[w * S + lane]; vc = O.lc[w * S + lane]; }
-      double rmin = wave_min_d(vf);
-      int j = 0;
-      if (rmin != PF_INF) {
-        unsigned long long t2 = __ballot(vf == rmin);
-        j = __builtin_ctzll(t2);
-        if (t2 & (t2 - 1)) j = resolve_tie(t2, vg, vc);
-      }
-      const double jg = bcast_d(vg, j);
+      if (lane < S) { vf = O.lf[w * S + lane]; vg = O.lg[w * S + lane]; vc = O.lc[w * S + lane]; }
+      const unsigned long long t2 = S <= 16 ? (argmin_mask_d<true>(vf) & 0xFFFFull) : argmin_mask_d<false>(vf);
+      int j = __builtin_ctzll(t2);
+      if (t2 & (t2 - 1)) j = resolve_tie(t2, vg, vc);
+      const double jf = bcast_d(vf, j), jg = bcast_d(vg, j);
       const int jc = bcast_i(vc, j);
-      if (lane == w) { mf = rmin; mg = jg; mc = jc; ms = j; }
+      if (lane == w) { mf = jf; mg = jg; mc = jc; ms = j; }   // jf == +inf when the bin is now empty
     }
-    // ---- the popped cell's own record ----
-    const double cur_g = bcast_d(rn.g, 8);
-    const uint32_t cur_tag = (uint32_t)bcast_i((int)rn.tag, 8);
-    const uint32_t cur_meta = (uint32_t)bcast_i((int)rn.meta, 8);
-    double base_g;
-    if (VARIANT == 0) {
-      const bool valid = cur_tag == tag && cur_g == pg && !(cur_meta & PF_M_CLOSED);
-      if (!valid) { st.stale += 1; continue; }               // superseded entry: not a reference pop
-      base_g = pg;                                           // astar.py:85 uses the popped g
-    } else {
-      base_g = cur_g;                                        // MPA.py:135 uses g_score[current]
-    }
+    // ---- the popped cell's own record (lane rr+8) ----
+    const int lcur = (rr + 8) & 63;
+    const double cur_g = bcast_d(rn.g, lcur);
+    const uint32_t cur_tagmm = (uint32_t)bcast_i((int)rn.tagmm, lcur);
+    const uint32_t cur_meta = (uint32_t)bcast_i((int)rn.meta, lcur);
+    const double base_g = VARIANT == 0 ? pg : cur_g;          // astar.py:85 popped g / MPA.py:135 g_score[current]
     steps += 1;
     if (cur == target) { status = 0; break; }                // astar.py:64 / MPA.py:123
-    if (lane == 8) {                                         // astar.py:74 closed.add / leave the open list
-      uint32_t m2 = VARIANT == 0 ? (cur_meta | PF_M_CLOSED) : (cur_meta & ~PF_M_INOPEN);
-      rec[cur].meta = m2;
-    }
+    if (lane == lcur)                                         // astar.py:74 closed.add / leave the open list
+      rec[cur].meta = VARIANT == 0 ? (cur_meta | PF_M_CLOSED) : (cur_meta & ~PF_M_INOPEN);
     // ---- relax the 8 neighbours in parallel ----
-    const unsigned M = (unsigned)bcast_i((int)mmask, 9);
-    const bool rvalid = rn.tag == tag;
+    const unsigned M = cur_tagmm & 0xFFu;
+    const bool rvalid = (rn.tagmm >> PF_TAG_SHIFT) == tag;
     const bool avoided = (rn.meta >> PF_AVOID_SHIFT) == avm;
-    bool ok = inb && ((M >> d) & 1u);
-    if (VARIANT == 0) ok = ok && !(rvalid && (rn.meta & PF_M_CLOSED)) && !(avoided && nidx != start && nidx != target);
+    const bool closed = rvalid && (rn.meta & PF_M_CLOSED);
+    bool ok = inb && ((M >> (d & 7)) & 1u);
+    if (VARIANT == 0) ok = ok && !closed && !(avoided && nidx != start && nidx != target);
     else ok = ok && !avoided;
-    const double tent = base_g + cost;
+    const double tent = base_g + (d < 4 ? 1.0 : PF_SQRT2);
     const bool better = ok && (!rvalid || tent < rn.g);      // astar.py:87 / MPA.py:137
-    const bool was_open = VARIANT == 1 && rvalid && (rn.meta & PF_M_INOPEN);
-    const bool push = better && !was_open;                   // MPA.py:141-150: an open node keeps its old entry
+    // a valid, unclosed record has a live open entry in VARIANT 0; VARIANT 1 tracks it with a flag
+    const bool in_open = VARIANT == 0 ? rvalid : (rvalid && (rn.meta & PF_M_INOPEN));
+    const bool push = better && !in_open;
+    const bool deckey = VARIANT == 0 && better && in_open;   // astar.py:96-100
     st.nbr += (unsigned long long)__builtin_popcountll(__ballot(ok));
     double fnew = 0.0;
+    unsigned pos = (rn.meta >> PF_POS_SHIFT) & PF_POS_MASK;
+    bool ovf = false;
     if (better) {
       long dr1 = nr - tr, dc1 = nc - tc;
       fnew = tent + __builtin_sqrt((double)(dr1 * dr1 + dc1 * dc1));   // astar.py:90 / MPA.py:140
-      Rec wv; wv.g = tent; wv.tag = tag;
-      wv.meta = (rn.meta & ~0xFFu) | (unsigned)d | ((VARIANT == 1 && (was_open || push)) ? PF_M_INOPEN : 0u);
-      rec[nidx] = wv;
-    }
-    // ---- pushes: k-th pushing lane -> bin (rr + k) & 63 via LDS staging ----
-    const unsigned long long pm = __ballot(push);
-    const int np = __builtin_popcountll(pm);
-    if (np) {
       if (push) {
-        const int k = __builtin_popcountll(pm & ((1ull << lane) - 1ull));
-        O.sf[k] = fnew; O.sg[k] = tent; O.sc[k] = (nr << 16) | nc;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      const int k2 = (lane - rr) & 63;
-      bool ovf = false;
-      if (k2 < np) {
-        if (cnt >= S) ovf = true;
+        if (occ == full) ovf = true;
         else {
-          const double ef = O.sf[k2], eg = O.sg[k2]; const int ec = O.sc[k2];
-          const int a = lane * S + cnt;
-          O.lf[a] = ef; O.lg[a] = eg; O.lc[a] = ec;
-          if (ent_lt(ef, eg, ec, mf, mg, mc) || mf == PF_INF) { mf = ef; mg = eg; mc = ec; ms = cnt; }
-          cnt += 1;
+          const int slot = __builtin_ctzll(~occ);
+          occ |= 1ull << slot;
+          const int a = lane * S + slot;
+          O.lf[a] = fnew; O.lg[a] = tent; O.lc[a] = (nr << 16) | nc;
+          if (mf == PF_INF || ent_lt(fnew, tent, (nr << 16) | nc, mf, mg, mc)) { mf = fnew; mg = tent; mc = (nr << 16) | nc; ms = slot; }
+          pos = ((unsigned)lane << 6) | (unsigned)slot;
         }
+      } else if (deckey) {
+        const int a = (int)(pos >> 6) * S + (int)(pos & 63u);
+        O.lf[a] = fnew; O.lg[a] = tent;
       }
-      __builtin_amdgcn_wave_barrier();
-      unsigned long long om = __ballot(ovf);
-      while (om) {                                           // designated bin full: any bin with room takes it
-        const int l = __builtin_ctzll(om);
-        om &= om - 1;
-        const int k3 = (l - rr) & 63;
-        const unsigned long long freem = __ballot(cnt < S);
-        if (!freem) { status = 3; break; }                   // all 64*S slots used: caller retries with a larger S
-        if (lane == __builtin_ctzll(freem)) {
-          const double ef = O.sf[k3], eg = O.sg[k3]; const int ec = O.sc[k3];
-          const int a = lane * S + cnt;
-          O.lf[a] = ef; O.lg[a] = eg; O.lc[a] = ec;
-          if (ent_lt(ef, eg, ec, mf, mg, mc) || mf == PF_INF) { mf = ef; mg = eg; mc = ec; ms = cnt; }
-          cnt += 1;
-        }
+      if (!ovf) {
+        Rec wv; wv.g = tent; wv.tagmm = (tag << PF_TAG_SHIFT) | (rn.tagmm & 0xFFu);
+        wv.meta = (rn.meta & PF_AVOID_KEEP) | (pos << PF_POS_SHIFT) | (unsigned)(d & 7) | (VARIANT == 1 ? PF_M_INOPEN : 0u);
+        rec[nidx] = wv;
       }
-      if (status == 3) break;
-      rr = (rr + np) & 63;
-      n_open += np; st.pushes += np;
-      if (n_open > st.max_open) st.max_open = n_open;
     }
+    const int np = __builtin_popcountll(__ballot(push));
+    // ---- decrease-key: the owning lane refreshes its cached minimum ----
+    if (VARIANT == 0) {
+      unsigned long long dm = __ballot(deckey);
+      st.deckey += (unsigned long long)__builtin_popcountll(dm);
+      while (dm) {
+        const int l = __builtin_ctzll(dm); dm &= dm - 1;
+        const unsigned p2 = (unsigned)bcast_i((int)pos, l);
+        const double f2 = bcast_d(fnew, l), g2 = bcast_d(tent, l);
+        const int c2 = (bcast_i(nr, l) << 16) | bcast_i(nc, l);
+        if (lane == (int)(p2 >> 6) && ((int)(p2 & 63u) == ms || ent_lt(f2, g2, c2, mf, mg, mc))) { mf = f2; mg = g2; mc = c2; ms = (int)(p2 & 63u); }
+      }
+    }
+    // ---- own bin full: hand the entry to any lane with room ----
+    unsigned long long om = __ballot(ovf);
+    while (om) {
+      const int l = __builtin_ctzll(om); om &= om - 1;
+      const unsigned long long freem = __ballot(occ != full);
+      if (!freem) { status = 3; break; }                     // all 64*S slots used: caller retries with a larger S
+      const int t = __builtin_ctzll(freem);
+      const double f2 = bcast_d(fnew, l), g2 = bcast_d(tent, l);
+      const int r2 = bcast_i(nr, l), c2 = bcast_i(nc, l), dd = bcast_i(d, l);
+      const uint32_t tm2 = (uint32_t)bcast_i((int)rn.tagmm, l), me2 = (uint32_t)bcast_i((int)rn.meta, l);
+      if (lane == t) {
+        const int slot = __builtin_ctzll(~occ);
+        occ |= 1ull << slot;
+        const int a = lane * S + slot, prc2 = (r2 << 16) | c2;
+        O.lf[a] = f2; O.lg[a] = g2; O.lc[a] = prc2;
+        if (mf == PF_INF || ent_lt(f2, g2, prc2, mf, mg, mc)) { mf = f2; mg = g2; mc = prc2; ms = slot; }
+        Rec wv; wv.g = g2; wv.tagmm = (tag << PF_TAG_SHIFT) | (tm2 & 0xFFu);
+        wv.meta = (me2 & PF_AVOID_KEEP) | ((((unsigned)lane << 6) | (unsigned)slot) << PF_POS_SHIFT) | (unsigned)(dd & 7) |
+                  (VARIANT == 1 ? PF_M_INOPEN : 0u);
+        rec[r2 * C + c2] = wv;
+      }
+    }
+    if (status == 3) break;
+    rr = (rr + 9) & 63;
+    n_open += np; st.pushes += np;
+    if (n_open > st.max_open) st.max_open = n_open;
   }
   st.pops += (unsigned long long)steps;
   if (status != 0) return status;
@@ -269,7 +279,7 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
     if (n >= out_cap - 1 || n > guard) return 3;
     if (lane == 0) out[n] = cell;
     const unsigned m = rec[cell].meta & PF_M_PARENT;
-    cell -= HM_DR[m] * C + HM_DC[m];
+    cell -= move_dr((int)m) * C + move_dc((int)m);
     n += 1;
   }
   if (lane == 0) out[n] = start;

@@ -20,13 +20,17 @@ namespace pf {
 // ---------------------------------------------------------------------------
 struct __attribute__((aligned(16))) Rec {
   double g;
-  uint32_t tag;
-  uint32_t meta;  // [2:0] parent move (helper order), [3] closed, [4] in-open, [31:8] avoid epoch
+  uint32_t tagmm;  // [7:0] static move mask of the cell (helper order, this handle's diagonal policy), [31:8] solve epoch
+  uint32_t meta;   // [2:0] parent move, [3] closed, [4] in-open, [16:5] open-list position (bin<<6|slot), [31:17] avoid epoch
 };
 #define PF_M_PARENT 7u
 #define PF_M_CLOSED 8u
 #define PF_M_INOPEN 16u
-#define PF_AVOID_SHIFT 8
+#define PF_POS_SHIFT 5
+#define PF_POS_MASK 0xFFFu
+#define PF_AVOID_SHIFT 17
+#define PF_AVOID_KEEP 0xFFFE0000u
+#define PF_TAG_SHIFT 8
 
 // helper.py:30-36 / MPA.py:71-77 move order
 __device__ __constant__ const int8_t HM_DR[8] = {0, 0, 1, -1, 1, 1, -1, -1};
@@ -78,6 +82,40 @@ PF_DEV double wave_min_d(double v) {
   v = dmin(v, dpp_d<0x143, 0xC>(v));  // row_bcast:31 into rows 2,3 -> lane 63 holds the wave min
   return bcast_d(v, 63);
 }
+// unsigned min with the DPP modifier folded into v_min_u32 (old = identity so the combiner can fold)
+template <int CTRL, int ROW_MASK>
+PF_DEV unsigned dpp_umin(unsigned v) {
+  unsigned m = (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, CTRL, ROW_MASK, 0xF, false);
+  return m < v ? m : v;
+}
+PF_DEV unsigned wave_min_u32(unsigned v) {
+  v = dpp_umin<0x121, 0xF>(v);
+  v = dpp_umin<0x122, 0xF>(v);
+  v = dpp_umin<0x124, 0xF>(v);
+  v = dpp_umin<0x128, 0xF>(v);
+  v = dpp_umin<0x142, 0xA>(v);
+  v = dpp_umin<0x143, 0xC>(v);
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// min over lanes 0..15 only (row 0); other rows are ignored
+PF_DEV unsigned row0_min_u32(unsigned v) {
+  v = dpp_umin<0x121, 0xF>(v);
+  v = dpp_umin<0x122, 0xF>(v);
+  v = dpp_umin<0x124, 0xF>(v);
+  v = dpp_umin<0x128, 0xF>(v);
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 0);
+}
+// Lanes holding the minimum of a non-negative double key (bit pattern order == value order).
+// ROW0: only lanes 0..15 take part (their keys; others must pass +inf).
+template <bool ROW0>
+PF_DEV unsigned long long argmin_mask_d(double key) {
+  const unsigned hi = (unsigned)__double2hiint(key), lo = (unsigned)__double2loint(key);
+  const unsigned mh = ROW0 ? row0_min_u32(hi) : wave_min_u32(hi);
+  const unsigned lo2 = hi == mh ? lo : 0xFFFFFFFFu;
+  const unsigned ml = ROW0 ? row0_min_u32(lo2) : wave_min_u32(lo2);
+  return __ballot(hi == mh && lo2 == ml && lo == ml);
+}
+
 PF_DEV int wave_sum_i(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);  // row_shr:1
   v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);  // row_shr:2

@@ -48,9 +48,9 @@ class DevBuf:
         return self.ptr + int(elem_offset) * self.dtype.itemsize
 
     def free(self):
-        if self.ptr:
+        if self.ptr and getattr(self.eng, "h", None):   # the handle may already be closed
             self.eng.L.pf_dev_free(self.eng.h, self.ptr)
-            self.ptr = 0
+        self.ptr = 0
 
     def __del__(self):
         try:
