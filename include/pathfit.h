@@ -168,24 +168,25 @@ int pf_maaco_best_scan(int32_t n, const double* plen, const int32_t* turns, int3
 
 /* ---- K7 + K2b + K1: MPA --------------------------------------------- */
 int pf_mpa_setup(pf_handle* h, const pf_mpa_params* p, const pf_score_params* sp);
-/* One phase sweep MPA.py:339-377 for predators i = agent0..agent0+n (global
- * indices in the fitness-sorted order): draws start idx + gate from the
- * predator's stream (seed, DOM_MPA=2, iter, i), then
- * MPA._reconstruct_path_segment (:284-318) or the phase's no-move branch.
- * Population = strided paths d_pop_cells/d_pop_len indexed through d_order
- * (int32[N], sorted position -> storage slot); d_elite_cells/elite_len/
- * d_elite_stats(double[5]) = the sweep-start elite (may alias the population
- * storage: candidates are written to separate buffers).  phase in {1,2,3}; CF per MPA.py:336.
+/* One phase sweep MPA.py:339-377 over n local predators.  d_gidx[a] = index
+ * of predator a in the GLOBAL fitness-sorted population of this iteration (the
+ * reference's loop index: it keys the stream (seed, DOM_MPA=2, iter, gidx) and
+ * decides the phase-2 Levy/Brownian split, MPA.py:351); d_slot[a] = its
+ * storage slot in the strided population d_pop_*.  The kernel draws the start
+ * idx + gate, then runs MPA._reconstruct_path_segment (:284-318) or the
+ * phase's no-move branch.  d_elite_cells/elite_len/d_elite_stats(double[5]) =
+ * the sweep-start elite (may alias the population storage: candidates go to
+ * separate buffers).  phase in {1,2,3}; CF per MPA.py:336.
  * Outputs candidate paths (strided, same cap) + stats double[n*5]. */
-int pf_mpa_phase_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uint64_t seed, int32_t agent0,
-                       int32_t n, int32_t path_cap, const int32_t* d_pop_cells, const int32_t* d_pop_len,
-                       const double* d_pop_stats, const int32_t* d_order, const int32_t* d_elite_cells,
-                       int32_t elite_len, const double* d_elite_stats, int32_t* d_out_cells, int32_t* d_out_len,
-                       double* d_out_stats, int32_t* d_status);
+int pf_mpa_phase_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uint64_t seed, int32_t n,
+                       int32_t path_cap, const int32_t* d_pop_cells, const int32_t* d_pop_len,
+                       const double* d_pop_stats, const int32_t* d_gidx, const int32_t* d_slot,
+                       const int32_t* d_elite_cells, int32_t elite_len, const double* d_elite_stats,
+                       int32_t* d_out_cells, int32_t* d_out_len, double* d_out_stats, int32_t* d_status);
 /* FADs sweep MPA.py:387-410 on the post-memory population (in place):
- * stream (seed, DOM_MPA_FADS=5, iter, i). */
-int pf_mpa_fads_batch(pf_handle* h, double CF, int32_t iter, uint64_t seed, int32_t agent0, int32_t n,
-                      int32_t path_cap, const int32_t* d_order, int32_t* d_pop_cells, int32_t* d_pop_len,
+ * stream (seed, DOM_MPA_FADS=5, iter, gidx). */
+int pf_mpa_fads_batch(pf_handle* h, double CF, int32_t iter, uint64_t seed, int32_t n, int32_t path_cap,
+                      const int32_t* d_gidx, const int32_t* d_slot, int32_t* d_pop_cells, int32_t* d_pop_len,
                       double* d_pop_stats, int32_t* d_status);
 /* MPA._reconstruct_path_segment (MPA.py:284-318) called directly: predator a
  * modifies population path a against the given elite path with explicit
@@ -195,10 +196,10 @@ int pf_mpa_rebuild_batch(pf_handle* h, int32_t iter, uint64_t seed, int32_t n, i
                          const int32_t* d_elite_cells, int32_t elite_len, const int32_t* d_idx,
                          const int32_t* d_is_levy, const double* d_scale, const int32_t* d_agent,
                          int32_t* d_out_cells, int32_t* d_out_len, double* d_out_stats, int32_t* d_status);
-/* memory step MPA.py:381-384: pop[i] <- cand[i] where cand fitness < pop fitness */
-int pf_mpa_memory(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_order, int32_t agent0,
-                  const int32_t* d_cand_cells, const int32_t* d_cand_len, const double* d_cand_stats,
-                  int32_t* d_pop_cells, int32_t* d_pop_len, double* d_pop_stats);
+/* memory step MPA.py:381-384: pop[d_slot[a]] <- cand[a] where cand fitness < pop fitness */
+int pf_mpa_memory(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_slot, const int32_t* d_cand_cells,
+                  const int32_t* d_cand_len, const double* d_cand_stats, int32_t* d_pop_cells, int32_t* d_pop_len,
+                  double* d_pop_stats);
 
 /* ---- device self-tests (used by tests/ to pin device arithmetic) ----- */
 /* out[i] = device sqrt((double)in[i]) -- must equal libm sqrt bit for bit

@@ -498,8 +498,10 @@ PF_DEV void copy_path(int* dst, const int* src, int n, int lane) {
 struct MpaPhaseArgs {
   Common c; ScoreP sp; MpaDev m;
   int phase, iter; double CF; unsigned long long seed;
-  int agent0, n, path_cap;
-  const int* pop_cells; const int* pop_len; const double* pop_stats; const int* order;
+  int n, path_cap;
+  const int* pop_cells; const int* pop_len; const double* pop_stats;
+  const int* gidx;   // [n] index of the predator in the GLOBAL fitness-sorted population (stream key, Levy split)
+  const int* slot;   // [n] storage slot of the predator in pop_*
   const int* elite_cells; int elite_len; const double* elite_stats;   // device double[5]
   int* out_cells; int* out_len; double* out_stats; int* status;
   // explicit mode (pf_mpa_rebuild_batch): no idx/gate draws
@@ -520,8 +522,8 @@ __global__ __launch_bounds__(64) void k_mpa_phase(MpaPhaseArgs p) {
     const int a = next_work(p.c.work, lane);
     if (a >= p.n) break;
     if (p.c.retry && p.status[a] != 3) continue;
-    const int gi = p.ex_idx ? p.ex_agent[a] : p.agent0 + a;      // index in the fitness-sorted population
-    const int slot = p.ex_idx ? a : p.order[gi];
+    const int gi = p.ex_idx ? p.ex_agent[a] : p.gidx[a];         // index in the fitness-sorted population
+    const int slot = p.ex_idx ? a : p.slot[a];
     const int* prey = p.pop_cells + (size_t)slot * p.path_cap;
     const int preyL = p.pop_len[slot];
     const double* prey_stats = p.pop_stats + (size_t)slot * 5;
@@ -603,8 +605,8 @@ __global__ __launch_bounds__(64) void k_mpa_phase(MpaPhaseArgs p) {
 struct MpaFadsArgs {
   Common c; ScoreP sp; MpaDev m;
   int iter; double CF; unsigned long long seed;
-  int agent0, n, path_cap;
-  int* pop_cells; int* pop_len; double* pop_stats; const int* order;
+  int n, path_cap;
+  int* pop_cells; int* pop_len; double* pop_stats; const int* gidx; const int* slot;
   int* tmp_cells;   // [nslots][path_cap]
   int* status;
 };
@@ -623,8 +625,8 @@ __global__ __launch_bounds__(64) void k_mpa_fads(MpaFadsArgs p) {
     const int a = next_work(p.c.work, lane);
     if (a >= p.n) break;
     if (p.c.retry && p.status[a] != 3) continue;
-    const int gi = p.agent0 + a;
-    const int slot = p.order ? p.order[gi] : gi;
+    const int gi = p.gidx[a];
+    const int slot = p.slot[a];
     int rc = 4, n = 0;
     bool have = false;
     Rng g; g.init(p.seed, DOM_MPA_FADS, (unsigned long long)p.iter, (unsigned long long)gi);
@@ -672,12 +674,12 @@ __global__ __launch_bounds__(64) void k_mpa_fads(MpaFadsArgs p) {
 }
 
 // memory step MPA.py:381-384
-__global__ __launch_bounds__(64) void k_mpa_memory(int n, int path_cap, const int* order, int agent0, const int* cand_cells,
+__global__ __launch_bounds__(64) void k_mpa_memory(int n, int path_cap, const int* slots, const int* cand_cells,
                                                    const int* cand_len, const double* cand_stats, int* pop_cells,
                                                    int* pop_len, double* pop_stats) {
   const int a = blockIdx.x;
   if (a >= n) return;
-  const int slot = order[agent0 + a];
+  const int slot = slots[a];
   if (!(cand_stats[(size_t)a * 5 + 4] < pop_stats[(size_t)slot * 5 + 4])) return;
   const int L = cand_len[a];
   for (int i = threadIdx.x; i < L; i += blockDim.x) pop_cells[(size_t)slot * path_cap + i] = cand_cells[(size_t)a * path_cap + i];
@@ -1225,21 +1227,21 @@ static MpaDev mpa_dev(const pf_handle* h) {
   return m;
 }
 
-int pf_mpa_phase_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uint64_t seed, int32_t agent0, int32_t n,
+int pf_mpa_phase_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uint64_t seed, int32_t n,
                        int32_t path_cap, const int32_t* d_pop_cells, const int32_t* d_pop_len,
-                       const double* d_pop_stats, const int32_t* d_order, const int32_t* d_elite_cells,
+                       const double* d_pop_stats, const int32_t* d_gidx, const int32_t* d_slot, const int32_t* d_elite_cells,
                        int32_t elite_len, const double* d_elite_stats, int32_t* d_out_cells, int32_t* d_out_len,
                        double* d_out_stats, int32_t* d_status) {
   if (!h) return -2;
   if (!h->mpa_ready) return failmsg(h, "pf_mpa_phase_batch: call pf_mpa_setup first");
-  if (phase < 1 || phase > 3 || n < 0 || path_cap < 2 || !d_pop_cells || !d_pop_len || !d_pop_stats || !d_order ||
+  if (phase < 1 || phase > 3 || n < 0 || path_cap < 2 || !d_pop_cells || !d_pop_len || !d_pop_stats || !d_gidx || !d_slot ||
       !d_elite_cells || !d_elite_stats || !d_out_cells || !d_out_len || !d_out_stats || !d_status) return failmsg(h, "pf_mpa_phase_batch: bad arguments");
   if (ensure_slots(h, h->mpp.allow_diag, h->mpp.restrict_corner)) return -1;
   MpaPhaseArgs a;
   a.c = make_common(h, h->mpp.allow_diag, h->mpp.restrict_corner, 16, 0);
   if (make_scorep(h, &h->mps, &a.sp)) return -1;
-  a.m = mpa_dev(h); a.phase = phase; a.iter = iter; a.CF = CF; a.seed = seed; a.agent0 = agent0; a.n = n; a.path_cap = path_cap;
-  a.pop_cells = d_pop_cells; a.pop_len = d_pop_len; a.pop_stats = d_pop_stats; a.order = d_order;
+  a.m = mpa_dev(h); a.phase = phase; a.iter = iter; a.CF = CF; a.seed = seed; a.n = n; a.path_cap = path_cap;
+  a.pop_cells = d_pop_cells; a.pop_len = d_pop_len; a.pop_stats = d_pop_stats; a.gidx = d_gidx; a.slot = d_slot;
   a.elite_cells = d_elite_cells; a.elite_len = elite_len;
   a.elite_stats = d_elite_stats;
   a.out_cells = d_out_cells; a.out_len = d_out_len; a.out_stats = d_out_stats; a.status = d_status;
@@ -1260,19 +1262,19 @@ int pf_mpa_rebuild_batch(pf_handle* h, int32_t iter, uint64_t seed, int32_t n, i
   MpaPhaseArgs a;
   a.c = make_common(h, h->mpp.allow_diag, h->mpp.restrict_corner, 16, 0);
   if (make_scorep(h, &h->mps, &a.sp)) return -1;
-  a.m = mpa_dev(h); a.phase = 0; a.iter = iter; a.CF = 0.0; a.seed = seed; a.agent0 = 0; a.n = n; a.path_cap = path_cap;
-  a.pop_cells = d_pop_cells; a.pop_len = d_pop_len; a.pop_stats = d_pop_stats; a.order = nullptr;
+  a.m = mpa_dev(h); a.phase = 0; a.iter = iter; a.CF = 0.0; a.seed = seed; a.n = n; a.path_cap = path_cap;
+  a.pop_cells = d_pop_cells; a.pop_len = d_pop_len; a.pop_stats = d_pop_stats; a.gidx = nullptr; a.slot = nullptr;
   a.elite_cells = d_elite_cells; a.elite_len = elite_len; a.elite_stats = d_pop_stats;
   a.out_cells = d_out_cells; a.out_len = d_out_len; a.out_stats = d_out_stats; a.status = d_status;
   a.ex_idx = d_idx; a.ex_levy = d_is_levy; a.ex_scale = d_scale; a.ex_agent = d_agent;
   return launch_with_retry(h, k_mpa_phase, a, n);
 }
 
-int pf_mpa_fads_batch(pf_handle* h, double CF, int32_t iter, uint64_t seed, int32_t agent0, int32_t n, int32_t path_cap,
-                      const int32_t* d_order, int32_t* d_pop_cells, int32_t* d_pop_len, double* d_pop_stats, int32_t* d_status) {
+int pf_mpa_fads_batch(pf_handle* h, double CF, int32_t iter, uint64_t seed, int32_t n, int32_t path_cap,
+                      const int32_t* d_gidx, const int32_t* d_slot, int32_t* d_pop_cells, int32_t* d_pop_len, double* d_pop_stats, int32_t* d_status) {
   if (!h) return -2;
   if (!h->mpa_ready) return failmsg(h, "pf_mpa_fads_batch: call pf_mpa_setup first");
-  if (n < 0 || path_cap < 2 || !d_pop_cells || !d_pop_len || !d_pop_stats || !d_status) return failmsg(h, "pf_mpa_fads_batch: bad arguments");
+  if (n < 0 || path_cap < 2 || !d_gidx || !d_slot || !d_pop_cells || !d_pop_len || !d_pop_stats || !d_status) return failmsg(h, "pf_mpa_fads_batch: bad arguments");
   if (ensure_slots(h, h->mpp.allow_diag, h->mpp.restrict_corner)) return -1;
   if (h->tmp_cap < path_cap) {
     if (h->d_tmp) CK(hipFree(h->d_tmp));
@@ -1282,19 +1284,19 @@ int pf_mpa_fads_batch(pf_handle* h, double CF, int32_t iter, uint64_t seed, int3
   MpaFadsArgs a;
   a.c = make_common(h, h->mpp.allow_diag, h->mpp.restrict_corner, 16, 0);
   if (make_scorep(h, &h->mps, &a.sp)) return -1;
-  a.m = mpa_dev(h); a.iter = iter; a.CF = CF; a.seed = seed; a.agent0 = agent0; a.n = n; a.path_cap = path_cap;
-  a.pop_cells = d_pop_cells; a.pop_len = d_pop_len; a.pop_stats = d_pop_stats; a.order = d_order;
+  a.m = mpa_dev(h); a.iter = iter; a.CF = CF; a.seed = seed; a.n = n; a.path_cap = path_cap;
+  a.pop_cells = d_pop_cells; a.pop_len = d_pop_len; a.pop_stats = d_pop_stats; a.gidx = d_gidx; a.slot = d_slot;
   a.tmp_cells = h->d_tmp; a.status = d_status;
   return launch_with_retry(h, k_mpa_fads, a, n);
 }
 
-int pf_mpa_memory(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_order, int32_t agent0,
+int pf_mpa_memory(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_slot,
                   const int32_t* d_cand_cells, const int32_t* d_cand_len, const double* d_cand_stats,
                   int32_t* d_pop_cells, int32_t* d_pop_len, double* d_pop_stats) {
   if (!h) return -2;
   if (n <= 0) return 0;
   CK(hipSetDevice(h->device));
-  hipLaunchKernelGGL(k_mpa_memory, dim3(n), dim3(64), 0, h->stream, n, path_cap, d_order, agent0, d_cand_cells, d_cand_len,
+  hipLaunchKernelGGL(k_mpa_memory, dim3(n), dim3(64), 0, h->stream, n, path_cap, d_slot, d_cand_cells, d_cand_len,
                      d_cand_stats, d_pop_cells, d_pop_len, d_pop_stats);
   CK(hipGetLastError());
   CK(hipStreamSynchronize(h->stream));

@@ -70,14 +70,14 @@ SYMBOLS = {
     "pf_maaco_tau_dev": (_vp, [_vp]),
     "pf_maaco_best_scan": (C.c_int, [_i32, _vp, _vp, _i32, C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_i32)]),
     "pf_mpa_setup": (C.c_int, [_vp, C.POINTER(MpaParams), C.POINTER(ScoreParams)]),
-    "pf_mpa_phase_batch": (C.c_int, [_vp, _i32, _dbl, _i32, _u64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32,
+    "pf_mpa_phase_batch": (C.c_int, [_vp, _i32, _dbl, _i32, _u64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32,
                                      _vp, _vp, _vp, _vp, _vp]),
-    "pf_mpa_fads_batch": (C.c_int, [_vp, _dbl, _i32, _u64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "pf_mpa_fads_batch": (C.c_int, [_vp, _dbl, _i32, _u64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pf_mpa_rebuild_batch": (C.c_int, [_vp, _i32, _u64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _vp, _vp]),
     "pf_selftest_sqrt": (C.c_int, [_vp, _i32, _vp, _vp]),
     "pf_selftest_rng": (C.c_int, [_vp, _u64, _u64, _u64, _u64, _vp, _vp, _vp]),
-    "pf_mpa_memory": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pf_mpa_memory": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 

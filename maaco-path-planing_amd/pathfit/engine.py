@@ -235,20 +235,18 @@ class Engine:
     def mpa_setup(self, mp, sp):
         self._ck(self.L.pf_mpa_setup(self.h, C.byref(mp), C.byref(sp)))
 
-    def mpa_phase(self, phase, CF, it, seed, agent0, n, path_cap, d_pop_cells, d_pop_len, d_pop_stats, d_order,
+    def mpa_phase(self, phase, CF, it, seed, n, path_cap, d_pop_cells, d_pop_len, d_pop_stats, d_gidx, d_slot,
                   elite_cells_ptr, elite_len, elite_stats_ptr, d_out_cells, d_out_len, d_out_stats, d_status):
-        self._ck(self.L.pf_mpa_phase_batch(self.h, int(phase), float(CF), int(it), int(seed), int(agent0), n,
-                                           path_cap, d_pop_cells.ptr, d_pop_len.ptr, d_pop_stats.ptr, d_order.ptr,
+        self._ck(self.L.pf_mpa_phase_batch(self.h, int(phase), float(CF), int(it), int(seed), n, path_cap,
+                                           d_pop_cells.ptr, d_pop_len.ptr, d_pop_stats.ptr, d_gidx.ptr, d_slot.ptr,
                                            elite_cells_ptr, int(elite_len), elite_stats_ptr, d_out_cells.ptr,
                                            d_out_len.ptr, d_out_stats.ptr, d_status.ptr))
 
-    def mpa_fads(self, CF, it, seed, agent0, n, path_cap, d_order, d_pop_cells, d_pop_len, d_pop_stats, d_status):
-        self._ck(self.L.pf_mpa_fads_batch(self.h, float(CF), int(it), int(seed), int(agent0), n, path_cap,
-                                          d_order.ptr if d_order else None, d_pop_cells.ptr, d_pop_len.ptr,
-                                          d_pop_stats.ptr, d_status.ptr))
+    def mpa_fads(self, CF, it, seed, n, path_cap, d_gidx, d_slot, d_pop_cells, d_pop_len, d_pop_stats, d_status):
+        self._ck(self.L.pf_mpa_fads_batch(self.h, float(CF), int(it), int(seed), n, path_cap, d_gidx.ptr, d_slot.ptr,
+                                          d_pop_cells.ptr, d_pop_len.ptr, d_pop_stats.ptr, d_status.ptr))
 
-    def mpa_memory(self, n, path_cap, d_order, agent0, d_cand_cells, d_cand_len, d_cand_stats, d_pop_cells,
-                   d_pop_len, d_pop_stats):
-        self._ck(self.L.pf_mpa_memory(self.h, n, path_cap, d_order.ptr, int(agent0), d_cand_cells.ptr,
-                                      d_cand_len.ptr, d_cand_stats.ptr, d_pop_cells.ptr, d_pop_len.ptr,
-                                      d_pop_stats.ptr))
+    def mpa_memory(self, n, path_cap, d_slot, d_cand_cells, d_cand_len, d_cand_stats, d_pop_cells, d_pop_len,
+                   d_pop_stats):
+        self._ck(self.L.pf_mpa_memory(self.h, n, path_cap, d_slot.ptr, d_cand_cells.ptr, d_cand_len.ptr,
+                                      d_cand_stats.ptr, d_pop_cells.ptr, d_pop_len.ptr, d_pop_stats.ptr))

@@ -1,0 +1,63 @@
+"""Cell values of the reference's env.py (env.py:4-7) and grid generators.
+
+The reference ships only literal grids (largest 256x256); the 128/512/1024
+grids named in BASELINE.json are synthesised here from a recipe.
+"""
+import hashlib
+
+import numpy as np
+
+FREE_SPACE = 0
+OBSTACLE = 1
+START_NODE_VAL = 2
+TARGET_NODE_VAL = 3
+
+
+def mark(grid01, start, target):
+    """Copy of an occupancy grid with the start/target markers set."""
+    g = np.array(grid01, dtype=np.int64)
+    g[g > 1] = FREE_SPACE
+    g[tuple(start)] = START_NODE_VAL
+    g[tuple(target)] = TARGET_NODE_VAL
+    return g
+
+
+def upsample(grid, k, start=None, target=None):
+    """k x nearest-neighbour upsample of the obstacle mask (np.kron), S=(0,0), T=(R-1,C-1) by default.
+    Preserves connectivity under the corner-cut rule."""
+    occ = np.kron((np.asarray(grid) == OBSTACLE).astype(np.int64), np.ones((k, k), np.int64))
+    R, C = occ.shape
+    return mark(occ, start or (0, 0), target or (R - 1, C - 1))
+
+
+def random_blocks(R, C, density=0.2, seed=0, block=(2, 6), start=None, target=None):
+    """Seeded random rectangular blocks until `density` of the cells are obstacles; the
+    start/target corners and a 2-cell margin around them stay free."""
+    rng = np.random.default_rng(seed)
+    occ = np.zeros((R, C), np.int64)
+    s = start or (0, 0)
+    t = target or (R - 1, C - 1)
+    goal = int(density * R * C)
+    guard = 0
+    while occ.sum() < goal and guard < 100000:
+        guard += 1
+        h, w = rng.integers(block[0], block[1] + 1, 2)
+        r, c = rng.integers(0, R - h + 1), rng.integers(0, C - w + 1)
+        occ[r:r + h, c:c + w] = 1
+    for (r, c) in (s, t):
+        occ[max(0, r - 2):r + 3, max(0, c - 2):c + 3] = 0
+    return mark(occ, s, t)
+
+
+def grid_hash(grid):
+    g = np.ascontiguousarray(np.asarray(grid), np.uint8)
+    return hashlib.sha256(bytes(g.shape[0].to_bytes(4, "little")) + bytes(g.shape[1].to_bytes(4, "little")) + g.tobytes()).hexdigest()
+
+
+def find_marker(grid, val, who):
+    """np.argwhere(grid == val)[0] with the reference's ValueError (astar.py:17-22 etc.)."""
+    found = np.argwhere(np.asarray(grid) == val)
+    if not found.size > 0:
+        what = "Start" if val == START_NODE_VAL else "Target"
+        raise ValueError(f"{who}: {what} node not found in grid." if who in ("AStar", "MPA") else f"{who}: {what} node not found.")
+    return (int(found[0][0]), int(found[0][1]))

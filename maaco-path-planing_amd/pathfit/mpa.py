@@ -1,0 +1,185 @@
+"""MPA with the reference's constructor / solve_path_planning() surface
+(MPA.py:10-18, :320-448).  The population lives in HBM as strided paths; the
+phase sweep (:339-377: target-cell proposal, two A* stitches, scoring), the
+memory step (:381-384) and the FADs sweep (:387-410) are device batches.  The
+host keeps what the reference keeps sequential and tiny: the stable sort by
+fitness (:333,:412), the elite choice (:334), CF (:336) and the 4-level
+best-so-far tie-break (:415-437).
+
+Per-predator streams: (seed, DOM_MPA, iter, i) for the phase sweep and
+(seed, DOM_MPA_FADS, iter, i) for FADs, with i the predator's index in the
+fitness-sorted population of that iteration (the reference's loop index).
+"""
+import math
+
+import numpy as np
+
+from ._lib import MpaParams
+from .engine import Engine, score_params
+from .env import START_NODE_VAL, TARGET_NODE_VAL, find_marker
+from .paths import CellPath
+
+INF = float("inf")
+
+
+def levy_sigma(beta):
+    """MPA.py:251-253 (Mantegna)."""
+    num = math.gamma(1 + beta) * math.sin(math.pi * beta / 2)
+    den = math.gamma((1 + beta) / 2) * beta * (2 ** ((beta - 1) / 2))
+    return (num / den) ** (1 / beta) if den > 1e-9 else 1.0
+
+
+class MPA:
+    def __init__(self, grid, num_predators, num_iterations, FADs_rate=0.2, P_const=0.5, levy_beta=1.5,
+                 turn_penalty_factor=0.1, safety_penalty_factor=0.05, min_safe_distance=1.5, allow_diagonal_moves=True,
+                 restrict_diagonal_near_obstacle=True, diagonal_obstacle_penalty=1000.0, engine=None, device=0, seed=0,
+                 verbose=False, agent0=0, n_local=None):
+        self.grid = np.array(grid, dtype=int)
+        self.rows, self.cols = self.grid.shape
+        self.num_predators, self.num_iterations = num_predators, num_iterations
+        self.FADs_rate, self.P_const, self.levy_beta = FADs_rate, P_const, levy_beta
+        self.turn_penalty_factor_mpa = turn_penalty_factor
+        self.safety_penalty_factor_mpa = safety_penalty_factor
+        self.min_safe_distance_mpa = min_safe_distance
+        self.allow_diagonal_moves = allow_diagonal_moves
+        self.restrict_diagonal_near_obstacle = restrict_diagonal_near_obstacle
+        self.diagonal_obstacle_penalty_val = diagonal_obstacle_penalty
+        self.start_node = find_marker(self.grid, START_NODE_VAL, "MPA")
+        self.target_node = find_marker(self.grid, TARGET_NODE_VAL, "MPA")
+        self.obstacle_nodes = np.argwhere(self.grid == 1)
+        self.best_path_overall = []
+        self.best_path_length_overall = INF
+        self.best_path_turns_overall = INF
+        self.best_safety_penalty_overall = INF
+        self.best_diag_penalty_overall = INF
+        self.best_fitness_overall = INF
+        self.convergence_curve_data = []
+        self.seed, self.verbose = int(seed), verbose
+        self.engine = engine if engine is not None else Engine(self.grid, device)
+        self._s = self.start_node[0] * self.cols + self.start_node[1]
+        self._t = self.target_node[0] * self.cols + self.target_node[1]
+        self._sp = score_params(1, restrict_diagonal_near_obstacle, turn_penalty_factor, safety_penalty_factor,
+                                min_safe_distance, diagonal_obstacle_penalty)
+        self.engine.mpa_setup(MpaParams(float(P_const), float(levy_beta), levy_sigma(levy_beta), float(FADs_rate),
+                                        int(num_predators), self._s, self._t, int(bool(allow_diagonal_moves)),
+                                        int(bool(restrict_diagonal_near_obstacle))), self._sp)
+        self.path_cap = min(self.rows * self.cols, 8 * (self.rows + self.cols) + 64)
+        self._init_population()
+
+    # ------------------------------------------------------------------
+    def _init_population(self):
+        """MPA._initialize_population_with_safety (MPA.py:231-245): N identical A*(start, target) paths."""
+        e, N = self.engine, self.num_predators
+        while True:
+            paths, st = e.astar_host(1, [self._s], [self._t], None, path_cap=self.path_cap,
+                                     allow_diag=self.allow_diagonal_moves, restrict_corner=self.restrict_diagonal_near_obstacle)
+            if st[0] == 3 and self.path_cap < self.rows * self.cols:
+                self.path_cap = min(self.rows * self.cols, self.path_cap * 4)
+                continue
+            break
+        p = paths[0]
+        if len(p) == 0:                                                  # :235-236
+            p = np.array([self._s, self._t] if self.grid[self.target_node] != 1 else [self._s], np.int32)
+        stats = e.score_host([p], self._sp)[0]
+        cap = self.path_cap
+        cells = np.zeros((N, cap), np.int32)
+        cells[:, :len(p)] = p
+        self.d_cells = e.put(cells)
+        self.d_len = e.put(np.full(N, len(p), np.int32))
+        self.d_stats = e.put(np.tile(stats, (N, 1)))
+        self.d_cand_cells, self.d_cand_len = e.buf((N, cap), np.int32), e.buf(N, np.int32)
+        self.d_cand_stats, self.d_status = e.buf((N, 5), np.float64), e.buf(N, np.int32)
+        self.order = np.arange(N, dtype=np.int32)                        # sorted position -> storage slot
+        self.d_order = e.put(self.order)
+        self.d_gidx = e.put(np.arange(N, dtype=np.int32))                # single GPU: every predator is local
+        self._stats_host = np.tile(stats, (N, 1))
+
+    @property
+    def population(self):
+        """The reference's list of dicts, in the current (sorted) order; materialised on demand."""
+        cells, lens, stats = self.d_cells.download(), self.d_len.download(), self.d_stats.download()
+        out = []
+        for slot in self.order:
+            s = stats[slot]
+            out.append({"path": CellPath(cells[slot, :lens[slot]].copy(), self.cols), "length": float(s[0]),
+                        "turns": int(s[1]), "safety_penalty": float(s[2]), "diag_penalty": float(s[3]),
+                        "fitness": float(s[4])})
+        return out
+
+    def _path_of_slot(self, slot):
+        L = int(self.d_len.download()[slot])
+        row = np.empty(self.path_cap, np.int32)
+        self.engine._ck(self.engine.L.pf_d2h(self.engine.h, row.ctypes.data, self.d_cells.at(slot * self.path_cap), row.nbytes))
+        return row[:L].copy()
+
+    def _sort(self):
+        """list.sort(key=fitness) is stable (MPA.py:321,:333,:412)."""
+        fit = self._stats_host[self.order, 4]
+        self.order = self.order[np.argsort(fit, kind="stable")].astype(np.int32)
+        self.d_order.upload(self.order)
+
+    def _update_best(self, s, slot):
+        self.best_fitness_overall = float(s[4])
+        self.best_path_overall = CellPath(self._path_of_slot(slot), self.cols).tolist()
+        self.best_path_length_overall = float(s[0])
+        self.best_path_turns_overall = int(s[1])
+        self.best_safety_penalty_overall = float(s[2])
+        self.best_diag_penalty_overall = float(s[3])
+
+    def step(self, it):
+        """One iteration of MPA.py:332-440 (it is 1-based)."""
+        e, N, cap = self.engine, self.num_predators, self.path_cap
+        self._sort()                                                     # :333
+        elite_slot = int(self.order[0])                                  # :334
+        elite_len = int(self.d_len.download()[elite_slot])
+        ratio = it / self.num_iterations
+        CF = 0.0 if ratio >= 1.0 else ((1.0 - ratio) ** (2.0 * ratio) if ratio > 0 else 1.0)   # :336
+        phase = 1 if it <= self.num_iterations / 3 else (2 if it <= 2 * self.num_iterations / 3 else 3)
+        e.mpa_phase(phase, CF, it, self.seed, N, cap, self.d_cells, self.d_len, self.d_stats, self.d_gidx, self.d_order,
+                    self.d_cells.at(elite_slot * cap), elite_len, self.d_stats.at(elite_slot * 5),
+                    self.d_cand_cells, self.d_cand_len, self.d_cand_stats, self.d_status)
+        self._check_overflow()
+        e.mpa_memory(N, cap, self.d_order, self.d_cand_cells, self.d_cand_len, self.d_cand_stats,
+                     self.d_cells, self.d_len, self.d_stats)            # :381-384
+        e.mpa_fads(CF, it, self.seed, N, cap, self.d_gidx, self.d_order, self.d_cells, self.d_len, self.d_stats, self.d_status)   # :387-410
+        self._check_overflow()
+        self._stats_host = self.d_stats.download()
+        self._sort()                                                     # :412
+        slot = int(self.order[0])
+        s = self._stats_host[slot]
+        # :415-437 best-so-far with the 4-level tie-break
+        if s[4] < self.best_fitness_overall:
+            self._update_best(s, slot)
+        elif abs(s[4] - self.best_fitness_overall) < 1e-9:
+            bl, bt, bs, bd = (self.best_path_length_overall, self.best_path_turns_overall,
+                              self.best_safety_penalty_overall, self.best_diag_penalty_overall)
+            if s[0] < bl:
+                self._update_best(s, slot)
+            elif abs(s[0] - bl) < 1e-9 and s[1] < bt:
+                self._update_best(s, slot)
+            elif abs(s[0] - bl) < 1e-9 and abs(s[1] - bt) < 1e-9 and s[2] < bs:
+                self._update_best(s, slot)
+            elif abs(s[0] - bl) < 1e-9 and abs(s[1] - bt) < 1e-9 and abs(s[2] - bs) < 1e-9 and s[3] < bd:
+                self._update_best(s, slot)
+        self.convergence_curve_data.append(
+            self.best_fitness_overall if self.best_fitness_overall != INF else
+            (self.convergence_curve_data[-1] if self.convergence_curve_data and self.convergence_curve_data[-1] is not None else None))
+        return s
+
+    def _check_overflow(self):
+        st = self.d_status.download()
+        if (st == 3).any():
+            raise RuntimeError("pathfit: scratch/path capacity overflow on %d predators (path_cap=%d)" %
+                               (int((st == 3).sum()), self.path_cap))
+
+    def solve_path_planning(self):
+        self._sort()                                                     # :321
+        slot = int(self.order[0])
+        self._update_best(self._stats_host[slot], slot)                  # :322-329
+        self.convergence_curve_data.append(self.best_fitness_overall if self.best_fitness_overall != INF else None)
+        for it in range(1, self.num_iterations + 1):
+            s = self.step(it)
+            if self.verbose and (it % 10 == 0 or it == 1 or it == self.num_iterations):
+                print(f"MPA Iter {it}/{self.num_iterations}: IterBest Fit={s[4]:.2f}; OverallBest Fit={self.best_fitness_overall:.2f}")
+        return (self.best_path_overall, self.best_path_length_overall, self.best_path_turns_overall,
+                self.best_safety_penalty_overall, self.best_diag_penalty_overall, self.best_fitness_overall)

@@ -1,0 +1,405 @@
+"""AStarSolver / GASolver / PSOSolver with the reference's constructor and solve()
+surface (astar.py:10-33, ga_solver.py:8-15,162, pso.py:8-15,163); the per-agent
+decode -> A*-stitch -> score hot path runs on the GPU through libpathfit.so.
+
+What stays on the host, as in the reference: selection / crossover / mutation
+(ga_solver.py:136-160), best-of bookkeeping and the convergence lists.  Random
+numbers come from per-agent keyed streams (pathfit/rng.py); PSO is evaluated
+synchronously per sweep (every particle sees the sweep-start gbest).
+"""
+import numpy as np
+
+from . import rng as pfrng
+from .engine import Engine, score_params
+from .env import START_NODE_VAL, TARGET_NODE_VAL, find_marker
+from .paths import CellPath, cells_of
+
+INF = float("inf")
+
+
+class BasePathfinder:
+    """helper.BasePathfinder (helper.py:115-161) minus the matplotlib half."""
+
+    def __init__(self, grid, start_node, target_node, turn_penalty_factor, safety_penalty_factor, min_safe_distance,
+                 allow_diagonal_moves, restrict_diagonal_near_obstacle_policy, diagonal_obstacle_penalty_value,
+                 engine=None, device=0, seed=0):
+        self.grid = np.array(grid, dtype=int)
+        self.rows, self.cols = self.grid.shape
+        self.start_node, self.target_node = start_node, target_node
+        self.obstacle_nodes = np.argwhere(self.grid == 1)
+        self.turn_penalty_factor = turn_penalty_factor
+        self.safety_penalty_factor = safety_penalty_factor
+        self.min_safe_distance = min_safe_distance
+        self.allow_diagonal_moves = allow_diagonal_moves
+        self.restrict_diagonal_near_obstacle_policy = restrict_diagonal_near_obstacle_policy
+        self.diagonal_obstacle_penalty_value = diagonal_obstacle_penalty_value
+        self.convergence_curve = []
+        self.seed = int(seed)
+        self.engine = engine if engine is not None else Engine(self.grid, device)
+        self._sp = score_params(0, restrict_diagonal_near_obstacle_policy, turn_penalty_factor, safety_penalty_factor,
+                                min_safe_distance, diagonal_obstacle_penalty_value)
+
+    def _cell(self, rc):
+        return int(rc[0]) * self.cols + int(rc[1])
+
+    def _calculate_stats_for_path(self, path):
+        """helper.py:138 -> (path, length, turns, safety, diag, fitness)."""
+        cells = cells_of(path, self.cols)
+        st = self.engine.score_host([cells], self._sp)[0]
+        if cells.size == 0:
+            return [], INF, 0, 0.0, 0.0, INF
+        return path, float(st[0]), int(st[1]), float(st[2]), float(st[3]), float(st[4])
+
+    @staticmethod
+    def _stats_tuple(path, st):
+        if len(path) == 0:
+            return [], INF, 0, 0.0, 0.0, INF
+        return path, float(st[0]), int(st[1]), float(st[2]), float(st[3]), float(st[4])
+
+
+class AStarSolver(BasePathfinder):
+    def __init__(self, grid, turn_penalty_factor=0.1, safety_penalty_factor=0.05, min_safe_distance=1.5,
+                 allow_diagonal_moves=True, restrict_diagonal_near_obstacle_policy=True,
+                 diagonal_obstacle_penalty_value=1000.0, engine=None, device=0, seed=0):
+        g = np.asarray(grid)
+        start_node = find_marker(g, START_NODE_VAL, "AStar")
+        target_node = find_marker(g, TARGET_NODE_VAL, "AStar")
+        super().__init__(grid, start_node, target_node, turn_penalty_factor, safety_penalty_factor, min_safe_distance,
+                         allow_diagonal_moves, restrict_diagonal_near_obstacle_policy, diagonal_obstacle_penalty_value,
+                         engine, device, seed)
+        self.astar_strictly_restricts_corners = self.restrict_diagonal_near_obstacle_policy
+
+    def solve(self, start_node_override=None, target_node_override=None, nodes_to_avoid=None):
+        """astar.py:33-101 for one query (batched form: Engine.astar_host)."""
+        s = start_node_override if start_node_override else self.start_node
+        t = target_node_override if target_node_override else self.target_node
+        inb = lambda n: 0 <= n[0] < self.rows and 0 <= n[1] < self.cols
+        if not inb(s) or not inb(t):
+            return self._calculate_stats_for_path([])
+        avoid = [np.array([self._cell(a) for a in nodes_to_avoid if inb(a)], np.int32)] if nodes_to_avoid else None
+        paths, st = self.engine.astar_host(0, [self._cell(s)], [self._cell(t)], avoid,
+                                           path_cap=self.rows * self.cols if self.rows * self.cols <= 1 << 16 else None,
+                                           allow_diag=self.allow_diagonal_moves,
+                                           restrict_corner=self.astar_strictly_restricts_corners)
+        if st[0] == 3:
+            paths, st = self.engine.astar_host(0, [self._cell(s)], [self._cell(t)], avoid, path_cap=self.rows * self.cols,
+                                               allow_diag=self.allow_diagonal_moves,
+                                               restrict_corner=self.astar_strictly_restricts_corners)
+        path = CellPath(paths[0], self.cols).tolist()
+        res = self._calculate_stats_for_path(path)
+        if len(path) > 1:
+            self.convergence_curve.append(res[1])      # astar.py:70: g of the goal == path length
+        return res
+
+
+class _WaypointSolver(BasePathfinder):
+    """Shared decode + score batch for GA / PSO."""
+
+    def _path_cap(self):
+        return min(self.rows * self.cols, 16 * (self.rows + self.cols) + 64)
+
+    def _evaluate(self, wp_cells=None, wp_pos=None):
+        """-> (list[CellPath], stats ndarray[n,5], feasible mask).  Retries with the full R*C capacity if a
+        path outgrows the default buffer."""
+        cap = self._path_cap()
+        paths, st, stats = self.engine.decode_host(self._cell(self.start_node), self._cell(self.target_node),
+                                                   wp_cells=wp_cells, wp_pos=wp_pos, sp=self._sp, path_cap=cap,
+                                                   allow_diag=self.allow_diagonal_moves,
+                                                   restrict_corner=self.restrict_diagonal_near_obstacle_policy)
+        if (st == 3).any():
+            cap = self.rows * self.cols
+            paths, st, stats = self.engine.decode_host(self._cell(self.start_node), self._cell(self.target_node),
+                                                       wp_cells=wp_cells, wp_pos=wp_pos, sp=self._sp, path_cap=cap,
+                                                       allow_diag=self.allow_diagonal_moves,
+                                                       restrict_corner=self.restrict_diagonal_near_obstacle_policy)
+            if (st == 3).any():
+                raise RuntimeError("pathfit: open-list scratch overflow on %d agents" % int((st == 3).sum()))
+        cps = [CellPath(p, self.cols) for p in paths]
+        return cps, stats, np.array([len(p) > 0 for p in paths])
+
+
+class GASolver(_WaypointSolver):
+    def __init__(self, grid, num_generations, population_size, num_waypoints_per_chromosome, mutation_rate,
+                 crossover_rate, tournament_size=3, turn_penalty_factor=0.1, safety_penalty_factor=0.05,
+                 min_safe_distance=1.5, allow_diagonal_moves=True, restrict_diagonal_near_obstacle_policy=True,
+                 diagonal_obstacle_penalty_value=1000.0, engine=None, device=0, seed=0, verbose=False):
+        g = np.asarray(grid)
+        start_node = find_marker(g, START_NODE_VAL, "GA")
+        target_node = find_marker(g, TARGET_NODE_VAL, "GA")
+        super().__init__(grid, start_node, target_node, turn_penalty_factor, safety_penalty_factor, min_safe_distance,
+                         allow_diagonal_moves, restrict_diagonal_near_obstacle_policy, diagonal_obstacle_penalty_value,
+                         engine, device, seed)
+        self.num_generations = num_generations
+        self.population_size = population_size
+        self.num_waypoints = num_waypoints_per_chromosome
+        self.mutation_rate = mutation_rate
+        self.crossover_rate = crossover_rate
+        self.tournament_size = tournament_size
+        # the connector obeys GA's diagonal policy (ga_solver.py:38-44); its weights are irrelevant when stitching
+        self.path_connector = AStarSolver(self.grid, 0, 0, 0, allow_diagonal_moves,
+                                          restrict_diagonal_near_obstacle_policy, 0, engine=self.engine)
+        self.population = []
+        self.best_solution_overall = {"fitness": INF, "path": []}
+        self.verbose = verbose
+        self._free = self.grid != 1
+
+    # ---- host-side genetic operators (ga_solver.py:48-56,136-160), per-agent streams ----
+    def _generate_random_waypoint(self, r):
+        while True:
+            rr = r.randint(0, self.rows - 1)
+            cc = r.randint(0, self.cols - 1)
+            if self._free[rr, cc]:
+                return (rr, cc)
+
+    def _create_chromosome(self, r):
+        return [self._generate_random_waypoint(r) for _ in range(self.num_waypoints)]
+
+    def _reconstruct_path_from_chromosome(self, chromosome):
+        """ga_solver.py:58-93 for one chromosome."""
+        if not chromosome:
+            return self.path_connector.solve(self.start_node, self.target_node)[0]
+        wp = np.array([[self._cell(w) for w in chromosome]], np.int32)
+        return self._evaluate(wp_cells=wp)[0][0].tolist()
+
+    def _individuals(self, chroms, cps, stats):
+        return [{"chromosome": c, "path": p, "fitness": float(s[4]), "length": float(s[0]), "turns": int(s[1]),
+                 "safety_penalty": float(s[2]), "diag_penalty": float(s[3])} for c, p, s in zip(chroms, cps, stats)]
+
+    def _initialize_population(self):
+        """ga_solver.py:95-133; attempt k draws its chromosome from stream (seed, DOM_INIT, 0, k)."""
+        self.population = []
+        max_total_attempts = self.population_size * 20
+        k = 0
+        while len(self.population) < self.population_size and k < max_total_attempts:
+            batch = min(max_total_attempts - k, max(self.population_size - len(self.population), 32) * 2)
+            chroms = [self._create_chromosome(pfrng.AgentRandom(self.seed, pfrng.DOM_INIT, 0, k + i)) for i in range(batch)]
+            wp = np.array([[self._cell(w) for w in c] for c in chroms], np.int32).reshape(batch, self.num_waypoints)
+            cps, stats, feas = self._evaluate(wp_cells=wp)
+            for ind, ok in zip(self._individuals(chroms, cps, stats), feas):
+                if ok and len(self.population) < self.population_size:
+                    self.population.append(ind)
+            k += batch
+        if not self.population and self.num_waypoints > 0:
+            path_direct = self._reconstruct_path_from_chromosome([])
+            if path_direct and path_direct[0] == self.start_node and path_direct[-1] == self.target_node:
+                _, l, t, sp, dp, f = self._calculate_stats_for_path(path_direct)
+                self.population.append({"chromosome": [], "path": path_direct, "fitness": f, "length": l, "turns": t,
+                                        "safety_penalty": sp, "diag_penalty": dp})
+        if not self.population:
+            self.population = [{"chromosome": [], "path": [], "fitness": INF, "length": INF, "turns": 0,
+                                "safety_penalty": 0, "diag_penalty": 0}] * self.population_size
+            return False
+        r = pfrng.AgentRandom(self.seed, pfrng.DOM_INIT, 1, 0)
+        while len(self.population) < self.population_size:
+            self.population.append(r.choice(self.population).copy())
+        self.population.sort(key=lambda x: x["fitness"])
+        return True
+
+    def _selection(self, gen):
+        out = []
+        for i in range(self.population_size):
+            r = pfrng.AgentRandom(self.seed, pfrng.DOM_GA_SELECT, gen, i)
+            tournament = r.sample(self.population, min(self.tournament_size, len(self.population)))
+            out.append(min(tournament, key=lambda x: x["fitness"]))
+        return out
+
+    def _crossover(self, p1, p2, r):
+        if r.random() < self.crossover_rate and self.num_waypoints > 0:
+            point = r.randint(1, self.num_waypoints - 1) if self.num_waypoints > 1 else 0
+            if point > 0:
+                return p1[:point] + p2[point:], p2[:point] + p1[point:]
+        return list(p1), list(p2)
+
+    def _mutate(self, chromosome, r):
+        if not chromosome:
+            return []
+        m = list(chromosome)
+        for i in range(len(m)):
+            if r.random() < self.mutation_rate:
+                m[i] = self._generate_random_waypoint(r)
+        return m
+
+    def solve(self):
+        if self.num_waypoints == 0:
+            path = self._reconstruct_path_from_chromosome([])
+            stats = self._calculate_stats_for_path(path)
+            self.best_solution_overall = {"path": stats[0], "fitness": stats[5], "length": stats[1], "turns": stats[2],
+                                          "safety_penalty": stats[3], "diag_penalty": stats[4]}
+            self.convergence_curve.append(stats[5])
+            return stats
+        if not self._initialize_population():
+            return [], INF, 0, 0.0, 0.0, INF
+        self.best_solution_overall = self.population[0].copy()
+        self.convergence_curve.append(self.best_solution_overall["fitness"])
+        N = self.population_size
+        for gen in range(self.num_generations):
+            parents = self._selection(gen)
+            # children of pair j come from stream (seed, DOM_GA, gen, j) (ga_solver.py:186-194)
+            kids, owners = [], []
+            idx = pair = 0
+            while len(kids) < N:
+                p1, p2 = parents[idx % len(parents)], parents[(idx + 1) % len(parents)]
+                idx += 2
+                r = pfrng.AgentRandom(self.seed, pfrng.DOM_GA, gen, pair)
+                pair += 1
+                c1, c2 = self._crossover(p1["chromosome"], p2["chromosome"], r)
+                for c in (self._mutate(c1, r), self._mutate(c2, r)):
+                    if len(kids) < N:
+                        kids.append(c)
+                        owners.append((p1, p2))
+            # ---- the hot path: decode + stitch + score every child on the GPU ----
+            with_wp = [i for i, c in enumerate(kids) if c]
+            cps, stats, feas = [None] * N, np.zeros((N, 5)), np.zeros(N, bool)
+            if with_wp:
+                wp = np.array([[self._cell(w) for w in kids[i]] for i in with_wp], np.int32)
+                a, b, c_ = self._evaluate(wp_cells=wp)
+                for j, i in enumerate(with_wp):
+                    cps[i], stats[i], feas[i] = a[j], b[j], c_[j]
+            new_pop = []
+            for i in range(N):
+                if kids[i] == [] :
+                    path = self._reconstruct_path_from_chromosome([])
+                    ok = bool(path) and path[0] == self.start_node and path[-1] == self.target_node
+                    st = self._calculate_stats_for_path(path) if ok else None
+                    if ok:
+                        new_pop.append({"chromosome": [], "path": path, "fitness": st[5], "length": st[1], "turns": st[2],
+                                        "safety_penalty": st[3], "diag_penalty": st[4]})
+                        continue
+                elif feas[i]:
+                    new_pop.append(self._individuals([kids[i]], [cps[i]], [stats[i]])[0])
+                    continue
+                p1, p2 = owners[i]                                   # ga_solver.py:204-205
+                new_pop.append(p1 if len(new_pop) % 2 == 0 else p2)
+            self.population = new_pop
+            self.population.sort(key=lambda x: x["fitness"])
+            if self.population[0]["fitness"] < self.best_solution_overall["fitness"]:
+                self.best_solution_overall = self.population[0].copy()
+            self.convergence_curve.append(self.best_solution_overall["fitness"])
+            if self.verbose and ((gen + 1) % 10 == 0 or gen == 0 or gen == self.num_generations - 1):
+                b = self.best_solution_overall
+                print(f"GA Gen {gen + 1}/{self.num_generations}: BestFit={b['fitness']:.2f} (L:{b['length']:.1f}, T:{b['turns']})")
+        res = self.best_solution_overall
+        path = res["path"].tolist() if isinstance(res["path"], CellPath) else res["path"]
+        return (path, res["length"], res["turns"], res["safety_penalty"], res["diag_penalty"], res["fitness"])
+
+
+class PSOSolver(_WaypointSolver):
+    def __init__(self, grid, num_iterations, num_particles, num_waypoints_per_particle, w, c1, c2,
+                 turn_penalty_factor=0.1, safety_penalty_factor=0.05, min_safe_distance=1.5, allow_diagonal_moves=True,
+                 restrict_diagonal_near_obstacle_policy=True, diagonal_obstacle_penalty_value=1000.0, engine=None,
+                 device=0, seed=0, verbose=False):
+        g = np.asarray(grid)
+        start_node = find_marker(g, START_NODE_VAL, "PSO")
+        target_node = find_marker(g, TARGET_NODE_VAL, "PSO")
+        super().__init__(grid, start_node, target_node, turn_penalty_factor, safety_penalty_factor, min_safe_distance,
+                         allow_diagonal_moves, restrict_diagonal_near_obstacle_policy, diagonal_obstacle_penalty_value,
+                         engine, device, seed)
+        self.num_iterations = num_iterations
+        self.num_particles = num_particles
+        self.num_waypoints = num_waypoints_per_particle
+        self.w, self.c1, self.c2 = w, c1, c2
+        self.max_vel = max(1.0, 0.15 * max(self.rows, self.cols))      # pso.py:34
+        self.path_connector = AStarSolver(self.grid, 0, 0, 0, allow_diagonal_moves,
+                                          restrict_diagonal_near_obstacle_policy, 0, engine=self.engine)
+        self.particles = []
+        self.gbest_particle_data = {"fitness": INF, "path": [], "position": []}
+        self.verbose = verbose
+
+    def _reconstruct_path_from_position(self, position_waypoints_float):
+        """pso.py:56-94 for one particle."""
+        if not len(position_waypoints_float):
+            return self.path_connector.solve(self.start_node, self.target_node)[0]
+        wp = np.asarray(position_waypoints_float, np.float64).reshape(1, -1, 2)
+        return self._evaluate(wp_pos=wp)[0][0].tolist()
+
+    def _initialize_particles(self):
+        """pso.py:97-161: attempt k draws position then velocity from stream (seed, DOM_INIT, 0, k)."""
+        W, N = self.num_waypoints, self.num_particles
+        pos, vel, cps, stats = [], [], [], []
+        k, max_total = 0, N * 20
+        while len(pos) < N and k < max_total:
+            batch = min(max_total - k, max(N - len(pos), 32) * 2)
+            P = np.zeros((batch, W, 2)); V = np.zeros((batch, W, 2))
+            for i in range(batch):
+                r = pfrng.AgentRandom(self.seed, pfrng.DOM_INIT, 0, k + i)
+                P[i] = [[r.uniform(0, self.rows - 1), r.uniform(0, self.cols - 1)] for _ in range(W)]     # :50-51
+                V[i] = [[r.uniform(-self.max_vel / 5, self.max_vel / 5) for _ in range(2)] for _ in range(W)]   # :105
+            a, b, feas = self._evaluate(wp_pos=P)
+            for i in range(batch):
+                if feas[i] and len(pos) < N:
+                    pos.append(P[i]); vel.append(V[i]); cps.append(a[i]); stats.append(b[i])
+            k += batch
+        if not pos:
+            return False
+        r = pfrng.AgentRandom(self.seed, pfrng.DOM_INIT, 1, 0)
+        while len(pos) < N:                                              # :159-160 random copies
+            j = r.randrange(len(pos))
+            pos.append(pos[j].copy()); vel.append(vel[j].copy()); cps.append(cps[j]); stats.append(stats[j])
+        self._pos, self._vel = np.array(pos), np.array(vel)
+        self._pbest, self._pbest_fit = self._pos.copy(), np.array([s[4] for s in stats])
+        self._pbest_path, self._pbest_stats = list(cps), [np.array(s) for s in stats]
+        self._cur_path, self._cur_stats = list(cps), [np.array(s) for s in stats]
+        g = int(np.argmin(self._pbest_fit))                              # first minimum == the sequential :121 scan
+        self._set_gbest(g, self._pos[g], cps[g], stats[g])
+        self._sync_particles()
+        return True
+
+    def _set_gbest(self, idx, position, path, st):
+        self.gbest_particle_data = {"fitness": float(st[4]), "path": path, "position": [list(p) for p in position],
+                                    "length": float(st[0]), "turns": int(st[1]), "safety_penalty": float(st[2]),
+                                    "diag_penalty": float(st[3])}
+
+    def _sync_particles(self):
+        self.particles = [{"position": self._pos[i].tolist(), "velocity": self._vel[i].tolist(),
+                           "pbest_position": self._pbest[i].tolist(), "pbest_fitness": float(self._pbest_fit[i]),
+                           "pbest_path": self._pbest_path[i], "current_path": self._cur_path[i],
+                           "current_fitness": float(self._cur_stats[i][4])} for i in range(len(self._pos))]
+
+    def solve(self):
+        if self.num_waypoints == 0:
+            path = self._reconstruct_path_from_position([])
+            stats = self._calculate_stats_for_path(path)
+            self.gbest_particle_data = {"path": stats[0], "fitness": stats[5], "length": stats[1], "turns": stats[2],
+                                        "safety_penalty": stats[3], "diag_penalty": stats[4], "position": []}
+            self.convergence_curve.append(stats[5])
+            return stats
+        if not self._initialize_particles():
+            return [], INF, 0, 0.0, 0.0, INF
+        self.convergence_curve.append(self.gbest_particle_data["fitness"])
+        e, N, W = self.engine, self.num_particles, self.num_waypoints
+        cap = self._path_cap()
+        d_pos, d_vel, d_pb = e.put(self._pos), e.put(self._vel), e.put(self._pbest)
+        d_pbf = e.put(self._pbest_fit)
+        d_gb = e.put(np.array(self.gbest_particle_data["position"], np.float64))
+        d_cells, d_len, d_st = e.buf((N, cap), np.int32), e.buf(N, np.int32), e.buf(N, np.int32)
+        d_stats, d_imp = e.buf((N, 5), np.float64), e.buf(N, np.int32)
+        s_cell, t_cell = self._cell(self.start_node), self._cell(self.target_node)
+        for it in range(self.num_iterations):
+            # ---- hot path, all resident in HBM: update -> decode/stitch -> score -> pbest ----
+            e.pso_update(N, W, self.w, self.c1, self.c2, self.max_vel, d_pos, d_vel, d_pb, d_gb, self.seed, it, 0)
+            e.decode_batch(N, W, s_cell, t_cell, cap, d_cells, d_len, d_st, None, d_pos, self._sp, d_stats,
+                           self.allow_diagonal_moves, self.restrict_diagonal_near_obstacle_policy)
+            st = d_st.download()
+            if (st == 3).any():
+                raise RuntimeError("pathfit: scratch/path capacity overflow in PSO decode")
+            e.pso_pbest(N, W, d_pos, d_stats, d_len, d_pb, d_pbf, d_imp)
+            stats, lens, imp = d_stats.download(), d_len.download(), d_imp.download()
+            # gbest: first improver with the smallest fitness below the current gbest (pso.py:222 in particle order)
+            cand = np.flatnonzero(imp)
+            if cand.size:
+                j = cand[np.argmin(stats[cand, 4])]
+                if stats[j, 4] < self.gbest_particle_data["fitness"]:
+                    cells = d_cells.download()[j, :lens[j]]
+                    pos_j = d_pos.download()[j]
+                    self._set_gbest(j, pos_j, CellPath(cells, self.cols), stats[j])
+                    d_gb.upload(pos_j)
+            self.convergence_curve.append(self.gbest_particle_data["fitness"])
+            if self.verbose and ((it + 1) % 10 == 0 or it == 0 or it == self.num_iterations - 1):
+                b = self.gbest_particle_data
+                print(f"PSO Iter {it + 1}/{self.num_iterations}: GBestFit={b['fitness']:.2f}")
+        self._pos, self._vel, self._pbest, self._pbest_fit = d_pos.download(), d_vel.download(), d_pb.download(), d_pbf.download()
+        res = self.gbest_particle_data
+        path = res["path"].tolist() if isinstance(res["path"], CellPath) else res["path"]
+        res["path"] = path
+        return (path, res.get("length", INF), res.get("turns", INF), res.get("safety_penalty", INF),
+                res.get("diag_penalty", INF), res["fitness"])

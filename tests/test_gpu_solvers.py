@@ -1,0 +1,146 @@
+"""End-to-end: the GPU solver facades == the same outer loops driven by the CPU oracle
+(oracle/pf_loops.py), bit for bit, including BASELINE.json config-1
+(MPA, 30 predators, 50 iterations, fig7 20x20)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import golden_io as gio
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cfg1_mpa_30x50_fig7_matches_oracle_loop():
+    import pathfit, pf_oracle as po, pf_loops
+    g, s, t = gio.grid("fig7")
+    for seed in (0, 1, 2):
+        m = pathfit.MPA(g, 30, 50, seed=seed)
+        got = m.solve_path_planning()
+        ref = pf_loops.MpaOracle(po.Oracle(g), s, t, 30, 50, seed=seed)
+        best = ref.solve()
+        assert [r * 20 + c for r, c in got[0]] == list(best[0]), seed
+        assert (got[1], got[2], got[3], got[4], got[5]) == (best[1][0], int(best[1][1]), best[1][2], best[1][3], best[1][4])
+        assert m.convergence_curve_data == ref.curve
+        # whole population too
+        pop = m.population
+        for a, b in zip(pop, ref.pop):
+            assert np.array_equal(a["path"].cells, b[0]) and a["fitness"] == b[1][4]
+        # reference's measured range for this config: 32.86 - 33.04
+        assert 31.0 < got[5] < 34.5
+
+
+def test_mpa_main_params_with_levy_phases():
+    import pathfit, pf_oracle as po, pf_loops
+    g, s, t = gio.grid("img1")
+    kw = dict(FADs_rate=0.2, P_const=0.5, levy_beta=2.0, turn_penalty_factor=0.1, safety_penalty_factor=0.8,
+              min_safe_distance=1.8, diagonal_obstacle_penalty=100.0)
+    m = pathfit.MPA(g, 24, 12, seed=5, **kw)
+    got = m.solve_path_planning()
+    ref = pf_loops.MpaOracle(po.Oracle(g), s, t, 24, 12, FADs_rate=0.2, P_const=0.5, levy_beta=2.0, w_turn=0.1,
+                             w_safe=0.8, min_safe=1.8, diag_pen=100.0, seed=5)
+    best = ref.solve()
+    assert [r * 20 + c for r, c in got[0]] == list(best[0]) and got[5] == best[1][4]
+    assert m.convergence_curve_data == ref.curve
+
+
+@pytest.mark.parametrize("beta", [7.0, 2.0])
+def test_maaco_solve_matches_oracle_loop(beta):
+    import pathfit, pf_oracle as po, pf_loops
+    g, s, t = gio.grid("fig7")
+    kw = dict(alpha=1.0, beta=beta, rho=0.1, Q=2.5, a_turn_coef=1.0, wh_max=0.9, wh_min=0.2, k_h_adaptive=0.9,
+              q0_initial=0.5)
+    m = pathfit.MAACO(g, 50, 12, C0_initial_pheromone=0.1, seed=3, **kw)
+    path, length, turns = m.solve_path_planning()
+    ref = pf_loops.maaco_solve(po.Oracle(g), s, t, 50, 12, C0=0.1, seed=3, **kw)
+    assert [r * 20 + c for r, c in path] == list(ref["path"]) and length == ref["length"] and turns == ref["turns"]
+    assert m.convergence_curve_data == ref["curve"]
+    assert np.array_equal(m.pheromone_matrix, ref["tau"])
+
+
+def test_maaco_alpha_not_one_uses_host_pow_table():
+    import pathfit, pf_oracle as po, pf_loops
+    g, s, t = gio.grid("fig13")
+    kw = dict(alpha=1.5, beta=3.0, rho=0.2, Q=2.5, a_turn_coef=1.0, wh_max=0.9, wh_min=0.2, k_h_adaptive=0.9, q0_initial=0.3)
+    m = pathfit.MAACO(g, 24, 5, seed=9, **kw)
+    path, length, turns = m.solve_path_planning()
+    ref = pf_loops.maaco_solve(po.Oracle(g), s, t, 24, 5, seed=9, **kw)
+    assert [r * 20 + c for r, c in path] == list(ref["path"]) and length == ref["length"]
+    assert np.array_equal(m.pheromone_matrix, ref["tau"])
+
+
+def _oracle_backed(cls, orc):
+    """Same facade, but decode+score from the CPU oracle (checker only)."""
+    from pathfit.paths import CellPath
+
+    class OB(cls):
+        def _evaluate(self, wp_cells=None, wp_pos=None):
+            n = len(wp_cells) if wp_cells is not None else len(wp_pos)
+            cps, stats, feas = [], np.zeros((n, 5)), np.zeros(n, bool)
+            for i in range(n):
+                wp = wp_cells[i] if wp_cells is not None else orc.pso_round(wp_pos[i])
+                p, _ = orc.decode(self._cell(self.start_node), self._cell(self.target_node), wp)
+                sp = self._sp
+                stats[i] = orc.score(p, 0, sp.w_turn, sp.w_safe, sp.min_safe, bool(sp.restrict_policy), sp.diag_pen)
+                cps.append(CellPath(p, self.cols)); feas[i] = len(p) > 0
+            return cps, stats, feas
+    return OB
+
+
+def test_ga_solve_matches_oracle_backed_facade():
+    import pathfit, pf_oracle as po
+    g, s, t = gio.grid("fig7")
+    kw = dict(num_generations=6, population_size=24, num_waypoints_per_chromosome=5, mutation_rate=0.1, crossover_rate=0.8,
+              tournament_size=3, turn_penalty_factor=0.3, safety_penalty_factor=0.8, min_safe_distance=1.8,
+              diagonal_obstacle_penalty_value=100.0, seed=4)
+    a = pathfit.GASolver(g, **kw)
+    ra = a.solve()
+    b = _oracle_backed(pathfit.GASolver, po.Oracle(g))(g, engine=a.engine, **kw)
+    rb = b.solve()
+    assert ra == rb and a.convergence_curve == b.convergence_curve
+    assert ra[0][0] == (0, 0) and ra[0][-1] == (19, 19)
+
+
+def test_pso_solve_matches_oracle_loop():
+    import pathfit, pf_oracle as po
+    g, s, t = gio.grid("fig7")
+    orc = po.Oracle(g)
+    kw = dict(num_iterations=8, num_particles=32, num_waypoints_per_particle=5, w=0.7, c1=1.5, c2=1.5,
+              turn_penalty_factor=0.3, safety_penalty_factor=0.8, min_safe_distance=1.8, diagonal_obstacle_penalty_value=100.0,
+              seed=6)
+    a = pathfit.PSOSolver(g, **kw)
+    ra = a.solve()
+    # oracle loop: same init (host RNG), then synchronous sweeps
+    b = _oracle_backed(pathfit.PSOSolver, orc)(g, engine=a.engine, **kw)
+    assert b._initialize_particles()
+    pos, vel, pb, pbf = b._pos.copy(), b._vel.copy(), b._pbest.copy(), b._pbest_fit.copy()
+    gb, gfit, gpath = np.array(b.gbest_particle_data["position"]), b.gbest_particle_data["fitness"], b.gbest_particle_data["path"]
+    curve = [gfit]
+    for it in range(8):
+        pos, vel = orc.pso_update(pos, vel, pb, gb, 0.7, 1.5, 1.5, b.max_vel, 6, it, 0)
+        cps, stats, feas = b._evaluate(wp_pos=pos)
+        imp = feas & (stats[:, 4] < pbf)
+        pb[imp] = pos[imp]; pbf[imp] = stats[imp, 4]
+        cand = np.flatnonzero(imp)
+        if cand.size:
+            j = cand[np.argmin(stats[cand, 4])]
+            if stats[j, 4] < gfit:
+                gfit, gb, gpath = stats[j, 4], pos[j].copy(), cps[j]
+        curve.append(gfit)
+    assert a.convergence_curve == curve and ra[5] == gfit
+    assert ra[0] == (gpath.tolist() if hasattr(gpath, "tolist") else gpath)
+    assert np.array_equal(a._pos, pos) and np.array_equal(a._pbest_fit, pbf)
+
+
+def test_astar_solver_single_query():
+    import pathfit, pf_oracle as po
+    g, s, t = gio.grid("fig7")
+    orc = po.Oracle(g)
+    a = pathfit.AStarSolver(g, 0.3, 0.8, 1.8, True, True, 100.0)
+    res = a.solve()
+    want, _ = orc.astar(s, t, None, 0)
+    assert [r * 20 + c for r, c in res[0]] == list(want)
+    assert list(res[1:]) == [v if i != 1 else int(v) for i, v in enumerate(orc.score(want, 0, 0.3, 0.8, 1.8, True, 100.0))]
+    assert a.solve((0, 4), (3, 3))[0] == [] and a.solve((0, 4), (3, 3))[5] == math.inf      # obstacle start -> []
+    assert a.solve((2, 2), (2, 2))[0] == [(2, 2)]
