@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py -- agent-fitness-evals/sec on a 512x512 grid (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--workload mpa512|maaco512|pso512|ga512]
+
+Workload at N=1 (default `mpa512`) = BASELINE.json configs[2]: MPA, 4096
+predators on G512 (np.kron 2x of the reference's 256x256 map), main.py:44-52
+parameters.  A "step" is one MPA iteration's population evaluate-and-update
+hot path: per predator propose a target cell, stitch with two A* connectors,
+score, greedy memory, FADs.  One eval = one predator's pass through it.  Inputs
+(grid, population) are resident in HBM when the timed region starts.  For N>1
+every rank owns 4096 predators (weak scaling); the only exchange is the
+fitness all_gather + elite broadcast per iteration (pathfit/dist.py).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`
+for the dominant kernel (k_mpa_phase / k_maaco_walk / k_decode_batch; HIP-event
+timed inside the library on its own stream) and `cpu_baseline` (the CPU oracle
+port, bounded sample, 1 core).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(ROOT, "maaco-path-planing_amd"), os.path.join(ROOT, "oracle")]
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+MPA_MAIN = dict(FADs_rate=0.2, P_const=0.5, levy_beta=2.0, turn_penalty_factor=0.1, safety_penalty_factor=0.8,
+                min_safe_distance=1.8, diagonal_obstacle_penalty=100.0)             # main.py:44-52
+MAACO_MAIN = dict(alpha=1.0, beta=7.0, rho=0.1, Q=2.5, a_turn_coef=1.0, wh_max=0.9, wh_min=0.2, k_h_adaptive=0.9,
+                  q0_initial=0.5, C0_initial_pheromone=0.1)                          # main.py:34-38
+W_MAIN = dict(turn_penalty_factor=0.3, safety_penalty_factor=0.8, min_safe_distance=1.8,
+              diagonal_obstacle_penalty_value=100.0)                                 # main.py:21-24
+
+
+def astar_bytes(c):
+    """Algorithmic bytes of the A* work of one launch: per pop a 24 B heap entry + the 3x3
+    occupancy window (9 B) + 1 B closed mark, 8 B per examined neighbour, 33 B per push; 4 B per emitted cell."""
+    return 34 * c["pops"] + 8 * c["nbr_examined"] + 33 * c["pushes"] + 4 * c["path_cells"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="mpa512", choices=["mpa512", "maaco512", "pso512", "ga512"])
+    ap.add_argument("--agents", type=int, default=0, help="agents per GPU (default: the config's)")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch = None
+    try:
+        import torch as _t
+        torch = _t
+    except Exception:
+        torch = None
+    if world > 1:
+        import torch.distributed as dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist_.init_process_group("nccl", rank=rank, world_size=world)
+        dist = dist_
+
+    import pathfit
+    from pathfit import env
+    from pathfit.dist import Comm, ShardedMPA, ShardedMAACO
+
+    comm = Comm(dist, torch.device("cuda", local_rank) if dist is not None else None)
+    grid = env.bench_grid(512)
+    eng = pathfit.Engine(grid, device=local_rank)
+    K, W = a.steps, a.warmup
+
+    def sync_all():
+        if torch is not None and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        eng._ck(eng.L.pf_sync(eng.h))
+        comm.barrier()
+
+    kern_ms, kern_bytes, launches = 0.0, 0.0, 0
+    per_gpu = a.agents
+    if a.workload == "mpa512":
+        per_gpu = per_gpu or 4096
+        total = per_gpu * world
+        iters = max(K + W, 3 * (K + W))      # keeps the whole run inside phase 1 (iter <= T/3), like early MPA iterations
+        sm = ShardedMPA(comm, lambda n: pathfit.MPA(grid, total, iters, engine=eng, seed=a.seed, n_local=n, **MPA_MAIN), total)
+        dominant = "k_mpa_phase"
+        it = 0
+
+        def step():
+            nonlocal it, kern_ms, kern_bytes, launches
+            it += 1
+            e = eng
+            # instrument the phase launch (dominant kernel) through the library's HIP-event timer + counters
+            orig = e.mpa_phase
+
+            def timed_phase(*args, **kw):
+                nonlocal kern_ms, kern_bytes, launches
+                orig(*args, **kw)
+                kern_ms += e.last_kernel_ms(); kern_bytes += astar_bytes(e.counters()); launches += 1
+            e.mpa_phase = timed_phase
+            try:
+                sm.step(it)
+            finally:
+                e.mpa_phase = orig
+        cfg = {"workload": "MPA 4096 predators/GPU, 512x512 G512 (BASELINE.json configs[2]), main.py:44-52 params, phase-1 iterations",
+               "agents_per_gpu": per_gpu, "grid": "G512=kron2(G256)", "grid_sha256": env.grid_hash(grid)[:16]}
+    elif a.workload == "maaco512":
+        per_gpu = per_gpu or 16384
+        total = per_gpu * world
+        sm = ShardedMAACO(comm, lambda: pathfit.MAACO(grid, total, 100, engine=eng, seed=a.seed, **MAACO_MAIN), total)
+        dominant = "k_maaco_walk"
+        it = 0
+
+        def step():
+            nonlocal it, kern_ms, kern_bytes, launches
+            it += 1
+            orig = eng.maaco_walk
+
+            def timed_walk(*args, **kw):
+                nonlocal kern_ms, kern_bytes, launches
+                orig(*args, **kw)
+                c = eng.counters()
+                kern_ms += eng.last_kernel_ms(); launches += 1
+                # 9 B window + 8 B tabu probes + 16 B per candidate (tau + eta) + 5 B path/tabu write
+                kern_bytes += 22 * c["steps"] + 16 * c["candidates"]
+            eng.maaco_walk = timed_walk
+            try:
+                sm.step(it)
+            finally:
+                eng.maaco_walk = orig
+        cfg = {"workload": "MAACO ants/GPU on 512x512 G512, main.py:34-38 params (walk + ordered pheromone update)",
+               "agents_per_gpu": per_gpu, "grid": "G512=kron2(G256)", "grid_sha256": env.grid_hash(grid)[:16]}
+    else:
+        per_gpu = per_gpu or 2048                     # BASELINE.json configs[3]: 16384 over 8 GPUs
+        Wp = 5
+        rng = np.random.default_rng(a.seed + rank)
+        free = np.flatnonzero(grid.reshape(-1) != 1)
+        sp = pathfit.score_params(0, True, 0.3, 0.8, 1.8, 100.0)
+        cap = 16 * 1024 + 64
+        d_cells, d_len, d_st, d_stats = eng.buf((per_gpu, cap), np.int32), eng.buf(per_gpu, np.int32), eng.buf(per_gpu, np.int32), eng.buf((per_gpu, 5), np.float64)
+        if a.workload == "ga512":
+            d_wp = eng.put(rng.choice(free, (per_gpu, Wp)).astype(np.int32).reshape(-1)); d_pos = None
+        else:
+            pos = rng.uniform(0, 511, (per_gpu, Wp, 2)); vel = rng.uniform(-15, 15, (per_gpu, Wp, 2))
+            d_pos, d_vel, d_pb, d_gb = eng.put(pos), eng.put(vel), eng.put(pos), eng.put(pos[0]); d_wp = None
+        dominant = "k_decode_batch"
+        it = 0
+
+        def step():
+            nonlocal it, kern_ms, kern_bytes, launches
+            it += 1
+            if d_pos is not None:
+                eng.pso_update(per_gpu, Wp, 0.7, 1.5, 1.5, 76.8, d_pos, d_vel, d_pb, d_gb, a.seed, it, rank * per_gpu)
+            eng.decode_batch(per_gpu, Wp, 0, 512 * 512 - 1, cap, d_cells, d_len, d_st, d_wp, d_pos, sp, d_stats)
+            kern_ms += eng.last_kernel_ms(); kern_bytes += astar_bytes(eng.counters()); launches += 1
+            if world > 1:       # gbest MINLOC exchange (C2)
+                comm.all_gather_concat(d_stats.download()[:, 4], [per_gpu] * world)
+        cfg = {"workload": f"{'GA' if a.workload == 'ga512' else 'PSO'} chained-waypoint decode+score, W=5, 2048 agents/GPU, G512 "
+                           "(BASELINE.json configs[3] per-GPU share)", "agents_per_gpu": per_gpu,
+               "grid_sha256": env.grid_hash(grid)[:16]}
+
+    for _ in range(W):
+        step()
+    kern_ms, kern_bytes, launches = 0.0, 0.0, 0
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    total_evals = per_gpu * world * K
+    value = total_evals / dt
+
+    roof = None
+    if launches:
+        avg_ms = kern_ms / launches
+        achieved = (kern_bytes / launches) / (avg_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "avg_launch_ms": round(avg_ms, 3), "algorithmic_bytes_per_launch": int(kern_bytes / launches)}
+
+    cpu = None
+    if rank == 0 and not a.no_cpu:
+        cpu = cpu_baseline(a.workload, grid, a.seed, a.cpu_seconds)
+
+    if rank == 0:
+        out = {"metric": "agent-fitness-evals/sec on 512x512 grid", "value": round(value, 2), "unit": "evals/s",
+               "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": cfg,
+               "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(workload, grid, seed, budget_s):
+    """Time the CPU oracle (the C port of the reference's algorithm; checker code, kind 'port') on a bounded
+    sample of the SAME workload, single thread."""
+    import pf_oracle as po
+    import pf_loops
+    orc = po.Oracle(grid)
+    s, t = 0, grid.size - 1
+    t0 = time.perf_counter()
+    n = 0
+    if workload == "mpa512":
+        ref = pf_loops.MpaOracle(orc, s, t, 4096, 15, FADs_rate=0.2, P_const=0.5, levy_beta=2.0, w_turn=0.1, w_safe=0.8,
+                                 min_safe=1.8, diag_pen=100.0, seed=seed)
+        ref._sort()
+        elite = ref.pop[0]
+        CF = (1.0 - 1 / 15) ** (2.0 / 15)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < budget_s and n < 4096:
+            cand = ref.phase_candidate(1, n, elite, CF)
+            ind = cand if cand[1][4] < ref.pop[n][1][4] else ref.pop[n]
+            ref.fads(1, n, ind, CF)
+            n += 1
+        sample = f"first {n} predators of iteration 1 (phase sweep + memory + FADs), same grid/params/seed"
+    elif workload == "maaco512":
+        P = po.MaacoParams(alpha=1.0, beta=7.0, rho=0.1, Q=2.5, a_turn=1.0, wh_max=0.9, wh_min=0.2, k_h=0.9, q0_initial=0.5,
+                           C0=0.1, num_iterations=100)
+        tau, dist = orc.maaco_init(s, t, 0.1)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < budget_s and n < 16384:
+            orc.maaco_walk(s, t, P, tau, dist, 1, seed, n)
+            n += 1
+        sample = f"first {n} ant walks of iteration 1, same grid/params/seed"
+    else:
+        rng = np.random.default_rng(seed)
+        free = np.flatnonzero(grid.reshape(-1) != 1)
+        wp = rng.choice(free, (2048, 5)).astype(np.int32)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < budget_s and n < 2048:
+            p, _ = orc.decode(s, t, wp[n])
+            orc.score(p, 0, 0.3, 0.8, 1.8, True, 100.0)
+            n += 1
+        sample = f"first {n} chromosomes (W=5 decode + score), same grid and seed"
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 3), "unit": "evals/s", "cores": 1, "kind": "port", "sample": sample,
+            "seconds": round(dt, 2)}
+
+
+if __name__ == "__main__":
+    main()

@@ -61,3 +61,25 @@ def find_marker(grid, val, who):
         what = "Start" if val == START_NODE_VAL else "Target"
         raise ValueError(f"{who}: {what} node not found in grid." if who in ("AStar", "MPA") else f"{who}: {what} node not found.")
     return (int(found[0][0]), int(found[0][1]))
+
+
+def g256():
+    """The 256x256 benchmark map G256: occupancy of the reference's
+    grid_map_from_image_data5 (env.py:114), shipped bit-packed as data; S=(0,0), T=(255,255)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "g256.npz"), allow_pickle=False)
+    R, C = (int(v) for v in z["shape"])
+    occ = np.unpackbits(z["bits"])[: R * C].reshape(R, C).astype(np.int64)
+    sr, sc, tr, tc = (int(v) for v in z["st"])
+    return mark(occ, (sr, sc), (tr, tc))
+
+
+def bench_grid(size):
+    """G256 / G512 / G1024 (np.kron upsample of G256's obstacle mask) or a seeded random-blocks G128."""
+    if size == 256:
+        return g256()
+    if size in (512, 1024):
+        return upsample(g256(), size // 256)
+    if size == 128:
+        return random_blocks(128, 128, 0.2, seed=128)
+    raise ValueError("bench grids: 128, 256, 512, 1024")

@@ -55,6 +55,7 @@ class MPA:
         self.best_fitness_overall = INF
         self.convergence_curve_data = []
         self.seed, self.verbose = int(seed), verbose
+        self.n_local = int(n_local) if n_local else int(num_predators)   # predators stored on this GPU (sharding)
         self.engine = engine if engine is not None else Engine(self.grid, device)
         self._s = self.start_node[0] * self.cols + self.start_node[1]
         self._t = self.target_node[0] * self.cols + self.target_node[1]
@@ -69,7 +70,7 @@ class MPA:
     # ------------------------------------------------------------------
     def _init_population(self):
         """MPA._initialize_population_with_safety (MPA.py:231-245): N identical A*(start, target) paths."""
-        e, N = self.engine, self.num_predators
+        e, N = self.engine, self.n_local
         while True:
             paths, st = e.astar_host(1, [self._s], [self._t], None, path_cap=self.path_cap,
                                      allow_diag=self.allow_diagonal_moves, restrict_corner=self.restrict_diagonal_near_obstacle)
@@ -128,7 +129,7 @@ class MPA:
 
     def step(self, it):
         """One iteration of MPA.py:332-440 (it is 1-based)."""
-        e, N, cap = self.engine, self.num_predators, self.path_cap
+        e, N, cap = self.engine, self.n_local, self.path_cap
         self._sort()                                                     # :333
         elite_slot = int(self.order[0])                                  # :334
         elite_len = int(self.d_len.download()[elite_slot])

@@ -58,7 +58,7 @@ class MpaOracle:
                  w_turn=0.1, w_safe=0.05, min_safe=1.5, diag_pen=1000.0, restrict=True, seed=0):
         self.o, self.s, self.t = orc, start, target
         self.N, self.K = num_predators, num_iterations
-        self.fads, self.P, self.beta, self.sigma = FADs_rate, P_const, levy_beta, levy_sigma(levy_beta)
+        self.fads_rate, self.P, self.beta, self.sigma = FADs_rate, P_const, levy_beta, levy_sigma(levy_beta)
         self.sw = (w_turn, w_safe, min_safe, restrict, diag_pen)
         self.seed = seed
         p, _ = orc.astar(start, target, None, 1)                    # MPA.py:231-245
@@ -105,7 +105,7 @@ class MpaOracle:
         """MPA.py:387-410 for predator i."""
         L, o = self.L, self.o
         g = o.rng(self.seed, DOM_MPA_FADS, it, i)
-        if L.orc_rng_random(C.byref(g)) < self.fads:
+        if L.orc_rng_random(C.byref(g)) < self.fads_rate:
             if L.orc_rng_random(C.byref(g)) < CF:
                 r = L.orc_rng_randint(C.byref(g), 0, o.R - 1)
                 c = L.orc_rng_randint(C.byref(g), 0, o.C - 1)
