@@ -29,6 +29,7 @@ struct DevCounters {
 struct Common {
   Grid G;
   Rec* rec;              // [nslots][RC]
+  char* tier2;           // [nslots][64*PF_T2*20] open-list overflow
   uint32_t* slot_state;  // [nslots][2] = {tag, avoid_ep}
   int* work;             // dynamic work counter
   DevCounters* cnt;
@@ -36,12 +37,16 @@ struct Common {
   int retry;             // only agents whose status == 3
 };
 
-PF_DEV Open make_open(char* smem, int S) {
+PF_DEV Open make_open(char* smem, int S, char* tier2) {
   Open O;
   O.lf = (double*)smem;
   O.lg = O.lf + 64 * S;
   O.lc = (int*)(O.lg + 64 * S);
   O.S = S;
+  char* t2 = tier2 + (size_t)blockIdx.x * (64 * PF_T2 * 20);
+  O.of = (double*)t2;
+  O.og = O.of + 64 * PF_T2;
+  O.oc = (int*)(O.og + 64 * PF_T2);
   return O;
 }
 static size_t open_bytes(int S) { return (size_t)64 * S * 20; }
@@ -60,7 +65,7 @@ PF_DEV void slot_store(const Common& c, const Slot& s, int lane) {
 // new agent evaluation: fresh avoid epoch; wipe the slot before an epoch can wrap
 PF_DEV void slot_begin_eval(Slot& s, int RC, int lane) {
   s.avoid_ep += 1;
-  if (s.avoid_ep >= 0x7FF0u || s.tag >= 0xFFFFF0u) slot_wipe(s, RC, lane);
+  if (s.avoid_ep >= 0x3FF0u || s.tag >= 0xFFFFF0u) slot_wipe(s, RC, lane);
 }
 PF_DEV int next_work(int* work, int lane) {
   int a = 0;
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(64) void k_astar_batch(AstarArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = lane_id();
   const int RC = p.c.G.R * p.c.G.C;
-  Open O = make_open(smem, p.c.S);
+  Open O = make_open(smem, p.c.S, p.c.tier2);
   Slot s = slot_load(p.c, RC);
   AStat tot = {0, 0, 0, 0, 0};
   unsigned long long cells = 0, ovf = 0;
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(64) void k_decode_batch(DecodeArgs p) {
   const int lane = lane_id();
   const Grid& G = p.c.G;
   const int RC = G.R * G.C;
-  Open O = make_open(smem, p.c.S);
+  Open O = make_open(smem, p.c.S, p.c.tier2);
   Slot s = slot_load(p.c, RC);
   AStat tot = {0, 0, 0, 0, 0};
   unsigned long long cells = 0, ovf = 0;
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(64) void k_mpa_phase(MpaPhaseArgs p) {
   const int lane = lane_id();
   const Grid& G = p.c.G;
   const int RC = G.R * G.C;
-  Open O = make_open(smem, p.c.S);
+  Open O = make_open(smem, p.c.S, p.c.tier2);
   Slot s = slot_load(p.c, RC);
   AStat tot = {0, 0, 0, 0, 0};
   unsigned long long cells = 0, ovf = 0;
@@ -616,7 +621,7 @@ __global__ __launch_bounds__(64) void k_mpa_fads(MpaFadsArgs p) {
   const int lane = lane_id();
   const Grid& G = p.c.G;
   const int RC = G.R * G.C;
-  Open O = make_open(smem, p.c.S);
+  Open O = make_open(smem, p.c.S, p.c.tier2);
   Slot s = slot_load(p.c, RC);
   AStat tot = {0, 0, 0, 0, 0};
   unsigned long long cells = 0, ovf = 0;
@@ -729,6 +734,7 @@ struct pf_handle {
   int nslots = 0;
   int rec_policy = -1;   // which move-mask variant the search records currently carry
   Rec* d_rec = nullptr;
+  char* d_tier2 = nullptr;
   uint32_t* d_slot_state = nullptr;
   int* d_work = nullptr;
   DevCounters* d_cnt = nullptr;
@@ -819,7 +825,7 @@ void pf_destroy(pf_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   void* ptrs[] = {h->d_occ, h->d_mm_r1, h->d_mm_r0, h->d_mm_r1_nd, h->d_mm_r0_nd, h->d_d2near, h->d_rec, h->d_slot_state,
-                  h->d_work, h->d_cnt, h->d_pen, h->d_tau, h->d_taua, h->d_eta, h->d_dep, h->d_visit, h->d_visit_epoch,
+                  h->d_work, h->d_cnt, h->d_pen, h->d_tier2, h->d_tau, h->d_taua, h->d_eta, h->d_dep, h->d_visit, h->d_visit_epoch,
                   h->d_bits, h->d_tmp, h->d_elite_stats};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -851,6 +857,7 @@ static int ensure_slots(pf_handle* h, int allow_diag = 1, int restrict_corner = 
     while (bytes > (64ull << 30) && h->nslots > cus) { h->nslots /= 2; bytes = (size_t)h->nslots * h->RC * sizeof(Rec); }
     CK(hipMalloc(&h->d_rec, bytes));
     CK(hipMalloc(&h->d_slot_state, sizeof(uint32_t) * 2 * h->nslots));
+    CK(hipMalloc(&h->d_tier2, (size_t)h->nslots * 64 * PF_T2 * 20));
   }
   const int policy = (allow_diag ? 2 : 0) | (restrict_corner ? 1 : 0);
   if (h->rec_policy != policy) {
@@ -869,7 +876,7 @@ static int ensure_slots(pf_handle* h, int allow_diag = 1, int restrict_corner = 
 static Common make_common(pf_handle* h, int allow_diag, int restrict_corner, int S, int retry) {
   Common c;
   c.G = make_grid(h, allow_diag, restrict_corner);
-  c.rec = h->d_rec; c.slot_state = h->d_slot_state; c.work = h->d_work; c.cnt = h->d_cnt; c.S = S; c.retry = retry;
+  c.rec = h->d_rec; c.tier2 = h->d_tier2; c.slot_state = h->d_slot_state; c.work = h->d_work; c.cnt = h->d_cnt; c.S = S; c.retry = retry;
   return c;
 }
 static int begin_batch(pf_handle* h) {

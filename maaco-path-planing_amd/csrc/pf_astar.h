@@ -38,13 +38,18 @@ struct Open {
   double* lg;
   int* lc;     // packed (r<<16)|c
   int S;
+  // tier 2: PF_T2 more slots per bin in this agent's HBM scratch, used only when a bin's LDS slots are
+  // full, so a search never has to restart with a larger LDS footprint
+  double* of;  // [64*PF_T2]
+  double* og;
+  int* oc;
 };
 
 struct Slot {
   Rec* rec;
   const uint8_t* mm;  // move masks the records were initialised from (for the wrap wipe)
   uint32_t tag;       // solve epoch (24 bit)
-  uint32_t avoid_ep;  // eval epoch (15 bit)
+  uint32_t avoid_ep;  // eval epoch (14 bit)
 };
 
 struct AStat {
@@ -121,7 +126,7 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
 
   // all slots of this lane's bin free
   for (int j = 0; j < S; ++j) O.lf[lane * S + j] = PF_INF;
-  unsigned long long occ = 0;
+  unsigned long long occ = 0, occ2 = 0;   // tier-1 (LDS) / tier-2 (HBM) slot occupancy of this lane's bin
   double mf = PF_INF, mg = 0.0;
   int mc = 0, ms = 0;
   int rr = 1;          // lane of move 0 for the current pop (rotates)
@@ -166,7 +171,10 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
     Rec rn; rn.g = 0.0; rn.tagmm = 0; rn.meta = 0;
     if (inb || d == 8) rn = rec[inb ? nidx : cur];
     // ---- free the popped slot and rescan bin w (LDS; overlaps the load) ----
-    if (lane == w) { occ &= ~(1ull << pslot); O.lf[w * S + pslot] = PF_INF; }
+    if (lane == w) {
+      if (pslot < S) { occ &= ~(1ull << pslot); O.lf[w * S + pslot] = PF_INF; }
+      else occ2 &= ~(1ull << (pslot - S));
+    }
     n_open -= 1;
     {
       double vf = PF_INF, vg = 0.0; int vc = 0;
@@ -174,8 +182,21 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
       const unsigned long long t2 = S <= 16 ? (argmin_mask_d<true>(vf) & 0xFFFFull) : argmin_mask_d<false>(vf);
       int j = __builtin_ctzll(t2);
       if (t2 & (t2 - 1)) j = resolve_tie(t2, vg, vc);
-      const double jf = bcast_d(vf, j), jg = bcast_d(vg, j);
-      const int jc = bcast_i(vc, j);
+      double jf = bcast_d(vf, j), jg = bcast_d(vg, j);
+      int jc = bcast_i(vc, j);
+      const unsigned o2lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)occ2, w);
+      const unsigned o2hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(occ2 >> 32), w);
+      const unsigned long long o2 = ((unsigned long long)o2hi << 32) | o2lo;
+      if (o2) {                                               // the bin also has tier-2 entries: scan them too
+        double uf = PF_INF, ug = 0.0; int uc = 0;
+        if ((o2 >> lane) & 1ull) { uf = O.of[w * PF_T2 + lane]; ug = O.og[w * PF_T2 + lane]; uc = O.oc[w * PF_T2 + lane]; }
+        const unsigned long long t3 = argmin_mask_d<false>(uf);
+        int j3 = __builtin_ctzll(t3);
+        if (t3 & (t3 - 1)) j3 = resolve_tie(t3, ug, uc);
+        const double kf = bcast_d(uf, j3), kg = bcast_d(ug, j3);
+        const int kc = bcast_i(uc, j3);
+        if (jf == PF_INF || ent_lt(kf, kg, kc, jf, jg, jc)) { jf = kf; jg = kg; jc = kc; j = S + j3; }
+      }
       if (lane == w) { mf = jf; mg = jg; mc = jc; ms = j; }   // jf == +inf when the bin is now empty
     }
     // ---- the popped cell's own record (lane rr+8) ----
@@ -210,18 +231,28 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
       long dr1 = nr - tr, dc1 = nc - tc;
       fnew = tent + __builtin_sqrt((double)(dr1 * dr1 + dc1 * dc1));   // astar.py:90 / MPA.py:140
       if (push) {
-        if (occ == full) ovf = true;
-        else {
-          const int slot = __builtin_ctzll(~occ);
+        const int prc = (nr << 16) | nc;
+        int slot = -1;
+        if (occ != full) {
+          slot = __builtin_ctzll(~occ);
           occ |= 1ull << slot;
           const int a = lane * S + slot;
-          O.lf[a] = fnew; O.lg[a] = tent; O.lc[a] = (nr << 16) | nc;
-          if (mf == PF_INF || ent_lt(fnew, tent, (nr << 16) | nc, mf, mg, mc)) { mf = fnew; mg = tent; mc = (nr << 16) | nc; ms = slot; }
-          pos = ((unsigned)lane << 6) | (unsigned)slot;
+          O.lf[a] = fnew; O.lg[a] = tent; O.lc[a] = prc;
+        } else if (occ2 != ~0ull) {                           // LDS slots of this bin are full: spill to HBM tier 2
+          const int j2 = __builtin_ctzll(~occ2);
+          occ2 |= 1ull << j2;
+          const int a = lane * PF_T2 + j2;
+          O.of[a] = fnew; O.og[a] = tent; O.oc[a] = prc;
+          slot = S + j2;
+        } else ovf = true;
+        if (slot >= 0) {
+          if (mf == PF_INF || ent_lt(fnew, tent, prc, mf, mg, mc)) { mf = fnew; mg = tent; mc = prc; ms = slot; }
+          pos = ((unsigned)lane << 7) | (unsigned)slot;
         }
       } else if (deckey) {
-        const int a = (int)(pos >> 6) * S + (int)(pos & 63u);
-        O.lf[a] = fnew; O.lg[a] = tent;
+        const int b = (int)(pos >> 7), sl = (int)(pos & 127u);
+        if (sl < S) { O.lf[b * S + sl] = fnew; O.lg[b * S + sl] = tent; }
+        else { O.of[b * PF_T2 + sl - S] = fnew; O.og[b * PF_T2 + sl - S] = tent; }
       }
       if (!ovf) {
         Rec wv; wv.g = tent; wv.tagmm = (tag << PF_TAG_SHIFT) | (rn.tagmm & 0xFFu);
@@ -239,27 +270,35 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
         const unsigned p2 = (unsigned)bcast_i((int)pos, l);
         const double f2 = bcast_d(fnew, l), g2 = bcast_d(tent, l);
         const int c2 = (bcast_i(nr, l) << 16) | bcast_i(nc, l);
-        if (lane == (int)(p2 >> 6) && ((int)(p2 & 63u) == ms || ent_lt(f2, g2, c2, mf, mg, mc))) { mf = f2; mg = g2; mc = c2; ms = (int)(p2 & 63u); }
+        if (lane == (int)(p2 >> 7) && ((int)(p2 & 127u) == ms || ent_lt(f2, g2, c2, mf, mg, mc))) { mf = f2; mg = g2; mc = c2; ms = (int)(p2 & 127u); }
       }
     }
-    // ---- own bin full: hand the entry to any lane with room ----
+    // ---- own bin full in both tiers: hand the entry to any lane with room ----
     unsigned long long om = __ballot(ovf);
     while (om) {
       const int l = __builtin_ctzll(om); om &= om - 1;
-      const unsigned long long freem = __ballot(occ != full);
-      if (!freem) { status = 3; break; }                     // all 64*S slots used: caller retries with a larger S
+      const unsigned long long freem = __ballot(occ != full || occ2 != ~0ull);
+      if (!freem) { status = 3; break; }                     // all 64*(S+PF_T2) slots used
       const int t = __builtin_ctzll(freem);
       const double f2 = bcast_d(fnew, l), g2 = bcast_d(tent, l);
       const int r2 = bcast_i(nr, l), c2 = bcast_i(nc, l), dd = bcast_i(d, l);
       const uint32_t tm2 = (uint32_t)bcast_i((int)rn.tagmm, l), me2 = (uint32_t)bcast_i((int)rn.meta, l);
       if (lane == t) {
-        const int slot = __builtin_ctzll(~occ);
-        occ |= 1ull << slot;
-        const int a = lane * S + slot, prc2 = (r2 << 16) | c2;
-        O.lf[a] = f2; O.lg[a] = g2; O.lc[a] = prc2;
+        const int prc2 = (r2 << 16) | c2;
+        int slot;
+        if (occ != full) {
+          slot = __builtin_ctzll(~occ); occ |= 1ull << slot;
+          const int a = lane * S + slot;
+          O.lf[a] = f2; O.lg[a] = g2; O.lc[a] = prc2;
+        } else {
+          const int j2 = __builtin_ctzll(~occ2); occ2 |= 1ull << j2;
+          const int a = lane * PF_T2 + j2;
+          O.of[a] = f2; O.og[a] = g2; O.oc[a] = prc2;
+          slot = S + j2;
+        }
         if (mf == PF_INF || ent_lt(f2, g2, prc2, mf, mg, mc)) { mf = f2; mg = g2; mc = prc2; ms = slot; }
         Rec wv; wv.g = g2; wv.tagmm = (tag << PF_TAG_SHIFT) | (tm2 & 0xFFu);
-        wv.meta = (me2 & PF_AVOID_KEEP) | ((((unsigned)lane << 6) | (unsigned)slot) << PF_POS_SHIFT) | (unsigned)(dd & 7) |
+        wv.meta = (me2 & PF_AVOID_KEEP) | ((((unsigned)lane << 7) | (unsigned)slot) << PF_POS_SHIFT) | (unsigned)(dd & 7) |
                   (VARIANT == 1 ? PF_M_INOPEN : 0u);
         rec[r2 * C + c2] = wv;
       }

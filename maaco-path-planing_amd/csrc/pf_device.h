@@ -21,15 +21,16 @@ namespace pf {
 struct __attribute__((aligned(16))) Rec {
   double g;
   uint32_t tagmm;  // [7:0] static move mask of the cell (helper order, this handle's diagonal policy), [31:8] solve epoch
-  uint32_t meta;   // [2:0] parent move, [3] closed, [4] in-open, [16:5] open-list position (bin<<6|slot), [31:17] avoid epoch
+  uint32_t meta;   // [2:0] parent move, [3] closed, [4] in-open, [17:5] open-list position (bin<<7|slot), [31:18] avoid epoch
 };
 #define PF_M_PARENT 7u
 #define PF_M_CLOSED 8u
 #define PF_M_INOPEN 16u
 #define PF_POS_SHIFT 5
-#define PF_POS_MASK 0xFFFu
-#define PF_AVOID_SHIFT 17
-#define PF_AVOID_KEEP 0xFFFE0000u
+#define PF_POS_MASK 0x1FFFu
+#define PF_AVOID_SHIFT 18
+#define PF_AVOID_KEEP 0xFFFC0000u
+#define PF_T2 64 /* tier-2 (HBM) overflow slots per bin */
 #define PF_TAG_SHIFT 8
 
 // helper.py:30-36 / MPA.py:71-77 move order
