@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -32,6 +34,7 @@ struct Common {
   char* tier2;           // [nslots][64*PF_T2*20] open-list overflow
   uint32_t* slot_state;  // [nslots][2] = {tag, avoid_ep}
   int* work;             // dynamic work counter
+  const int* queue;      // optional work order (longest-expected-first), else identity
   DevCounters* cnt;
   int S;                 // LDS bin capacity
   int retry;             // only agents whose status == 3
@@ -71,6 +74,13 @@ PF_DEV int next_work(int* work, int lane) {
   int a = 0;
   if (lane == 0) a = atomicAdd(work, 1);
   return first_i(a);
+}
+// dynamic work distribution in longest-expected-first order (the batch finishes when its longest search
+// does, so long searches must start first); returns -1 when the queue is drained
+PF_DEV int next_agent(const Common& c, int n, int lane) {
+  const int w = next_work(c.work, lane);
+  if (w >= n) return -1;
+  return c.queue ? c.queue[w] : w;
 }
 PF_DEV void flush_counters(DevCounters* c, const AStat& st, unsigned long long cells, unsigned long long ovf, int lane) {
   if (lane == 0) {
@@ -115,6 +125,37 @@ __global__ void k_slot_init(Rec* rec, const uint8_t* mm, int RC, size_t total) {
 }
 
 // ===========================================================================
+// work estimates (longest-expected-first scheduling)
+// ===========================================================================
+PF_DEV float cell_dist(const Grid& G, int a, int b) {
+  const int ar = a / G.C, ac = a - ar * G.C, br = b / G.C, bc = b - br * G.C;
+  const float dr = (float)(ar - br), dc = (float)(ac - bc);
+  return sqrtf(dr * dr + dc * dc);
+}
+__global__ void k_plan_astar(Grid G, int n, const int* start, const int* target, float* est) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a < n) est[a] = cell_dist(G, start[a], target[a]);
+}
+__global__ void k_plan_decode(Grid G, int n, int W, const int* wp_cells, const double* wp_pos, int start, int target, float* est) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n) return;
+  int cur = start; float e = 0.f;
+  for (int k = 0; k <= W; ++k) {
+    int goal = target;
+    if (k < W) {
+      if (wp_cells) goal = wp_cells[(size_t)a * W + k];
+      else {
+        long r = (long)__builtin_rint(wp_pos[((size_t)a * W + k) * 2]), c = (long)__builtin_rint(wp_pos[((size_t)a * W + k) * 2 + 1]);
+        r = r < 0 ? 0 : (r > G.R - 1 ? G.R - 1 : r); c = c < 0 ? 0 : (c > G.C - 1 ? G.C - 1 : c);
+        goal = (int)(r * G.C + c);
+      }
+    }
+    e += cell_dist(G, cur, goal); cur = goal;
+  }
+  est[a] = e;
+}
+
+// ===========================================================================
 // K2: A* connector batch
 // ===========================================================================
 struct AstarArgs {
@@ -135,8 +176,8 @@ __global__ __launch_bounds__(64) void k_astar_batch(AstarArgs p) {
   AStat tot = {0, 0, 0, 0, 0};
   unsigned long long cells = 0, ovf = 0;
   for (;;) {
-    const int a = next_work(p.c.work, lane);
-    if (a >= p.n) break;
+    const int a = next_agent(p.c, p.n, lane);
+    if (a < 0) break;
     if (p.c.retry && p.status[a] != 3) continue;
     slot_begin_eval(s, RC, lane);
     if (p.avoid_off) {
@@ -197,8 +238,8 @@ __global__ __launch_bounds__(64) void k_decode_batch(DecodeArgs p) {
   AStat tot = {0, 0, 0, 0, 0};
   unsigned long long cells = 0, ovf = 0;
   for (;;) {
-    const int a = next_work(p.c.work, lane);
-    if (a >= p.n) break;
+    const int a = next_agent(p.c, p.n, lane);
+    if (a < 0) break;
     if (p.c.retry && p.status[a] != 3) continue;
     slot_begin_eval(s, RC, lane);
     int* out = p.cells + (size_t)a * p.path_cap;
@@ -524,8 +565,8 @@ __global__ __launch_bounds__(64) void k_mpa_phase(MpaPhaseArgs p) {
   AStat tot = {0, 0, 0, 0, 0};
   unsigned long long cells = 0, ovf = 0;
   for (;;) {
-    const int a = next_work(p.c.work, lane);
-    if (a >= p.n) break;
+    const int a = next_agent(p.c, p.n, lane);
+    if (a < 0) break;
     if (p.c.retry && p.status[a] != 3) continue;
     const int gi = p.ex_idx ? p.ex_agent[a] : p.gidx[a];         // index in the fitness-sorted population
     const int slot = p.ex_idx ? a : p.slot[a];
@@ -614,6 +655,9 @@ struct MpaFadsArgs {
   int* pop_cells; int* pop_len; double* pop_stats; const int* gidx; const int* slot;
   int* tmp_cells;   // [nslots][path_cap]
   int* status;
+  // MPA._generate_initial_path() (MPA.py:154) is a pure function of the grid: A*(start,target) with no
+  // avoid set.  It is computed once (pf_mpa_setup) and reused by the FADs re-init branch (:405).
+  const int* init_cells; int init_len; const double* init_stats;
 };
 // FADs sweep MPA.py:387-410, in place on the post-memory population.
 __global__ __launch_bounds__(64) void k_mpa_fads(MpaFadsArgs p) {
@@ -627,13 +671,13 @@ __global__ __launch_bounds__(64) void k_mpa_fads(MpaFadsArgs p) {
   unsigned long long cells = 0, ovf = 0;
   int* tmp = p.tmp_cells + (size_t)blockIdx.x * p.path_cap;
   for (;;) {
-    const int a = next_work(p.c.work, lane);
-    if (a >= p.n) break;
+    const int a = next_agent(p.c, p.n, lane);
+    if (a < 0) break;
     if (p.c.retry && p.status[a] != 3) continue;
     const int gi = p.gidx[a];
     const int slot = p.slot[a];
     int rc = 4, n = 0;
-    bool have = false;
+    bool have = false, have_stats = false;
     Rng g; g.init(p.seed, DOM_MPA_FADS, (unsigned long long)p.iter, (unsigned long long)gi);
     if (g.random() < p.m.fads) {                                   // :389
       slot_begin_eval(s, RC, lane);
@@ -653,16 +697,15 @@ __global__ __launch_bounds__(64) void k_mpa_fads(MpaFadsArgs p) {
             else if (r2 == 0 && m2 > 0) { n = m1 + m2 - 1; have = true; }   // :398-400 (last is the target by construction)
           }
         }
-      } else {
-        int m1 = 0;
-        int r1 = astar<1>(G, s, O, p.m.start, p.m.target, tmp, p.path_cap, m1, tot, lane);   // :405
-        if (r1 == 3) rc = 3;
-        else if (r1 == 0 && m1 > 0) { n = m1; have = true; }
+      } else if (p.init_len > 0) {                                 // :405 re-init path (memoised, see MpaFadsArgs)
+        if (p.init_len > p.path_cap) rc = 3;
+        else { copy_path(tmp, p.init_cells, p.init_len, lane); n = p.init_len; have = true; have_stats = true; }
       }
     }
     if (have) {
       double sc[5];
-      score_path(G, p.sp, tmp, n, lane, sc);
+      if (have_stats) { for (int i = 0; i < 5; ++i) sc[i] = p.init_stats[i]; }
+      else score_path(G, p.sp, tmp, n, lane, sc);
       const double curfit = p.pop_stats[(size_t)slot * 5 + 4];
       if (sc[4] < curfit) {                                        // :402 / :408
         copy_path(p.pop_cells + (size_t)slot * p.path_cap, tmp, n, lane);
@@ -676,6 +719,39 @@ __global__ __launch_bounds__(64) void k_mpa_fads(MpaFadsArgs p) {
   }
   slot_store(p.c, s, lane);
   flush_counters(p.c.cnt, tot, cells, ovf, lane);
+}
+
+// work estimates for the two MPA sweeps: replay only the gating draws of each predator's stream
+__global__ void k_plan_mpa_phase(MpaPhaseArgs p, float* est) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= p.n) return;
+  float e = 0.f;
+  if (p.ex_idx) { const int L = p.pop_len[a]; e = p.ex_idx[a] < L - 1 ? (float)(L - p.ex_idx[a]) : 0.f; }
+  else {
+    const int gi = p.gidx[a], slot = p.slot[a];
+    int modL; double gate_p;
+    if (p.phase == 1) { modL = p.pop_len[slot]; gate_p = p.m.P; }
+    else if (p.phase == 2) { const bool lv = gi < p.m.N / 2; modL = lv ? p.pop_len[slot] : p.elite_len; gate_p = lv ? p.m.P : p.m.P * p.CF; }
+    else { modL = p.elite_len; gate_p = p.m.P * p.CF; }
+    if (modL > 1) {
+      Rng g; g.init(p.seed, DOM_MPA, (unsigned long long)p.iter, (unsigned long long)gi);
+      const int idx = (int)g.randint(0, modL - 2);
+      if (g.random() < gate_p) e = (float)(modL - idx);
+    }
+  }
+  est[a] = e;
+}
+__global__ void k_plan_mpa_fads(MpaFadsArgs p, float* est) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= p.n) return;
+  float e = 0.f;
+  Rng g; g.init(p.seed, DOM_MPA_FADS, (unsigned long long)p.iter, (unsigned long long)p.gidx[a]);
+  if (g.random() < p.m.fads && g.random() < p.CF) {
+    const int rr_ = (int)g.randint(0, p.c.G.R - 1), rc_ = (int)g.randint(0, p.c.G.C - 1);
+    const int node = rr_ * p.c.G.C + rc_;
+    if (p.c.G.occ[node] != 1) e = cell_dist(p.c.G, p.m.start, node) + cell_dist(p.c.G, node, p.m.target);
+  }
+  est[a] = e;
 }
 
 // memory step MPA.py:381-384
@@ -756,6 +832,8 @@ struct pf_handle {
   pf_score_params mps = {};
   int* d_tmp = nullptr; int tmp_cap = 0;
   double* d_elite_stats = nullptr;
+  int* d_init_cells = nullptr; int init_len = 0; int init_cap = 0; double* d_init_stats = nullptr;
+  float* d_est = nullptr; int* d_queue = nullptr; int est_cap = 0;
 };
 
 static std::string g_create_err;
@@ -826,7 +904,7 @@ void pf_destroy(pf_handle* h) {
   (void)hipSetDevice(h->device);
   void* ptrs[] = {h->d_occ, h->d_mm_r1, h->d_mm_r0, h->d_mm_r1_nd, h->d_mm_r0_nd, h->d_d2near, h->d_rec, h->d_slot_state,
                   h->d_work, h->d_cnt, h->d_pen, h->d_tier2, h->d_tau, h->d_taua, h->d_eta, h->d_dep, h->d_visit, h->d_visit_epoch,
-                  h->d_bits, h->d_tmp, h->d_elite_stats};
+                  h->d_bits, h->d_tmp, h->d_elite_stats, h->d_init_cells, h->d_init_stats, h->d_est, h->d_queue};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -845,7 +923,10 @@ float pf_last_kernel_ms(pf_handle* h) { return h->last_ms; }
 }  // extern "C"
 
 // ---- scratch / launch helpers ----------------------------------------------
-static const int kSlotsPerCU = 8;
+// resident agent slots per CU and LDS bin capacity; PF_SLOTS_PER_CU / PF_LDS_S override for experiments
+static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; }
+static const int kSlotsPerCU = env_int("PF_SLOTS_PER_CU", 8);
+static const int kLdsS = env_int("PF_LDS_S", 16);
 static int ensure_slots(pf_handle* h, int allow_diag = 1, int restrict_corner = 1) {
   CK(hipSetDevice(h->device));
   if (!h->d_rec) {
@@ -876,7 +957,7 @@ static int ensure_slots(pf_handle* h, int allow_diag = 1, int restrict_corner = 
 static Common make_common(pf_handle* h, int allow_diag, int restrict_corner, int S, int retry) {
   Common c;
   c.G = make_grid(h, allow_diag, restrict_corner);
-  c.rec = h->d_rec; c.tier2 = h->d_tier2; c.slot_state = h->d_slot_state; c.work = h->d_work; c.cnt = h->d_cnt; c.S = S; c.retry = retry;
+  c.rec = h->d_rec; c.tier2 = h->d_tier2; c.slot_state = h->d_slot_state; c.work = h->d_work; c.queue = nullptr; c.cnt = h->d_cnt; c.S = S; c.retry = retry;
   return c;
 }
 static int begin_batch(pf_handle* h) {
@@ -891,36 +972,49 @@ static int end_batch(pf_handle* h, DevCounters* dc) {
   h->last.steps = dc->steps; h->last.candidates = dc->candidates; h->last.decrease_keys = dc->deckey; h->last.overflow_agents = dc->overflow;
   return 0;
 }
-// LDS bin capacities tried in order; a retry pass re-runs only agents that overflowed
-static const int kS[] = {16, 32, 64};
+
+// Sort the batch longest-expected-first from per-agent estimates produced by `plan` (a functor that
+// launches a plan kernel writing h->d_est[0..n)).
+template <typename Plan>
+static int make_queue(pf_handle* h, int n, Plan plan) {
+  if (n > h->est_cap) {
+    if (h->d_est) CK(hipFree(h->d_est));
+    if (h->d_queue) CK(hipFree(h->d_queue));
+    CK(hipMalloc(&h->d_est, sizeof(float) * (size_t)n)); CK(hipMalloc(&h->d_queue, sizeof(int) * (size_t)n));
+    h->est_cap = n;
+  }
+  plan(h->d_est);
+  CK(hipGetLastError());
+  std::vector<float> est(n);
+  CK(hipMemcpyAsync(est.data(), h->d_est, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+  CK(hipStreamSynchronize(h->stream));
+  std::vector<int> q(n);
+  for (int i = 0; i < n; ++i) q[i] = i;
+  std::stable_sort(q.begin(), q.end(), [&](int a, int b) { return est[a] > est[b]; });
+  CK(hipMemcpyAsync(h->d_queue, q.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+  CK(hipStreamSynchronize(h->stream));
+  return 0;
+}
 
 template <typename KArgs, typename Kern>
 static int launch_with_retry(pf_handle* h, Kern kern, KArgs& args, int n) {
   if (n <= 0) return 0;
-  DevCounters total = {}; float ms_total = 0.f;
-  for (int pass = 0; pass < 3; ++pass) {
-    const int S = kS[pass];
-    args.c.S = S; args.c.retry = pass > 0;
-    const size_t lds = open_bytes(S);
-    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int per_cu = (int)((160 * 1024) / lds); if (per_cu > kSlotsPerCU) per_cu = kSlotsPerCU; if (per_cu < 1) per_cu = 1;
-    int grid = (h->nslots / kSlotsPerCU) * per_cu; if (grid > n) grid = n; if (grid > h->nslots) grid = h->nslots;
-    CK(hipMemsetAsync(h->d_work, 0, sizeof(int), h->stream));
-    CK(hipMemsetAsync(h->d_cnt, 0, sizeof(DevCounters), h->stream));
-    CK(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, h->stream, args);
-    CK(hipGetLastError());
-    CK(hipEventRecord(h->ev1, h->stream));
-    DevCounters dc;
-    if (end_batch(h, &dc)) return -1;
-    float ms = 0.f; CK(hipEventElapsedTime(&ms, h->ev0, h->ev1)); ms_total += ms;
-    total.pops += dc.pops; total.pushes += dc.pushes; total.nbr += dc.nbr; total.path_cells += dc.path_cells;
-    total.deckey += dc.deckey; total.overflow = dc.overflow;
-    if (dc.overflow == 0) break;
-  }
-  h->last.pops = total.pops; h->last.pushes = total.pushes; h->last.nbr_examined = total.nbr; h->last.path_cells = total.path_cells;
-  h->last.decrease_keys = total.deckey; h->last.overflow_agents = total.overflow; h->last.steps = 0; h->last.candidates = 0;
-  h->last_ms = ms_total;
+  // LDS bin capacity S = 16 (20 KiB per agent); bins spill to the HBM tier, so there is no retry pass.
+  const int S = kLdsS;
+  args.c.S = S; args.c.retry = 0;
+  const size_t lds = open_bytes(S);
+  CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int per_cu = (int)((160 * 1024) / lds); if (per_cu > kSlotsPerCU) per_cu = kSlotsPerCU; if (per_cu < 1) per_cu = 1;
+  int grid = (h->nslots / kSlotsPerCU) * per_cu; if (grid > n) grid = n; if (grid > h->nslots) grid = h->nslots;
+  CK(hipMemsetAsync(h->d_work, 0, sizeof(int), h->stream));
+  CK(hipMemsetAsync(h->d_cnt, 0, sizeof(DevCounters), h->stream));
+  CK(hipEventRecord(h->ev0, h->stream));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, h->stream, args);
+  CK(hipGetLastError());
+  CK(hipEventRecord(h->ev1, h->stream));
+  DevCounters dc;
+  if (end_batch(h, &dc)) return -1;
+  CK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
   return 0;
 }
 
@@ -959,6 +1053,10 @@ int pf_astar_batch(pf_handle* h, int32_t variant, int32_t allow_diag, int32_t re
   a.n = n; a.path_cap = path_cap; a.start = d_start; a.target = d_target;
   a.avoid_off = (const long long*)d_avoid_off; a.avoid_cells = d_avoid_cells;
   a.cells = d_cells; a.len = d_len; a.status = d_status; a.counters = (long long*)d_counters;
+  if (n > 64) {
+    if (make_queue(h, n, [&](float* est) { hipLaunchKernelGGL(k_plan_astar, dim3((n + 255) / 256), dim3(256), 0, h->stream, a.c.G, n, d_start, d_target, est); })) return -1;
+    a.c.queue = h->d_queue;
+  }
   if (variant == PF_ASTAR_REF) return launch_with_retry(h, k_astar_batch<0>, a, n);
   if (variant == PF_ASTAR_MPA) return launch_with_retry(h, k_astar_batch<1>, a, n);
   return failmsg(h, "pf_astar_batch: unknown variant");
@@ -999,6 +1097,10 @@ int pf_decode_batch(pf_handle* h, int32_t allow_diag, int32_t restrict_corner, i
   if (sp) { if (make_scorep(h, sp, &a.sp)) return -1; } else memset(&a.sp, 0, sizeof(a.sp));
   a.n = n; a.W = W; a.path_cap = path_cap; a.start = start; a.target = target;
   a.wp_cells = d_wp_cells; a.wp_pos = d_wp_pos; a.cells = d_cells; a.len = d_len; a.status = d_status; a.stats = d_stats;
+  if (n > 64) {
+    if (make_queue(h, n, [&](float* est) { hipLaunchKernelGGL(k_plan_decode, dim3((n + 255) / 256), dim3(256), 0, h->stream, a.c.G, n, W, d_wp_cells, d_wp_pos, start, target, est); })) return -1;
+    a.c.queue = h->d_queue;
+  }
   return launch_with_retry(h, k_decode_batch, a, n);
 }
 
@@ -1226,7 +1328,27 @@ int pf_mpa_setup(pf_handle* h, const pf_mpa_params* p, const pf_score_params* sp
   if (!h) return -2;
   if (!p || !sp || p->start < 0 || p->start >= h->RC || p->target < 0 || p->target >= h->RC) return failmsg(h, "pf_mpa_setup: bad arguments");
   h->mpp = *p; h->mps = *sp; h->mpa_ready = true;
-  return ensure_slots(h, p->allow_diag, p->restrict_corner);
+  if (ensure_slots(h, p->allow_diag, p->restrict_corner)) return -1;
+  // memoise MPA._generate_initial_path() = _a_star(start, target) (MPA.py:154) and its stats
+  const int cap = h->RC;
+  if (h->init_cap < cap) {
+    if (h->d_init_cells) CK(hipFree(h->d_init_cells));
+    CK(hipMalloc(&h->d_init_cells, sizeof(int) * (size_t)cap)); h->init_cap = cap;
+  }
+  if (!h->d_init_stats) CK(hipMalloc(&h->d_init_stats, sizeof(double) * 5));
+  int *d_s = nullptr, *d_t = nullptr, *d_l = nullptr, *d_st = nullptr;
+  CK(hipMalloc(&d_s, 4 * sizeof(int))); d_t = d_s + 1; d_l = d_s + 2; d_st = d_s + 3;
+  int hv[4] = {p->start, p->target, 0, 0};
+  CK(hipMemcpyAsync(d_s, hv, sizeof(hv), hipMemcpyHostToDevice, h->stream));
+  int rc = pf_astar_batch(h, PF_ASTAR_MPA, p->allow_diag, p->restrict_corner, 1, d_s, d_t, nullptr, nullptr, cap, h->d_init_cells, d_l, d_st, nullptr);
+  if (rc == 0) {
+    CK(hipMemcpyAsync(hv, d_s, sizeof(hv), hipMemcpyDeviceToHost, h->stream));
+    CK(hipStreamSynchronize(h->stream));
+    h->init_len = hv[3] == 0 ? hv[2] : 0;
+    rc = pf_score_batch(h, sp, 1, cap, h->d_init_cells, d_l, h->d_init_stats);
+  }
+  (void)hipFree(d_s);
+  return rc;
 }
 static MpaDev mpa_dev(const pf_handle* h) {
   MpaDev m; m.P = h->mpp.P_const; m.levy_beta = h->mpp.levy_beta; m.sigma = h->mpp.levy_sigma; m.fads = h->mpp.FADs_rate;
@@ -1253,6 +1375,10 @@ int pf_mpa_phase_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uin
   a.elite_stats = d_elite_stats;
   a.out_cells = d_out_cells; a.out_len = d_out_len; a.out_stats = d_out_stats; a.status = d_status;
   a.ex_idx = nullptr; a.ex_levy = nullptr; a.ex_scale = nullptr; a.ex_agent = nullptr;
+  if (n > 64) {
+    if (make_queue(h, n, [&](float* est) { hipLaunchKernelGGL(k_plan_mpa_phase, dim3((n + 255) / 256), dim3(256), 0, h->stream, a, est); })) return -1;
+    a.c.queue = h->d_queue;
+  }
   return launch_with_retry(h, k_mpa_phase, a, n);
 }
 
@@ -1294,6 +1420,11 @@ int pf_mpa_fads_batch(pf_handle* h, double CF, int32_t iter, uint64_t seed, int3
   a.m = mpa_dev(h); a.iter = iter; a.CF = CF; a.seed = seed; a.n = n; a.path_cap = path_cap;
   a.pop_cells = d_pop_cells; a.pop_len = d_pop_len; a.pop_stats = d_pop_stats; a.gidx = d_gidx; a.slot = d_slot;
   a.tmp_cells = h->d_tmp; a.status = d_status;
+  a.init_cells = h->d_init_cells; a.init_len = h->init_len; a.init_stats = h->d_init_stats;
+  if (n > 64) {
+    if (make_queue(h, n, [&](float* est) { hipLaunchKernelGGL(k_plan_mpa_fads, dim3((n + 255) / 256), dim3(256), 0, h->stream, a, est); })) return -1;
+    a.c.queue = h->d_queue;
+  }
   return launch_with_retry(h, k_mpa_fads, a, n);
 }
 

@@ -1,0 +1,76 @@
+"""N>1 path on CPU: world_size-2 gloo ranks run the sharded MAACO loop (pathfit/dist.py) over oracle-backed
+stand-ins; the result must equal the single-rank loop bit for bit (strict ordered pheromone fold), i.e.
+partitioning the population does not change the answer."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KW = dict(alpha=1.0, beta=2.0, rho=0.1, Q=2.5, a_turn_coef=1.0, wh_max=0.9, wh_min=0.2, k_h_adaptive=0.9, q0_initial=0.5)
+
+
+def _worker(rank, world, port, out_dir, strict):
+    for p in (os.path.join(ROOT, "maaco-path-planing_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import golden_io as gio
+    from dist_fakes import FakeMAACO
+    from pathfit.dist import Comm, ShardedMAACO
+    g, s, t = gio.grid("fig7")
+    comm = Comm(dist, None)
+    sm = ShardedMAACO(comm, lambda: FakeMAACO(g, s, t, 21, 5, 7, **KW), 21, strict=strict)
+    path, length, turns = sm.solve_path_planning()
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), path=np.array(path), length=length, turns=turns,
+             tau=sm.local.engine.maaco_get_pheromone(), curve=np.array(sm.local.convergence_curve_data, float))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _single(strict=True):
+    import golden_io as gio
+    from dist_fakes import FakeMAACO
+    from pathfit.dist import Comm, ShardedMAACO
+    g, s, t = gio.grid("fig7")
+    sm = ShardedMAACO(Comm(None), lambda: FakeMAACO(g, s, t, 21, 5, 7, **KW), 21, strict=strict)
+    path, length, turns = sm.solve_path_planning()
+    return np.array(path), length, turns, sm.local.engine.maaco_get_pheromone(), np.array(sm.local.convergence_curve_data, float)
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_sharded_maaco_two_ranks_equals_one(tmp_path, strict):
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000) + (1 if strict else 0)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), strict), nprocs=2, join=True)
+    ref = _single(strict)
+    for r in (0, 1):
+        z = np.load(tmp_path / f"r{r}.npz")
+        assert np.array_equal(z["path"], ref[0]) and float(z["length"]) == ref[1] and float(z["turns"]) == ref[2]
+        assert np.array_equal(z["curve"], ref[4])
+        if strict:
+            assert np.array_equal(z["tau"], ref[3])          # ordered fold == sequential deposits, bit for bit
+        else:
+            assert np.allclose(z["tau"], ref[3], rtol=1e-12)  # all_reduce(SUM): ulp-level deviation only
+
+
+def test_single_rank_sharded_equals_oracle_loop():
+    import pf_loops, pf_oracle as po, golden_io as gio
+    g, s, t = gio.grid("fig7")
+    ref = pf_loops.maaco_solve(po.Oracle(g), s, t, 21, 5, C0=0.1, seed=7, **KW)
+    path, length, turns, tau, curve = _single(True)
+    assert [r * 20 + c for r, c in path.tolist()] == list(ref["path"]) and length == ref["length"]
+    assert np.array_equal(tau, ref["tau"])
+
+
+def test_shard_helpers():
+    from pathfit.dist import shard_range, owner_of, global_stable_order, maaco_best_scan_host
+    assert [shard_range(10, r, 3) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
+    assert owner_of(5, [4, 3, 3]) == (1, 1) and owner_of(9, [4, 3, 3]) == (2, 2)
+    assert list(global_stable_order([3.0, 1.0, 3.0, 1.0])) == [1, 3, 0, 2]
+    # sequential scan semantics MAACO.py:343-349: a later near-tie with fewer turns takes the path, not the length
+    L, T, i = maaco_best_scan_host(np.array([10.0, 10.0 - 5e-10, 10.0 + 4e-10]), np.array([5, 6, 2]))
+    assert (L, T, i) == (10.0 - 5e-10, 2.0, 2)
