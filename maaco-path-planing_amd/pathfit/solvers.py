@@ -196,9 +196,10 @@ class GASolver(_WaypointSolver):
         return True
 
     def _selection(self, gen):
+        """ga_solver.py:136-142; the whole generation's tournaments draw from stream (seed, DOM_GA_SELECT, gen, 0)."""
         out = []
-        for i in range(self.population_size):
-            r = pfrng.AgentRandom(self.seed, pfrng.DOM_GA_SELECT, gen, i)
+        r = pfrng.AgentRandom(self.seed, pfrng.DOM_GA_SELECT, gen, 0)
+        for _ in range(self.population_size):
             tournament = r.sample(self.population, min(self.tournament_size, len(self.population)))
             out.append(min(tournament, key=lambda x: x["fitness"]))
         return out

@@ -349,12 +349,42 @@ def cap_rng():
     np.savez_compressed(os.path.join(OUT, "rng.npz"), **d, **{"meta_" + k: v for k, v in META.items()})
 
 
+def cap_e2e(G):
+    """Full solve loops of the unmodified reference under the per-agent stream contract (oracle/ref_e2e.py)."""
+    import ref_e2e
+    d = {}
+    mk = dict(alpha=1.0, rho=0.1, Q=2.5, a_turn_coef=1.0, wh_max=0.9, wh_min=0.2, k_h_adaptive=0.9, q0_initial=0.5,
+              C0_initial_pheromone=0.1)
+    for i, (gname, beta, ants, iters, seed) in enumerate([("fig7", 7.0, 50, 12, 3), ("fig7", 2.0, 50, 12, 3), ("fig13", 7.0, 24, 6, 9)]):
+        r = ref_e2e.maaco_solve(G[gname], seed, num_ants=ants, num_iterations=iters, beta=beta, **mk)
+        d[f"maaco{i}_cfg"] = np.array([beta, ants, iters, seed]); d[f"maaco{i}_grid"] = np.array(gname)
+        for k in ("path", "length", "turns", "curve", "tau"):
+            d[f"maaco{i}_{k}"] = np.asarray(r[k])
+    mpa_runs = [("fig7", s_, 30, 50, {}) for s_ in (0, 1, 2)] + \
+               [("img1", 5, 24, 12, dict(FADs_rate=0.2, P_const=0.5, levy_beta=2.0, turn_penalty_factor=0.1,
+                                         safety_penalty_factor=0.8, min_safe_distance=1.8, diagonal_obstacle_penalty=100.0))]
+    for i, (gname, seed, n, it, kw) in enumerate(mpa_runs):
+        r = ref_e2e.mpa_solve(G[gname], seed, n, it, **kw)
+        d[f"mpa{i}_cfg"] = np.array([seed, n, it, 1 if kw else 0]); d[f"mpa{i}_grid"] = np.array(gname)
+        for k in ("path", "stats", "curve", "pop_fitness", "pop_len"):
+            d[f"mpa{i}_{k}"] = np.asarray(r[k])
+        print("e2e mpa", gname, seed, "fitness", r["stats"][4])
+    gk = dict(num_generations=6, population_size=24, num_waypoints_per_chromosome=5, mutation_rate=0.1, crossover_rate=0.8,
+              tournament_size=3, **MAIN_W)
+    r = ref_e2e.ga_solve(G["fig7"], 4, **gk)
+    for k in ("path", "stats", "curve", "pop_fitness"):
+        d[f"ga0_{k}"] = np.asarray(r[k])
+    d["ga0_attempts"] = np.array(r["attempts"])
+    print("e2e ga fitness", r["stats"][4], "attempts", r["attempts"])
+    np.savez_compressed(os.path.join(OUT, "e2e.npz"), **d, **{"meta_" + k: v for k, v in META.items()})
+
+
 if __name__ == "__main__":
     assert rh.available(), "needs /root/reference"
     os.makedirs(OUT, exist_ok=True)
     rh.install()
     G = grids()
-    which = sys.argv[1:] or ["grids", "rng", "astar", "decode", "maaco", "mpa", "pso"]
+    which = sys.argv[1:] or ["grids", "rng", "astar", "decode", "maaco", "mpa", "pso", "e2e"]
     if "grids" in which: cap_grids(G)
     if "rng" in which: cap_rng()
     if "astar" in which: cap_astar(G)
@@ -362,4 +392,5 @@ if __name__ == "__main__":
     if "maaco" in which: cap_maaco(G)
     if "mpa" in which: cap_mpa(G)
     if "pso" in which: cap_pso_update(G)
+    if "e2e" in which: cap_e2e(G)
     print("golden fixtures written to", OUT)
