@@ -1,0 +1,162 @@
+"""BASELINE.json configs at (per-GPU) full size, checked through size-independent properties: every emitted
+path is a legal start->target walk (8-connected, free cells, no corner cuts, self-avoiding where the
+algorithm guarantees it), stored stats are reproduced by an independent numpy recomputation and by a
+second scoring pass (idempotence), greedy steps are monotone, and the two A* variants agree on the optimal
+length when no avoid set is involved."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SQ2 = math.sqrt(2.0)
+
+
+def check_paths(grid, cells, lens, start, target, self_avoiding=False, sample=None):
+    R, C = grid.shape
+    occ = grid == 1
+    idx = np.flatnonzero(lens > 0)
+    if sample is not None and idx.size > sample:
+        idx = idx[np.linspace(0, idx.size - 1, sample).astype(int)]
+    out_len = {}
+    for a in idx:
+        p = cells[a, :lens[a]].astype(np.int64)
+        r, c = p // C, p % C
+        assert p[0] == start and p[-1] == target, a
+        assert not occ[r, c].any(), a
+        dr, dc = np.diff(r), np.diff(c)
+        assert (np.maximum(np.abs(dr), np.abs(dc)) == 1).all(), a
+        diag = (dr != 0) & (dc != 0)
+        # corner-cut rule (helper.py:45-49): both orthogonal cells of a diagonal step are free
+        assert not occ[r[1:][diag], c[:-1][diag]].any() and not occ[r[:-1][diag], c[1:][diag]].any(), a
+        if self_avoiding:
+            assert np.unique(p).size == p.size, a
+        L = 0.0
+        for d in diag:                                   # naive left-to-right sum, as the reference
+            L = L + (SQ2 if d else 1.0)
+        turns = int(((dr[1:] != dr[:-1]) | (dc[1:] != dc[:-1])).sum())
+        out_len[int(a)] = (L, turns)
+    return out_len
+
+
+def test_cfg2_maaco_256_ants_128():
+    import pathfit
+    from pathfit import env
+    g = env.bench_grid(128)
+    m = pathfit.MAACO(g, 256, 100, 1.0, 7.0, 0.1, 2.5, 1.0, 0.9, 0.2, 0.9, 0.5, 0.1, seed=2)
+    succ = []
+    for it in range(1, 9):
+        plen, turns = m.walk_iteration(it)
+        dc, dl = m._bufs[1].download(), m._bufs[2].download()
+        got = check_paths(g, dc, dl, 0, 128 * 128 - 1, self_avoiding=True, sample=64)
+        for a, (L, T) in got.items():
+            assert plen[a] == L and turns[a] == T
+        assert ((dl == 0) == np.isinf(plen)).all()
+        succ.append((dl > 0).mean())
+        best = plen.min()
+        m.best_path_length_overall = min(m.best_path_length_overall, best)
+        m.update_pheromone()
+        tau = m.pheromone_matrix
+        bl = m.best_path_length_overall if np.isfinite(m.best_path_length_overall) else 256.0
+        tmax = (1.0 / 0.9) * (1.0 / bl)
+        assert (tau[g == 1] == 1e-9).all() and tau[g != 1].max() <= tmax and tau[g != 1].min() >= tmax / 256.0
+    assert np.mean(succ) >= 0.5, succ                      # the cfg-2 grid must keep >= 50 % of the ants alive
+
+
+def test_cfg3_mpa_4096_predators_512():
+    import pathfit
+    from pathfit import env
+    from pathfit.engine import score_params
+    g = env.bench_grid(512)
+    N = 4096
+    m = pathfit.MPA(g, N, 12, FADs_rate=0.2, P_const=0.5, levy_beta=2.0, turn_penalty_factor=0.1, safety_penalty_factor=0.8,
+                    min_safe_distance=1.8, diagonal_obstacle_penalty=100.0, seed=1)
+    fit0 = m.d_stats.download()[:, 4].copy()
+    for it in (1, 2):
+        m.step(it)
+        cand_len, cand_cells, cand_stats = m.d_cand_len.download(), m.d_cand_cells.download(), m.d_cand_stats.download()
+        got = check_paths(g, cand_cells, cand_len, 0, 512 * 512 - 1, sample=96)
+        for a, (L, T) in got.items():
+            assert cand_stats[a, 0] == L and cand_stats[a, 1] == T and cand_stats[a, 2] == 0.0
+            assert cand_stats[a, 4] == L + 0.1 * T + 0.8 * 0.0 + cand_stats[a, 3]
+        stats = m.d_stats.download()
+        lens, cells = m.d_len.download(), m.d_cells.download()
+        check_paths(g, cells, lens, 0, 512 * 512 - 1, sample=64)
+        assert (stats[:, 4] <= fit0).all()                  # memory + FADs only ever improve (MPA.py:382,:402,:408)
+        # idempotence: a second scoring pass over the stored population reproduces the stored stats
+        e = m.engine
+        d2 = e.buf((N, 5), np.float64)
+        e._ck(e.L.pf_score_batch(e.h, m._sp, N, m.path_cap, m.d_cells.ptr, m.d_len.ptr, d2.ptr))
+        assert np.array_equal(d2.download(), stats)
+        assert (np.diff(stats[m.order, 4]) >= 0).all()      # population sorted by fitness (MPA.py:412)
+        fit0 = stats[:, 4].copy()
+    assert (m.d_status.download() != 3).all()
+
+
+def test_cfg4_ga_pso_2048_per_gpu_512():
+    import pathfit
+    from pathfit import env
+    from pathfit.engine import score_params
+    g = env.bench_grid(512)
+    e = pathfit.Engine(g)
+    rnd = np.random.default_rng(4)
+    free = np.flatnonzero(g.reshape(-1) != 1)
+    n, W, cap = 2048, 5, 16 * 1024 + 64
+    sp = score_params(0, True, 0.3, 0.8, 1.8, 100.0)
+    wp = rnd.choice(free, (n, W)).astype(np.int32)
+    paths, st, stats = e.decode_host(0, 512 * 512 - 1, wp_cells=wp, sp=sp, path_cap=cap)
+    assert (st != 3).all() and (st == 0).sum() > n // 2
+    lens = np.array([len(p) for p in paths]); cells = np.zeros((n, max(lens.max(), 1)), np.int32)
+    for i, p in enumerate(paths):
+        cells[i, :len(p)] = p
+    got = check_paths(g, cells, lens, 0, 512 * 512 - 1, sample=64)
+    for a, (L, T) in got.items():
+        assert stats[a, 0] == L and stats[a, 1] == T
+        assert all(w in set(paths[a].tolist()) for w in wp[a])        # every waypoint is visited, in order
+    assert np.isinf(stats[lens == 0, 4]).all()
+    # PSO: the same chromosomes as float positions (exact integers round to themselves)
+    pos = np.stack([wp // 512, wp % 512], -1).astype(np.float64)
+    paths2, st2, stats2 = e.decode_host(0, 512 * 512 - 1, wp_pos=pos, sp=sp, path_cap=cap)
+    assert all(np.array_equal(a, b) for a, b in zip(paths, paths2)) and np.array_equal(stats, stats2)
+
+
+def test_cfg5_maaco_and_astar_8192_per_gpu_1024():
+    import pathfit
+    from pathfit import env
+    g = env.bench_grid(1024)
+    e = pathfit.Engine(g)
+    m = pathfit.MAACO(g, 8192, 100, 1.0, 7.0, 0.1, 2.5, 1.0, 0.9, 0.2, 0.9, 0.5, 0.1, engine=e, seed=5)
+    plen, turns = m.walk_iteration(1)
+    dc, dl = m._bufs[1].download(), m._bufs[2].download()
+    got = check_paths(g, dc, dl, 0, 1024 * 1024 - 1, self_avoiding=True, sample=48)
+    for a, (L, T) in got.items():
+        assert plen[a] == L and turns[a] == T
+    assert (dl > 0).mean() > 0.3
+    m.best_path_length_overall = plen.min()
+    m.update_pheromone()
+    # standalone connector batch (MAACO itself never calls A*): 8192 seeded pairs, both variants
+    rnd = np.random.default_rng(6)
+    free = np.flatnonzero(g.reshape(-1) != 1)
+    n = 8192
+    # keep pairs within 192 cells so the batch stays a few seconds
+    s = rnd.choice(free, n)
+    off = rnd.integers(-192, 193, (n, 2))
+    tr = np.clip(s // 1024 + off[:, 0], 0, 1023); tc = np.clip(s % 1024 + off[:, 1], 0, 1023)
+    t = (tr * 1024 + tc)
+    t = np.where(g.reshape(-1)[t] == 1, s, t)
+    p0, st0 = e.astar_host(0, s, t, path_cap=4096)
+    p1, st1 = e.astar_host(1, s, t, path_cap=4096)
+    assert (st0 != 3).all() and (st1 != 3).all() and ((st0 == 0) == (st1 == 0)).all()
+    lens = np.array([len(p) for p in p0]); cells = np.zeros((n, max(lens.max(), 1)), np.int32)
+    for i, p in enumerate(p0):
+        cells[i, :len(p)] = p
+    ok = np.flatnonzero(st0 == 0)[:64]
+    for a in ok:
+        r = check_paths(g, cells[a:a + 1], lens[a:a + 1], int(s[a]), int(t[a]))
+    # both variants are optimal without an avoid set: equal path lengths (within fp summation order)
+    def plen_of(p):
+        d = np.diff(np.stack([p // 1024, p % 1024], 1).astype(np.int64), axis=0)
+        return float(np.sqrt((d * d).sum(1).astype(np.float64)).sum())
+    for a in np.flatnonzero(st0 == 0)[:512]:
+        assert abs(plen_of(p0[a]) - plen_of(p1[a])) < 1e-6, a
