@@ -95,6 +95,70 @@ PF_DEV void slot_wipe(Slot& s, int RC, int lane) {
 PF_DEV int move_dr(int d) { return (int)((0x0A25u >> (2 * d)) & 3u) - 1; }   // {0,0,1,-1,1,1,-1,-1} + 1 packed
 PF_DEV int move_dc(int d) { return (int)((0x2252u >> (2 * d)) & 3u) - 1; }   // {1,-1,0,0,1,-1,1,-1} + 1 packed
 
+// ---------------------------------------------------------------------------
+// Bounded pocket check.  When the goal (or the start) is sealed inside a small pocket by the avoid set, the
+// reference's A* pops the ENTIRE reachable region (~190 k pops on G512) before returning [] -- these cases
+// are ~1 % of MPA rebuilds but set the tail of every batch.  The search graph is undirected (free cells;
+// the corner-cut rule of helper.py:45-49 looks at the same two cells in both directions), and a cell may be
+// entered iff it is not in the avoid set (VARIANT 0 exempts start/target, astar.py:55-56).  So a flood from
+// `from` that exhausts its frontier without meeting `to` proves A* would fail; the flood is capped at
+// PF_FLOOD_K cells (it answers "unknown" beyond that and the real search runs).  8 frontier cells x 8 moves
+// per step on the 64 lanes; visited set = LDS hash table carved from the (not yet used) open-list area.
+// Returns 0 reachable, 1 proven unreachable, 2 unknown.
+// ---------------------------------------------------------------------------
+#define PF_FLOOD_K 512
+#define PF_FLOOD_TAB 2048
+PF_DEV int pocket_flood(const Grid& G, const Slot& s, int* lds, int from, int to, int exempt, int lane) {
+  int* tab = lds;                    // [PF_FLOOD_TAB] visited cells (open addressing), -1 = empty
+  int* queue = lds + PF_FLOOD_TAB;   // [PF_FLOOD_K]
+  for (int i = lane; i < PF_FLOOD_TAB; i += 64) tab[i] = -1;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_barrier();
+  if (lane == 0) { queue[0] = from; tab[(unsigned)(from * 0x9E3779B1u) >> 21] = from; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_barrier();
+  const int C = G.C;
+  const uint32_t avm = s.avoid_ep;
+  const int q = lane >> 3, m = lane & 7;
+  const int ddr = move_dr(m), ddc = move_dc(m);
+  int head = 0, tail = 1;
+  while (head < tail) {
+    const bool live = head + q < tail;
+    int cell = live ? queue[head + q] : 0;
+    head = head + 8 < tail ? head + 8 : tail;
+    bool cand = false; int n = 0;
+    if (live) {
+      const unsigned mm = G.mm[cell];
+      if ((mm >> m) & 1u) {
+        const int r = row_of(G, cell), c = cell - r * C;
+        n = (r + ddr) * C + (c + ddc);
+        const bool avoided = (s.rec[n].meta >> PF_AVOID_SHIFT) == avm;
+        cand = !avoided || n == to || n == exempt;
+      }
+    }
+    if (__ballot(cand && n == to)) return 0;
+    // claim unseen cells in the hash table
+    bool fresh = false;
+    if (cand) {
+      unsigned h = (unsigned)(n * 0x9E3779B1u) >> 21;
+      for (;;) {
+        const int old = atomicCAS(&tab[h], -1, n);
+        if (old == -1) { fresh = true; break; }
+        if (old == n) break;
+        h = (h + 1) & (PF_FLOOD_TAB - 1);
+      }
+    }
+    const unsigned long long fm = __ballot(fresh);
+    const int nf = __builtin_popcountll(fm);
+    if (tail + nf > PF_FLOOD_K) return 2;
+    if (fresh) queue[tail + __builtin_popcountll(fm & ((1ull << lane) - 1ull))] = n;
+    tail += nf;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+  }
+  return 1;
+}
+
 // Returns status (PF_ST_*).  On PF_ST_OK, out[0..out_n) holds the path cells
 // (r*C+c) start..target.  out_cap is the room available at `out`.
 template <int VARIANT>
@@ -117,16 +181,28 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
     out_n = 1;
     return 0;
   }
-  s.tag += 1;
-  const uint32_t tag = s.tag;
   const uint32_t avm = s.avoid_ep;
   Rec* rec = s.rec;
+  // MPA._a_star drops avoid nodes from every neighbour list (MPA.py:82) with no exemption for the goal, so a
+  // goal inside the avoid set can never be pushed: the reference then pops the whole reachable region and
+  // returns [] (MPA.py:151).  Same result, none of the work.  (On G512 this case is 44 % of all pops of an
+  // MPA sweep: the Brownian target often lands on the predator's own prefix.)
+  if (VARIANT == 1 && (rec[target].meta >> PF_AVOID_SHIFT) == avm) return 1;
+  // small-pocket proof of unreachability, from both ends (see pocket_flood)
+  {
+    const int ex = VARIANT == 0 ? start : -1;               // VARIANT 0: start/target may sit in the avoid set
+    if (pocket_flood(G, s, (int*)O.lf, target, start, ex, lane) == 1) return 1;
+    if (pocket_flood(G, s, (int*)O.lf, start, target, VARIANT == 0 ? target : -1, lane) == 1) return 1;
+  }
+  s.tag += 1;
+  const uint32_t tag = s.tag;
   const int S = O.S;
   const unsigned long long full = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
 
   // all slots of this lane's bin free
   for (int j = 0; j < S; ++j) O.lf[lane * S + j] = PF_INF;
   unsigned long long occ = 0, occ2 = 0;   // tier-1 (LDS) / tier-2 (HBM) slot occupancy of this lane's bin
+  bool any_t2 = false;                    // uniform: some bin of this search has spilled to tier 2
   double mf = PF_INF, mg = 0.0;
   int mc = 0, ms = 0;
   int rr = 1;          // lane of move 0 for the current pop (rotates)
@@ -144,18 +220,20 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
       w.meta = (r0.meta & PF_AVOID_KEEP) | (VARIANT == 1 ? PF_M_INOPEN : 0u);   // position (0,0)
       rec[start] = w;
     }
-    n_open = 1; st.pushes += 1;
+    n_open = 1;
   }
-  const long long max_steps = (long long)G.R * C * (VARIANT == 0 ? 3 : 2);   // astar.py:58 / MPA.py:118
-  long long steps = 0;
+  const int max_steps = G.R * C * (VARIANT == 0 ? 3 : 2);   // astar.py:58 / MPA.py:118 (R,C <= 4096)
+  int steps = 0;
+  unsigned nbr32 = 0, push32 = 1, dk32 = 0;
   int status = 1;
 
   for (;;) {
     if (steps >= max_steps) { status = n_open > 0 ? 2 : 1; break; }
     // ---- pop: argmin over the 64 cached bin minima ----
-    unsigned long long tie = argmin_mask_d<false>(mf);
+    unsigned kh, kl;
+    unsigned long long tie = argmin_mask_d<false>(mf, kh, kl);
     int w = __builtin_ctzll(tie);
-    if (bcast_d(mf, w) == PF_INF) { status = 1; break; }     // open list empty
+    if (kh == PF_INF_HI) { status = 1; break; }              // every bin minimum is +inf: open list empty
     if (tie & (tie - 1)) w = resolve_tie(tie, mg, mc);
     const double pg = bcast_d(mg, w);
     const int pprc = bcast_i(mc, w);
@@ -170,6 +248,9 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
     const int nidx = nr * C + nc;
     Rec rn; rn.g = 0.0; rn.tagmm = 0; rn.meta = 0;
     if (inb || d == 8) rn = rec[inb ? nidx : cur];
+    // the heuristic of each neighbour does not depend on the load: computed in its shadow (astar.py:90 / MPA.py:140)
+    const long hdr = nr - tr, hdc = nc - tc;
+    const double hn = __builtin_sqrt((double)(hdr * hdr + hdc * hdc));
     // ---- free the popped slot and rescan bin w (LDS; overlaps the load) ----
     if (lane == w) {
       if (pslot < S) { occ &= ~(1ull << pslot); O.lf[w * S + pslot] = PF_INF; }
@@ -179,23 +260,28 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
     {
       double vf = PF_INF, vg = 0.0; int vc = 0;
       if (lane < S) { vf = O.lf[w * S + lane]; vg = O.lg[w * S + lane]; vc = O.lc[w * S + lane]; }
-      const unsigned long long t2 = S <= 16 ? (argmin_mask_d<true>(vf) & 0xFFFFull) : argmin_mask_d<false>(vf);
+      unsigned rh, rl;
+      const unsigned long long t2 = S <= 16 ? (argmin_mask_d<true>(vf, rh, rl) & 0xFFFFull) : argmin_mask_d<false>(vf, rh, rl);
       int j = __builtin_ctzll(t2);
       if (t2 & (t2 - 1)) j = resolve_tie(t2, vg, vc);
-      double jf = bcast_d(vf, j), jg = bcast_d(vg, j);
-      int jc = bcast_i(vc, j);
-      const unsigned o2lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)occ2, w);
-      const unsigned o2hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(occ2 >> 32), w);
-      const unsigned long long o2 = ((unsigned long long)o2hi << 32) | o2lo;
-      if (o2) {                                               // the bin also has tier-2 entries: scan them too
-        double uf = PF_INF, ug = 0.0; int uc = 0;
-        if ((o2 >> lane) & 1ull) { uf = O.of[w * PF_T2 + lane]; ug = O.og[w * PF_T2 + lane]; uc = O.oc[w * PF_T2 + lane]; }
-        const unsigned long long t3 = argmin_mask_d<false>(uf);
-        int j3 = __builtin_ctzll(t3);
-        if (t3 & (t3 - 1)) j3 = resolve_tie(t3, ug, uc);
-        const double kf = bcast_d(uf, j3), kg = bcast_d(ug, j3);
-        const int kc = bcast_i(uc, j3);
-        if (jf == PF_INF || ent_lt(kf, kg, kc, jf, jg, jc)) { jf = kf; jg = kg; jc = kc; j = S + j3; }
+      // every lane re-reads the winning slot (uniform LDS address = broadcast read) instead of 5 v_readlane
+      double jf = __hiloint2double((int)rh, (int)rl), jg = O.lg[w * S + j];
+      int jc = O.lc[w * S + j];
+      if (any_t2) {
+        const unsigned o2lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)occ2, w);
+        const unsigned o2hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(occ2 >> 32), w);
+        const unsigned long long o2 = ((unsigned long long)o2hi << 32) | o2lo;
+        if (o2) {                                             // the bin also has tier-2 entries: scan them too
+          double uf = PF_INF, ug = 0.0; int uc = 0;
+          if ((o2 >> lane) & 1ull) { uf = O.of[w * PF_T2 + lane]; ug = O.og[w * PF_T2 + lane]; uc = O.oc[w * PF_T2 + lane]; }
+          unsigned uh, ul;
+          const unsigned long long t3 = argmin_mask_d<false>(uf, uh, ul);
+          int j3 = __builtin_ctzll(t3);
+          if (t3 & (t3 - 1)) j3 = resolve_tie(t3, ug, uc);
+          const double kf = bcast_d(uf, j3), kg = bcast_d(ug, j3);
+          const int kc = bcast_i(uc, j3);
+          if (jf == PF_INF || ent_lt(kf, kg, kc, jf, jg, jc)) { jf = kf; jg = kg; jc = kc; j = S + j3; }
+        }
       }
       if (lane == w) { mf = jf; mg = jg; mc = jc; ms = j; }   // jf == +inf when the bin is now empty
     }
@@ -223,13 +309,12 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
     const bool in_open = VARIANT == 0 ? rvalid : (rvalid && (rn.meta & PF_M_INOPEN));
     const bool push = better && !in_open;
     const bool deckey = VARIANT == 0 && better && in_open;   // astar.py:96-100
-    st.nbr += (unsigned long long)__builtin_popcountll(__ballot(ok));
+    nbr32 += (unsigned)__builtin_popcountll(__ballot(ok));
     double fnew = 0.0;
     unsigned pos = (rn.meta >> PF_POS_SHIFT) & PF_POS_MASK;
     bool ovf = false;
     if (better) {
-      long dr1 = nr - tr, dc1 = nc - tc;
-      fnew = tent + __builtin_sqrt((double)(dr1 * dr1 + dc1 * dc1));   // astar.py:90 / MPA.py:140
+      fnew = tent + hn;                                        // astar.py:90 / MPA.py:140
       if (push) {
         const int prc = (nr << 16) | nc;
         int slot = -1;
@@ -264,7 +349,7 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
     // ---- decrease-key: the owning lane refreshes its cached minimum ----
     if (VARIANT == 0) {
       unsigned long long dm = __ballot(deckey);
-      st.deckey += (unsigned long long)__builtin_popcountll(dm);
+      dk32 += (unsigned)__builtin_popcountll(dm);
       while (dm) {
         const int l = __builtin_ctzll(dm); dm &= dm - 1;
         const unsigned p2 = (unsigned)bcast_i((int)pos, l);
@@ -304,11 +389,12 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
       }
     }
     if (status == 3) break;
+    if (!any_t2 && __ballot(occ2 != 0)) any_t2 = true;       // after every insertion path of this pop
     rr = (rr + 9) & 63;
-    n_open += np; st.pushes += np;
+    n_open += np; push32 += (unsigned)np;
     if (n_open > st.max_open) st.max_open = n_open;
   }
-  st.pops += (unsigned long long)steps;
+  st.pops += (unsigned long long)steps; st.pushes += push32; st.nbr += nbr32; st.deckey += dk32;
   if (status != 0) return status;
 
   // ---- walk parents target -> start (astar.py:65-69 / MPA.py:124-130), then reverse in place ----

@@ -109,13 +109,14 @@ PF_DEV unsigned row0_min_u32(unsigned v) {
 // Lanes holding the minimum of a non-negative double key (bit pattern order == value order).
 // ROW0: only lanes 0..15 take part (their keys; others must pass +inf).
 template <bool ROW0>
-PF_DEV unsigned long long argmin_mask_d(double key) {
+PF_DEV unsigned long long argmin_mask_d(double key, unsigned& mh, unsigned& ml) {
   const unsigned hi = (unsigned)__double2hiint(key), lo = (unsigned)__double2loint(key);
-  const unsigned mh = ROW0 ? row0_min_u32(hi) : wave_min_u32(hi);
+  mh = ROW0 ? row0_min_u32(hi) : wave_min_u32(hi);
   const unsigned lo2 = hi == mh ? lo : 0xFFFFFFFFu;
-  const unsigned ml = ROW0 ? row0_min_u32(lo2) : wave_min_u32(lo2);
-  return __ballot(hi == mh && lo2 == ml && lo == ml);
+  ml = ROW0 ? row0_min_u32(lo2) : wave_min_u32(lo2);
+  return __ballot(hi == mh && lo == ml);
 }
+#define PF_INF_HI 0x7FF00000u
 
 PF_DEV int wave_sum_i(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);  // row_shr:1
