@@ -13,7 +13,7 @@ every rank owns 4096 predators (weak scaling); the only exchange is the
 fitness all_gather + elite broadcast per iteration (pathfit/dist.py).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`
-for the dominant kernel (k_mpa_phase / k_maaco_walk / k_decode_batch; HIP-event
+for the dominant kernel (k_mpa_sweep / k_maaco_walk / k_decode_batch; HIP-event
 timed inside the library on its own stream) and `cpu_baseline` (the CPU oracle
 port, bounded sample, 1 core).
 """
@@ -95,7 +95,7 @@ def main():
         total = per_gpu * world
         iters = max(K + W, 3 * (K + W))      # keeps the whole run inside phase 1 (iter <= T/3), like early MPA iterations
         sm = ShardedMPA(comm, lambda n: pathfit.MPA(grid, total, iters, engine=eng, seed=a.seed, n_local=n, **MPA_MAIN), total)
-        dominant = "k_mpa_phase"
+        dominant = "k_mpa_sweep"
         it = 0
 
         def step():
@@ -103,17 +103,17 @@ def main():
             it += 1
             e = eng
             # instrument the phase launch (dominant kernel) through the library's HIP-event timer + counters
-            orig = e.mpa_phase
+            orig = e.mpa_iter
 
-            def timed_phase(*args, **kw):
+            def timed_iter(*args, **kw):
                 nonlocal kern_ms, kern_bytes, launches
                 orig(*args, **kw)
                 kern_ms += e.last_kernel_ms(); kern_bytes += astar_bytes(e.counters()); launches += 1
-            e.mpa_phase = timed_phase
+            e.mpa_iter = timed_iter
             try:
                 sm.step(it)
             finally:
-                e.mpa_phase = orig
+                e.mpa_iter = orig
         cfg = {"workload": "MPA 4096 predators/GPU, 512x512 G512 (BASELINE.json configs[2]), main.py:44-52 params, phase-1 iterations",
                "agents_per_gpu": per_gpu, "grid": "G512=kron2(G256)", "grid_sha256": env.grid_hash(grid)[:16]}
     elif a.workload == "maaco512":

@@ -188,6 +188,17 @@ int pf_mpa_phase_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uin
 int pf_mpa_fads_batch(pf_handle* h, double CF, int32_t iter, uint64_t seed, int32_t n, int32_t path_cap,
                       const int32_t* d_gidx, const int32_t* d_slot, int32_t* d_pop_cells, int32_t* d_pop_len,
                       double* d_pop_stats, int32_t* d_status);
+/* One whole MPA iteration's device work in a single longest-first work queue: the phase sweep (as
+ * pf_mpa_phase_batch, candidates -> d_c1_*) and the FADs candidates (MPA.py:387-410; they depend only on the
+ * predator's stream and the grid, so they are produced concurrently -> d_c2_*, d_c2_len 0 = none), then the
+ * memory step (:381-384) and the FADs acceptance (:402/:408) in place on the population.  Equivalent to
+ * pf_mpa_phase_batch + pf_mpa_memory + pf_mpa_fads_batch, with one tail instead of two.  An agent whose
+ * scratch overflowed is reported through pf_get_counters().overflow_agents and d_status (phase items). */
+int pf_mpa_iter_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uint64_t seed, int32_t n, int32_t path_cap,
+                      int32_t* d_pop_cells, int32_t* d_pop_len, double* d_pop_stats, const int32_t* d_gidx,
+                      const int32_t* d_slot, const int32_t* d_elite_cells, int32_t elite_len, const double* d_elite_stats,
+                      int32_t* d_c1_cells, int32_t* d_c1_len, double* d_c1_stats, int32_t* d_c2_cells, int32_t* d_c2_len,
+                      double* d_c2_stats, int32_t* d_status);
 /* MPA._reconstruct_path_segment (MPA.py:284-318) called directly: predator a
  * modifies population path a against the given elite path with explicit
  * idx / is_levy / scale and stream (seed, DOM_MPA, iter, d_agent[a]). */

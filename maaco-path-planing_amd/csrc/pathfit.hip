@@ -555,19 +555,11 @@ struct MpaPhaseArgs {
 };
 
 // One predator of one phase sweep, MPA.py:339-377 + _reconstruct_path_segment :284-318.
-__global__ __launch_bounds__(64) void k_mpa_phase(MpaPhaseArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = lane_id();
+__device__ void mpa_phase_item(const MpaPhaseArgs& p, int a, Slot& s, const Open& O, AStat& tot,
+                               unsigned long long& cells, unsigned long long& ovf, int lane) {
   const Grid& G = p.c.G;
   const int RC = G.R * G.C;
-  Open O = make_open(smem, p.c.S, p.c.tier2);
-  Slot s = slot_load(p.c, RC);
-  AStat tot = {0, 0, 0, 0, 0};
-  unsigned long long cells = 0, ovf = 0;
-  for (;;) {
-    const int a = next_agent(p.c, p.n, lane);
-    if (a < 0) break;
-    if (p.c.retry && p.status[a] != 3) continue;
+  {
     const int gi = p.ex_idx ? p.ex_agent[a] : p.gidx[a];         // index in the fitness-sorted population
     const int slot = p.ex_idx ? a : p.slot[a];
     const int* prey = p.pop_cells + (size_t)slot * p.path_cap;
@@ -644,6 +636,19 @@ __global__ __launch_bounds__(64) void k_mpa_phase(MpaPhaseArgs p) {
     if (rc != 3 && lane < 5) p.out_stats[(size_t)a * 5 + lane] = sc[lane];
     cells += n; ovf += rc == 3;
   }
+}
+__global__ __launch_bounds__(64) void k_mpa_phase(MpaPhaseArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = lane_id();
+  Open O = make_open(smem, p.c.S, p.c.tier2);
+  Slot s = slot_load(p.c, p.c.G.R * p.c.G.C);
+  AStat tot = {0, 0, 0, 0, 0};
+  unsigned long long cells = 0, ovf = 0;
+  for (;;) {
+    const int a = next_agent(p.c, p.n, lane);
+    if (a < 0) break;
+    mpa_phase_item(p, a, s, O, tot, cells, ovf, lane);
+  }
   slot_store(p.c, s, lane);
   flush_counters(p.c.cnt, tot, cells, ovf, lane);
 }
@@ -658,22 +663,18 @@ struct MpaFadsArgs {
   // MPA._generate_initial_path() (MPA.py:154) is a pure function of the grid: A*(start,target) with no
   // avoid set.  It is computed once (pf_mpa_setup) and reused by the FADs re-init branch (:405).
   const int* init_cells; int init_len; const double* init_stats;
+  // candidate mode (fused sweep): the FADs candidate of predator a depends only on its stream and the grid,
+  // never on the population, so it is produced alongside the phase sweep into cand_* (cand_len 0 = none);
+  // k_mpa_apply does the :402/:408 comparison after the memory step.
+  int* cand_cells; int* cand_len; double* cand_stats;
 };
-// FADs sweep MPA.py:387-410, in place on the post-memory population.
-__global__ __launch_bounds__(64) void k_mpa_fads(MpaFadsArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = lane_id();
+// One predator of the FADs sweep MPA.py:387-410 (in place on the post-memory population, or candidate mode).
+__device__ void mpa_fads_item(const MpaFadsArgs& p, int a, Slot& s, const Open& O, AStat& tot,
+                              unsigned long long& cells, unsigned long long& ovf, int lane) {
   const Grid& G = p.c.G;
   const int RC = G.R * G.C;
-  Open O = make_open(smem, p.c.S, p.c.tier2);
-  Slot s = slot_load(p.c, RC);
-  AStat tot = {0, 0, 0, 0, 0};
-  unsigned long long cells = 0, ovf = 0;
-  int* tmp = p.tmp_cells + (size_t)blockIdx.x * p.path_cap;
-  for (;;) {
-    const int a = next_agent(p.c, p.n, lane);
-    if (a < 0) break;
-    if (p.c.retry && p.status[a] != 3) continue;
+  int* tmp = p.cand_cells ? p.cand_cells + (size_t)a * p.path_cap : p.tmp_cells + (size_t)blockIdx.x * p.path_cap;
+  {
     const int gi = p.gidx[a];
     const int slot = p.slot[a];
     int rc = 4, n = 0;
@@ -706,19 +707,77 @@ __global__ __launch_bounds__(64) void k_mpa_fads(MpaFadsArgs p) {
       double sc[5];
       if (have_stats) { for (int i = 0; i < 5; ++i) sc[i] = p.init_stats[i]; }
       else score_path(G, p.sp, tmp, n, lane, sc);
-      const double curfit = p.pop_stats[(size_t)slot * 5 + 4];
-      if (sc[4] < curfit) {                                        // :402 / :408
-        copy_path(p.pop_cells + (size_t)slot * p.path_cap, tmp, n, lane);
-        if (lane == 0) p.pop_len[slot] = n;
-        if (lane < 5) p.pop_stats[(size_t)slot * 5 + lane] = sc[lane];
+      if (p.cand_cells) {
+        if (lane < 5) p.cand_stats[(size_t)a * 5 + lane] = sc[lane];
         rc = 0;
+      } else {
+        const double curfit = p.pop_stats[(size_t)slot * 5 + 4];
+        if (sc[4] < curfit) {                                      // :402 / :408
+          copy_path(p.pop_cells + (size_t)slot * p.path_cap, tmp, n, lane);
+          if (lane == 0) p.pop_len[slot] = n;
+          if (lane < 5) p.pop_stats[(size_t)slot * 5 + lane] = sc[lane];
+          rc = 0;
+        }
       }
     }
-    if (lane == 0) p.status[a] = rc;
+    if (p.cand_cells && lane == 0) p.cand_len[a] = have ? n : 0;
+    if (!p.cand_cells && lane == 0) p.status[a] = rc;
     cells += n; ovf += rc == 3;
+  }
+}
+__global__ __launch_bounds__(64) void k_mpa_fads(MpaFadsArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = lane_id();
+  Open O = make_open(smem, p.c.S, p.c.tier2);
+  Slot s = slot_load(p.c, p.c.G.R * p.c.G.C);
+  AStat tot = {0, 0, 0, 0, 0};
+  unsigned long long cells = 0, ovf = 0;
+  for (;;) {
+    const int a = next_agent(p.c, p.n, lane);
+    if (a < 0) break;
+    mpa_fads_item(p, a, s, O, tot, cells, ovf, lane);
   }
   slot_store(p.c, s, lane);
   flush_counters(p.c.cnt, tot, cells, ovf, lane);
+}
+
+// Fused sweep: phase items [0,n) and FADs candidate items [n,2n) share one longest-first work queue, so an
+// iteration pays ONE tail instead of two (the FADs candidates are population independent).
+struct MpaSweepArgs { MpaPhaseArgs ph; MpaFadsArgs fd; };
+__global__ __launch_bounds__(64) void k_mpa_sweep(MpaSweepArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = lane_id();
+  Open O = make_open(smem, p.ph.c.S, p.ph.c.tier2);
+  Slot s = slot_load(p.ph.c, p.ph.c.G.R * p.ph.c.G.C);
+  AStat tot = {0, 0, 0, 0, 0};
+  unsigned long long cells = 0, ovf = 0;
+  for (;;) {
+    const int item = next_agent(p.ph.c, 2 * p.ph.n, lane);
+    if (item < 0) break;
+    if (item < p.ph.n) mpa_phase_item(p.ph, item, s, O, tot, cells, ovf, lane);
+    else mpa_fads_item(p.fd, item - p.ph.n, s, O, tot, cells, ovf, lane);
+  }
+  slot_store(p.ph.c, s, lane);
+  flush_counters(p.ph.c.cnt, tot, cells, ovf, lane);
+}
+// memory step (MPA.py:381-384) then FADs acceptance (:402 / :408) for predator a
+__global__ __launch_bounds__(64) void k_mpa_apply(int n, int path_cap, const int* slots, const int* c1_cells, const int* c1_len,
+                                                  const double* c1_stats, const int* c2_cells, const int* c2_len,
+                                                  const double* c2_stats, int* pop_cells, int* pop_len, double* pop_stats) {
+  const int a = blockIdx.x;
+  if (a >= n) return;
+  const int slot = slots[a];
+  double fit = pop_stats[(size_t)slot * 5 + 4];
+  int take = 0;
+  if (c1_stats[(size_t)a * 5 + 4] < fit) { take = 1; fit = c1_stats[(size_t)a * 5 + 4]; }
+  if (c2_len[a] > 0 && c2_stats[(size_t)a * 5 + 4] < fit) take = 2;
+  if (!take) return;
+  const int* src = take == 1 ? c1_cells : c2_cells;
+  const double* st = take == 1 ? c1_stats : c2_stats;
+  const int L = take == 1 ? c1_len[a] : c2_len[a];
+  for (int i = threadIdx.x; i < L; i += blockDim.x) pop_cells[(size_t)slot * path_cap + i] = src[(size_t)a * path_cap + i];
+  if (threadIdx.x < 5) pop_stats[(size_t)slot * 5 + threadIdx.x] = st[(size_t)a * 5 + threadIdx.x];
+  if (threadIdx.x == 0) pop_len[slot] = L;
 }
 
 // work estimates for the two MPA sweeps: replay only the gating draws of each predator's stream
@@ -1421,11 +1480,63 @@ int pf_mpa_fads_batch(pf_handle* h, double CF, int32_t iter, uint64_t seed, int3
   a.pop_cells = d_pop_cells; a.pop_len = d_pop_len; a.pop_stats = d_pop_stats; a.gidx = d_gidx; a.slot = d_slot;
   a.tmp_cells = h->d_tmp; a.status = d_status;
   a.init_cells = h->d_init_cells; a.init_len = h->init_len; a.init_stats = h->d_init_stats;
+  a.cand_cells = nullptr; a.cand_len = nullptr; a.cand_stats = nullptr;
   if (n > 64) {
     if (make_queue(h, n, [&](float* est) { hipLaunchKernelGGL(k_plan_mpa_fads, dim3((n + 255) / 256), dim3(256), 0, h->stream, a, est); })) return -1;
     a.c.queue = h->d_queue;
   }
   return launch_with_retry(h, k_mpa_fads, a, n);
+}
+
+int pf_mpa_iter_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uint64_t seed, int32_t n, int32_t path_cap,
+                      int32_t* d_pop_cells, int32_t* d_pop_len, double* d_pop_stats, const int32_t* d_gidx,
+                      const int32_t* d_slot, const int32_t* d_elite_cells, int32_t elite_len, const double* d_elite_stats,
+                      int32_t* d_c1_cells, int32_t* d_c1_len, double* d_c1_stats, int32_t* d_c2_cells, int32_t* d_c2_len,
+                      double* d_c2_stats, int32_t* d_status) {
+  if (!h) return -2;
+  if (!h->mpa_ready) return failmsg(h, "pf_mpa_iter_batch: call pf_mpa_setup first");
+  if (phase < 1 || phase > 3 || n < 0 || path_cap < 2 || !d_pop_cells || !d_pop_len || !d_pop_stats || !d_gidx || !d_slot ||
+      !d_elite_cells || !d_elite_stats || !d_c1_cells || !d_c1_len || !d_c1_stats || !d_c2_cells || !d_c2_len || !d_c2_stats || !d_status)
+    return failmsg(h, "pf_mpa_iter_batch: bad arguments");
+  if (n == 0) return 0;
+  if (ensure_slots(h, h->mpp.allow_diag, h->mpp.restrict_corner)) return -1;
+  MpaSweepArgs a;
+  a.ph.c = make_common(h, h->mpp.allow_diag, h->mpp.restrict_corner, 16, 0);
+  if (make_scorep(h, &h->mps, &a.ph.sp)) return -1;
+  a.ph.m = mpa_dev(h); a.ph.phase = phase; a.ph.iter = iter; a.ph.CF = CF; a.ph.seed = seed; a.ph.n = n; a.ph.path_cap = path_cap;
+  a.ph.pop_cells = d_pop_cells; a.ph.pop_len = d_pop_len; a.ph.pop_stats = d_pop_stats; a.ph.gidx = d_gidx; a.ph.slot = d_slot;
+  a.ph.elite_cells = d_elite_cells; a.ph.elite_len = elite_len; a.ph.elite_stats = d_elite_stats;
+  a.ph.out_cells = d_c1_cells; a.ph.out_len = d_c1_len; a.ph.out_stats = d_c1_stats; a.ph.status = d_status;
+  a.ph.ex_idx = nullptr; a.ph.ex_levy = nullptr; a.ph.ex_scale = nullptr; a.ph.ex_agent = nullptr;
+  a.fd.c = a.ph.c; a.fd.sp = a.ph.sp; a.fd.m = a.ph.m; a.fd.iter = iter; a.fd.CF = CF; a.fd.seed = seed; a.fd.n = n; a.fd.path_cap = path_cap;
+  a.fd.pop_cells = d_pop_cells; a.fd.pop_len = d_pop_len; a.fd.pop_stats = d_pop_stats; a.fd.gidx = d_gidx; a.fd.slot = d_slot;
+  a.fd.tmp_cells = nullptr; a.fd.status = d_status;
+  a.fd.init_cells = h->d_init_cells; a.fd.init_len = h->init_len; a.fd.init_stats = h->d_init_stats;
+  a.fd.cand_cells = d_c2_cells; a.fd.cand_len = d_c2_len; a.fd.cand_stats = d_c2_stats;
+  if (make_queue(h, 2 * n, [&](float* est) {
+        hipLaunchKernelGGL(k_plan_mpa_phase, dim3((n + 255) / 256), dim3(256), 0, h->stream, a.ph, est);
+        hipLaunchKernelGGL(k_plan_mpa_fads, dim3((n + 255) / 256), dim3(256), 0, h->stream, a.fd, est + n);
+      })) return -1;
+  a.ph.c.queue = h->d_queue; a.fd.c.queue = h->d_queue;
+  const int S = kLdsS;
+  a.ph.c.S = S; a.fd.c.S = S; a.ph.c.retry = 0; a.fd.c.retry = 0;
+  const size_t lds = open_bytes(S);
+  CK(hipFuncSetAttribute((const void*)k_mpa_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int per_cu = (int)((160 * 1024) / lds); if (per_cu > kSlotsPerCU) per_cu = kSlotsPerCU; if (per_cu < 1) per_cu = 1;
+  int grid = (h->nslots / kSlotsPerCU) * per_cu; if (grid > 2 * n) grid = 2 * n; if (grid > h->nslots) grid = h->nslots;
+  CK(hipMemsetAsync(h->d_work, 0, sizeof(int), h->stream));
+  CK(hipMemsetAsync(h->d_cnt, 0, sizeof(DevCounters), h->stream));
+  CK(hipEventRecord(h->ev0, h->stream));
+  hipLaunchKernelGGL(k_mpa_sweep, dim3(grid), dim3(64), lds, h->stream, a);
+  CK(hipGetLastError());
+  CK(hipEventRecord(h->ev1, h->stream));
+  hipLaunchKernelGGL(k_mpa_apply, dim3(n), dim3(64), 0, h->stream, n, path_cap, d_slot, d_c1_cells, d_c1_len, d_c1_stats,
+                     d_c2_cells, d_c2_len, d_c2_stats, d_pop_cells, d_pop_len, d_pop_stats);
+  CK(hipGetLastError());
+  DevCounters dc;
+  if (end_batch(h, &dc)) return -1;
+  CK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  return 0;
 }
 
 int pf_mpa_memory(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_slot,

@@ -73,6 +73,8 @@ SYMBOLS = {
     "pf_mpa_phase_batch": (C.c_int, [_vp, _i32, _dbl, _i32, _u64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32,
                                      _vp, _vp, _vp, _vp, _vp]),
     "pf_mpa_fads_batch": (C.c_int, [_vp, _dbl, _i32, _u64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pf_mpa_iter_batch": (C.c_int, [_vp, _i32, _dbl, _i32, _u64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp,
+                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pf_mpa_rebuild_batch": (C.c_int, [_vp, _i32, _u64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _vp, _vp]),
     "pf_selftest_sqrt": (C.c_int, [_vp, _i32, _vp, _vp]),

@@ -232,11 +232,8 @@ class ShardedMPA:
         ratio = it / m.num_iterations
         CF = 0.0 if ratio >= 1.0 else ((1.0 - ratio) ** (2.0 * ratio) if ratio > 0 else 1.0)
         phase = 1 if it <= m.num_iterations / 3 else (2 if it <= 2 * m.num_iterations / 3 else 3)
-        e.mpa_phase(phase, CF, it, m.seed, n, cap, m.d_cells, m.d_len, m.d_stats, d_gidx, d_slot, d_el.ptr, L, d_es.ptr,
-                    m.d_cand_cells, m.d_cand_len, m.d_cand_stats, m.d_status)
-        m._check_overflow()
-        e.mpa_memory(n, cap, d_slot, m.d_cand_cells, m.d_cand_len, m.d_cand_stats, m.d_cells, m.d_len, m.d_stats)
-        e.mpa_fads(CF, it, m.seed, n, cap, d_gidx, d_slot, m.d_cells, m.d_len, m.d_stats, m.d_status)
+        e.mpa_iter(phase, CF, it, m.seed, n, cap, m.d_cells, m.d_len, m.d_stats, d_gidx, d_slot, d_el.ptr, L, d_es.ptr,
+                   m.d_cand_cells, m.d_cand_len, m.d_cand_stats, m.d_c2_cells, m.d_c2_len, m.d_c2_stats, m.d_status)
         m._check_overflow()
         m._stats_host = m.d_stats.download()
         self._resort()                                                # :412

@@ -242,6 +242,15 @@ class Engine:
                                            elite_cells_ptr, int(elite_len), elite_stats_ptr, d_out_cells.ptr,
                                            d_out_len.ptr, d_out_stats.ptr, d_status.ptr))
 
+    def mpa_iter(self, phase, CF, it, seed, n, path_cap, d_pop_cells, d_pop_len, d_pop_stats, d_gidx, d_slot,
+                 elite_cells_ptr, elite_len, elite_stats_ptr, d_c1_cells, d_c1_len, d_c1_stats, d_c2_cells, d_c2_len,
+                 d_c2_stats, d_status):
+        self._ck(self.L.pf_mpa_iter_batch(self.h, int(phase), float(CF), int(it), int(seed), n, path_cap,
+                                          d_pop_cells.ptr, d_pop_len.ptr, d_pop_stats.ptr, d_gidx.ptr, d_slot.ptr,
+                                          elite_cells_ptr, int(elite_len), elite_stats_ptr, d_c1_cells.ptr,
+                                          d_c1_len.ptr, d_c1_stats.ptr, d_c2_cells.ptr, d_c2_len.ptr, d_c2_stats.ptr,
+                                          d_status.ptr))
+
     def mpa_fads(self, CF, it, seed, n, path_cap, d_gidx, d_slot, d_pop_cells, d_pop_len, d_pop_stats, d_status):
         self._ck(self.L.pf_mpa_fads_batch(self.h, float(CF), int(it), int(seed), n, path_cap, d_gidx.ptr, d_slot.ptr,
                                           d_pop_cells.ptr, d_pop_len.ptr, d_pop_stats.ptr, d_status.ptr))

@@ -33,7 +33,7 @@ class MPA:
     def __init__(self, grid, num_predators, num_iterations, FADs_rate=0.2, P_const=0.5, levy_beta=1.5,
                  turn_penalty_factor=0.1, safety_penalty_factor=0.05, min_safe_distance=1.5, allow_diagonal_moves=True,
                  restrict_diagonal_near_obstacle=True, diagonal_obstacle_penalty=1000.0, engine=None, device=0, seed=0,
-                 verbose=False, agent0=0, n_local=None):
+                 verbose=False, agent0=0, n_local=None, fused=True):
         self.grid = np.array(grid, dtype=int)
         self.rows, self.cols = self.grid.shape
         self.num_predators, self.num_iterations = num_predators, num_iterations
@@ -56,6 +56,7 @@ class MPA:
         self.convergence_curve_data = []
         self.seed, self.verbose = int(seed), verbose
         self.n_local = int(n_local) if n_local else int(num_predators)   # predators stored on this GPU (sharding)
+        self.fused = bool(fused)   # one work queue for the phase sweep + FADs candidates (pf_mpa_iter_batch)
         self.engine = engine if engine is not None else Engine(self.grid, device)
         self._s = self.start_node[0] * self.cols + self.start_node[1]
         self._t = self.target_node[0] * self.cols + self.target_node[1]
@@ -90,6 +91,7 @@ class MPA:
         self.d_stats = e.put(np.tile(stats, (N, 1)))
         self.d_cand_cells, self.d_cand_len = e.buf((N, cap), np.int32), e.buf(N, np.int32)
         self.d_cand_stats, self.d_status = e.buf((N, 5), np.float64), e.buf(N, np.int32)
+        self.d_c2_cells, self.d_c2_len, self.d_c2_stats = e.buf((N, cap), np.int32), e.buf(N, np.int32), e.buf((N, 5), np.float64)
         self.order = np.arange(N, dtype=np.int32)                        # sorted position -> storage slot
         self.d_order = e.put(self.order)
         self.d_gidx = e.put(np.arange(N, dtype=np.int32))                # single GPU: every predator is local
@@ -136,14 +138,20 @@ class MPA:
         ratio = it / self.num_iterations
         CF = 0.0 if ratio >= 1.0 else ((1.0 - ratio) ** (2.0 * ratio) if ratio > 0 else 1.0)   # :336
         phase = 1 if it <= self.num_iterations / 3 else (2 if it <= 2 * self.num_iterations / 3 else 3)
-        e.mpa_phase(phase, CF, it, self.seed, N, cap, self.d_cells, self.d_len, self.d_stats, self.d_gidx, self.d_order,
-                    self.d_cells.at(elite_slot * cap), elite_len, self.d_stats.at(elite_slot * 5),
-                    self.d_cand_cells, self.d_cand_len, self.d_cand_stats, self.d_status)
-        self._check_overflow()
-        e.mpa_memory(N, cap, self.d_order, self.d_cand_cells, self.d_cand_len, self.d_cand_stats,
-                     self.d_cells, self.d_len, self.d_stats)            # :381-384
-        e.mpa_fads(CF, it, self.seed, N, cap, self.d_gidx, self.d_order, self.d_cells, self.d_len, self.d_stats, self.d_status)   # :387-410
-        self._check_overflow()
+        el_c, el_s = self.d_cells.at(elite_slot * cap), self.d_stats.at(elite_slot * 5)
+        if self.fused:
+            e.mpa_iter(phase, CF, it, self.seed, N, cap, self.d_cells, self.d_len, self.d_stats, self.d_gidx, self.d_order,
+                       el_c, elite_len, el_s, self.d_cand_cells, self.d_cand_len, self.d_cand_stats,
+                       self.d_c2_cells, self.d_c2_len, self.d_c2_stats, self.d_status)     # :339-410 in one queue
+            self._check_overflow()
+        else:
+            e.mpa_phase(phase, CF, it, self.seed, N, cap, self.d_cells, self.d_len, self.d_stats, self.d_gidx, self.d_order,
+                        el_c, elite_len, el_s, self.d_cand_cells, self.d_cand_len, self.d_cand_stats, self.d_status)
+            self._check_overflow()
+            e.mpa_memory(N, cap, self.d_order, self.d_cand_cells, self.d_cand_len, self.d_cand_stats,
+                         self.d_cells, self.d_len, self.d_stats)            # :381-384
+            e.mpa_fads(CF, it, self.seed, N, cap, self.d_gidx, self.d_order, self.d_cells, self.d_len, self.d_stats, self.d_status)   # :387-410
+            self._check_overflow()
         self._stats_host = self.d_stats.download()
         self._sort()                                                     # :412
         slot = int(self.order[0])
@@ -169,7 +177,7 @@ class MPA:
 
     def _check_overflow(self):
         st = self.d_status.download()
-        if (st == 3).any():
+        if (st == 3).any() or self.engine.counters()["overflow_agents"]:
             raise RuntimeError("pathfit: scratch/path capacity overflow on %d predators (path_cap=%d)" %
                                (int((st == 3).sum()), self.path_cap))
 

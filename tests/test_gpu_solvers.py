@@ -36,7 +36,7 @@ def test_mpa_main_params_with_levy_phases():
     g, s, t = gio.grid("img1")
     kw = dict(FADs_rate=0.2, P_const=0.5, levy_beta=2.0, turn_penalty_factor=0.1, safety_penalty_factor=0.8,
               min_safe_distance=1.8, diagonal_obstacle_penalty=100.0)
-    m = pathfit.MPA(g, 24, 12, seed=5, **kw)
+    m = pathfit.MPA(g, 24, 12, seed=5, fused=False, **kw)      # the three separate ABI calls
     got = m.solve_path_planning()
     ref = pf_loops.MpaOracle(po.Oracle(g), s, t, 24, 12, FADs_rate=0.2, P_const=0.5, levy_beta=2.0, w_turn=0.1,
                              w_safe=0.8, min_safe=1.8, diag_pen=100.0, seed=5)
