@@ -195,6 +195,17 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                 "avg_launch_ms": round(avg_ms, 3), "algorithmic_bytes_per_launch": int(kern_bytes / launches)}
 
+    if roof is not None:
+        # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/r01_traffic.json:
+        # FETCH_SIZE and WRITE_SIZE in separate --pmc runs, KB -> B, FETCH x2 per MI355X_MICROARCH.md)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if a.workload in tj and tj[a.workload]["kernel"] == dominant:
+                roof["traffic"] = int(tj[a.workload]["traffic_bytes_per_launch"])
+                roof["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, offline)"
+        except Exception:
+            pass
+
     cpu = None
     if rank == 0 and not a.no_cpu:
         cpu = cpu_baseline(a.workload, grid, a.seed, a.cpu_seconds)
