@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + PF_BENCH_SHARE_GPU=1 rehearses N ranks on one GPU (exchange logic only)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -66,18 +68,22 @@ def main():
         torch = _t
     except Exception:
         torch = None
+    share_gpu = os.environ.get("PF_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist_.init_process_group("nccl", rank=rank, world_size=world)
+        if a.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist_.init_process_group(a.backend, rank=rank, world_size=world)
         dist = dist_
 
     import pathfit
     from pathfit import env
     from pathfit.dist import Comm, ShardedMPA, ShardedMAACO
 
-    comm = Comm(dist, torch.device("cuda", local_rank) if dist is not None else None)
+    comm = Comm(dist, torch.device("cuda", local_rank) if (dist is not None and a.backend == "nccl") else None)
     grid = env.bench_grid(512)
     eng = pathfit.Engine(grid, device=local_rank)
     K, W = a.steps, a.warmup
@@ -181,7 +187,7 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", local_rank) if a.backend == "nccl" else None)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     total_evals = per_gpu * world * K

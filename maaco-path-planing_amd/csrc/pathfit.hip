@@ -1192,6 +1192,14 @@ int pf_pso_pbest(pf_handle* h, int32_t n, int32_t W, const double* d_pos, const 
   return 0;
 }
 
+#ifdef PF_STAMPS
+extern "C" int pf_debug_stamps(pf_handle* h, uint64_t* out, int reset) {
+  CK(hipSetDevice(h->device));
+  CK(hipMemcpyFromSymbol(out, HIP_SYMBOL(pf::g_stamps), sizeof(uint64_t) * 16));
+  if (reset) { uint64_t z[16] = {0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(pf::g_stamps), z, sizeof(z))); }
+  return 0;
+}
+#endif
 int pf_selftest_sqrt(pf_handle* h, int32_t n, const int64_t* d_in, double* d_out) {
   if (!h || n < 0 || !d_in || !d_out) return failmsg(h, "pf_selftest_sqrt: bad arguments");
   if (n == 0) return 0;

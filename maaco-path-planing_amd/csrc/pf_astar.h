@@ -56,6 +56,15 @@ struct AStat {
   unsigned long long pops, pushes, nbr, deckey;
   int max_open;
 };
+// diagnostic build only (-DPF_STAMPS): shader-clock time per section of the pop loop, never in the product .so
+#ifdef PF_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define PF_T(var) unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+#define PF_ACC(i, a, b) st_acc[i] += (b) - (a);
+#else
+#define PF_T(var)
+#define PF_ACC(i, a, b)
+#endif
 
 PF_DEV bool ent_lt(double f1, double g1, int c1, double f2, double g2, int c2) {
   if (f1 != f2) return f1 < f2;
@@ -227,14 +236,20 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
   unsigned nbr32 = 0, push32 = 1, dk32 = 0;
   int status = 1;
 
+#ifdef PF_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   for (;;) {
+    PF_T(t0)
     if (steps >= max_steps) { status = n_open > 0 ? 2 : 1; break; }
     // ---- pop: argmin over the 64 cached bin minima ----
     unsigned kh, kl;
     unsigned long long tie = argmin_mask_d<false>(mf, kh, kl);
     int w = __builtin_ctzll(tie);
     if (kh == PF_INF_HI) { status = 1; break; }              // every bin minimum is +inf: open list empty
-    if (tie & (tie - 1)) w = resolve_tie(tie, mg, mc);
+    PF_T(t1)
+    if (tie & (tie - 1)) { w = resolve_tie(tie, mg, mc); }
+    PF_T(t2)
     const double pg = bcast_d(mg, w);
     const int pprc = bcast_i(mc, w);
     const int pslot = bcast_i(ms, w);
@@ -251,6 +266,7 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
     // the heuristic of each neighbour does not depend on the load: computed in its shadow (astar.py:90 / MPA.py:140)
     const long hdr = nr - tr, hdc = nc - tc;
     const double hn = __builtin_sqrt((double)(hdr * hdr + hdc * hdc));
+    PF_T(t3)
     // ---- free the popped slot and rescan bin w (LDS; overlaps the load) ----
     if (lane == w) {
       if (pslot < S) { occ &= ~(1ull << pslot); O.lf[w * S + pslot] = PF_INF; }
@@ -285,9 +301,11 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
       }
       if (lane == w) { mf = jf; mg = jg; mc = jc; ms = j; }   // jf == +inf when the bin is now empty
     }
+    PF_T(t4)
     // ---- the popped cell's own record (lane rr+8) ----
     const int lcur = (rr + 8) & 63;
     const double cur_g = bcast_d(rn.g, lcur);
+    PF_T(t5)
     const uint32_t cur_tagmm = (uint32_t)bcast_i((int)rn.tagmm, lcur);
     const uint32_t cur_meta = (uint32_t)bcast_i((int)rn.meta, lcur);
     const double base_g = VARIANT == 0 ? pg : cur_g;          // astar.py:85 popped g / MPA.py:135 g_score[current]
@@ -345,6 +363,7 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
         rec[nidx] = wv;
       }
     }
+    PF_T(t6)
     const int np = __builtin_popcountll(__ballot(push));
     // ---- decrease-key: the owning lane refreshes its cached minimum ----
     if (VARIANT == 0) {
@@ -392,8 +411,16 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
     if (!any_t2 && __ballot(occ2 != 0)) any_t2 = true;       // after every insertion path of this pop
     rr = (rr + 9) & 63;
     n_open += np; push32 += (unsigned)np;
+    PF_T(t7)
+    PF_ACC(0, t0, t1) PF_ACC(1, t1, t2) PF_ACC(2, t2, t3) PF_ACC(3, t3, t4) PF_ACC(4, t4, t5) PF_ACC(5, t5, t6) PF_ACC(6, t6, t7)
+#ifdef PF_STAMPS
+    st_acc[7] += (tie & (tie - 1)) ? 1 : 0;
+#endif
     if (n_open > st.max_open) st.max_open = n_open;
   }
+#ifdef PF_STAMPS
+  if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_stamps[i], st_acc[i]);
+#endif
   st.pops += (unsigned long long)steps; st.pushes += push32; st.nbr += nbr32; st.deckey += dk32;
   if (status != 0) return status;
 
