@@ -40,12 +40,11 @@ struct Common {
   int retry;             // only agents whose status == 3
 };
 
-PF_DEV Open make_open(char* smem, int S, char* tier2) {
+PF_DEV Open make_open(char* smem, int /*S*/, char* tier2) {
   Open O;
   O.lf = (double*)smem;
-  O.lg = O.lf + 64 * S;
-  O.lc = (int*)(O.lg + 64 * S);
-  O.S = S;
+  O.lg = O.lf + 64 * PF_S;
+  O.lc = (int*)(O.lg + 64 * PF_S);
   char* t2 = tier2 + (size_t)blockIdx.x * (64 * PF_T2 * 20);
   O.of = (double*)t2;
   O.og = O.of + 64 * PF_T2;
@@ -985,7 +984,7 @@ float pf_last_kernel_ms(pf_handle* h) { return h->last_ms; }
 // resident agent slots per CU and LDS bin capacity; PF_SLOTS_PER_CU / PF_LDS_S override for experiments
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; }
 static const int kSlotsPerCU = env_int("PF_SLOTS_PER_CU", 8);
-static const int kLdsS = env_int("PF_LDS_S", 16);
+static const int kLdsS = PF_S;
 static int ensure_slots(pf_handle* h, int allow_diag = 1, int restrict_corner = 1) {
   CK(hipSetDevice(h->device));
   if (!h->d_rec) {

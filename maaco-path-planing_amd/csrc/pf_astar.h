@@ -33,11 +33,11 @@
 
 namespace pf {
 
+#define PF_S 16 /* LDS slots per bin (compile-time: LDS addresses fold to constants, fewer SGPRs) */
 struct Open {
   double* lf;  // [64*S] bin-major; +inf == free slot
   double* lg;
   int* lc;     // packed (r<<16)|c
-  int S;
   // tier 2: PF_T2 more slots per bin in this agent's HBM scratch, used only when a bin's LDS slots are
   // full, so a search never has to restart with a larger LDS footprint
   double* of;  // [64*PF_T2]
@@ -205,7 +205,7 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
   }
   s.tag += 1;
   const uint32_t tag = s.tag;
-  const int S = O.S;
+  constexpr int S = PF_S;
   const unsigned long long full = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
 
   // all slots of this lane's bin free
