@@ -212,6 +212,11 @@ int pf_mpa_memory(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_sl
                   const int32_t* d_cand_len, const double* d_cand_stats, int32_t* d_pop_cells, int32_t* d_pop_len,
                   double* d_pop_stats);
 
+/* Tuning knobs.  "use16_min": batches of at least this many agents run four agents per wavefront (one per
+ * 16-lane DPP row, pf_astar16.h); smaller batches run one agent per wavefront.  Results are identical.
+ * Default: off (INT_MAX) -- the lockstep form measured slower on heterogeneous searches. */
+int pf_set_option(pf_handle* h, const char* name, int64_t value);
+
 /* ---- device self-tests (used by tests/ to pin device arithmetic) ----- */
 /* out[i] = device sqrt((double)in[i]) -- must equal libm sqrt bit for bit
  * (heuristic astar.py:90 / helper.py:12). */

@@ -77,6 +77,7 @@ SYMBOLS = {
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pf_mpa_rebuild_batch": (C.c_int, [_vp, _i32, _u64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _vp, _vp]),
+    "pf_set_option": (C.c_int, [_vp, C.c_char_p, _i64]),
     "pf_selftest_sqrt": (C.c_int, [_vp, _i32, _vp, _vp]),
     "pf_selftest_rng": (C.c_int, [_vp, _u64, _u64, _u64, _u64, _vp, _vp, _vp]),
     "pf_mpa_memory": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -101,6 +101,9 @@ class Engine:
         a = np.ascontiguousarray(arr, dtype)
         return DevBuf(self, a.shape if a.ndim else (1,), a.dtype).upload(a)
 
+    def set_option(self, name, value):
+        self._ck(self.L.pf_set_option(self.h, name.encode(), int(value)))
+
     def counters(self):
         c = Counters()
         self._ck(self.L.pf_get_counters(self.h, C.byref(c)))
