@@ -568,6 +568,159 @@ __global__ __launch_bounds__(64) void k_maaco_walk(MaacoArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// K4, packed form: EIGHT ants per wavefront.  A walk step only ever uses 8 lanes (the 8 moves), so each group
+// of 8 lanes walks its own ant; "per-ant uniform" values are replicated in the group's lanes, broadcasts are
+// ds_bpermute inside the group, candidate masks are 8-bit slices of the wave ballot.  A group that finishes
+// its ant emits the result and immediately fetches the next ant from the queue inside the same loop, so no
+// lanes idle until the queue is empty.  Same draws, same arithmetic, same order as k_maaco_walk.
+// ---------------------------------------------------------------------------
+PF_DEV unsigned gballot8(bool p) { return (unsigned)(__ballot(p) >> (lane_id() & 56)) & 0xFFu; }
+PF_DEV int gbcast8_i(int v, int k) { return __builtin_amdgcn_ds_bpermute(((lane_id() & 56) + k) << 2, v); }
+PF_DEV double gbcast8_d(double v, int k) {
+  const int lo = gbcast8_i(__double2loint(v), k), hi = gbcast8_i(__double2hiint(v), k);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
+  const Grid& G = p.G;
+  const int R = G.R, C = G.C, RC = R * C;
+  const int lane = lane_id();
+  const int k = lane & 7, grp = lane >> 3;
+  const int slot = blockIdx.x * 8 + grp;
+  unsigned* visit = p.visit + (size_t)slot * RC;
+  unsigned epoch = p.slot_epoch[slot];
+  const int mdr = AM_DR[k], mdc = AM_DC[k];
+  const unsigned hbit = 1u << AM_TO_HM[k];
+  const int sr = row_of(G, p.start), sc = p.start - sr * C;
+  const int tr = row_of(G, p.target), tc = p.target - tr * C;
+  const int vrS = tr - sr, vcS = tc - sc;
+  const bool o1 = !((vcS > 0 && mdc < 0) || (vcS < 0 && mdc > 0) || (vrS > 0 && mdr < 0) || (vrS < 0 && mdr > 0));
+  const unsigned O1 = gballot8(o1);
+  const double mcost = (mdr != 0 && mdc != 0) ? PF_SQRT2 : 1.0;
+  const long long max_steps = (long long)RC * 2;                   // MAACO.py:283
+  unsigned long long steps_tot = 0, cand_tot = 0, cells_tot = 0;
+  // per-ant state (replicated in the 8 lanes of the group)
+  int a = -1, cr = 0, cc = 0, n = 0, prev_k = -1, nturn = 0, rc = 0;
+  long long steps = 0;
+  double plen = 0.0;
+  Rng g; g.key = 0; g.ctr = 0;
+  int* out = p.cells;
+  bool need = true, alive = true;
+  while (__ballot(alive)) {
+    if (alive && need) {                                           // fetch + initialise the next ant of this group
+      int w = 0;
+      if (k == 0) w = atomicAdd(p.work, 1);
+      w = gbcast8_i(w, 0);
+      if (w >= p.n) alive = false;
+      else {
+        a = w;
+        epoch += 1;
+        if (epoch >= 0xFFFFFFF0u) {
+          for (int i = k; i < RC; i += 8) visit[i] = 0;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          epoch = 1;
+        }
+        g.init(p.seed, DOM_MAACO, (unsigned long long)p.iter, (unsigned long long)(p.ant0 + a));
+        out = p.cells + (size_t)a * p.path_cap;
+        cr = sr; cc = sc; n = 1; prev_k = -1; nturn = 0; rc = 0; plen = 0.0; steps = 0;
+        if (k == 0) { out[0] = p.start; visit[p.start] = epoch; }
+        need = false;
+      }
+    }
+    if (!alive) continue;
+    bool done = (cr == tr && cc == tc) || steps >= max_steps;
+    if (!done) {
+      const int cur = cr * C + cc;
+      const int nr = cr + mdr, nc = cc + mdc;
+      const bool inb = nr >= 0 && nr < R && nc >= 0 && nc < C;
+      const int nidx = nr * C + nc;
+      const int turn = (prev_k >= 0 && k != prev_k) ? 1 : 0;       // MAACO.py:184-195
+      unsigned vst = 0; double tv = 0.0, ev = 0.0;
+      const unsigned M = G.mm[cur];
+      if (inb) { vst = visit[nidx]; tv = p.tau[nidx]; ev = p.eta[(size_t)nidx * 2 + turn]; }
+      const bool ok = inb && (M & hbit) && vst != epoch;
+      const unsigned mall = gballot8(ok);
+      const int vr = tr - cr, vc = tc - cc;
+      const bool o2 = !((vc > 0 && mdc < 0) || (vc < 0 && mdc > 0) || (vr > 0 && mdr < 0) || (vr < 0 && mdr > 0));
+      const unsigned O2 = gballot8(o2);
+      unsigned cand = mall & O1;                                    // :165
+      if (!cand) cand = mall & O2;                                  // :168-169
+      if (!cand) cand = mall;                                       // :172-180
+      if (!cand) { rc = 1; done = true; }                           // :287-288
+      else {
+        const int ncand = __builtin_popcount(cand);
+        cand_tot += ncand;
+        const double q = g.random();                                // :232
+        const double attr = tv * ev;                                // :238
+        int pick = 0;
+        if (q <= p.q0) {                                            // :241-250
+          double mx = -1.0; unsigned bm = 0;
+          for (unsigned c2 = cand; c2; c2 &= c2 - 1) {
+            const int j = __builtin_ctz(c2);
+            const double aj = gbcast8_d(attr, j);
+            if (aj > mx) { mx = aj; bm = 1u << j; }
+            else if (fabs(aj - mx) < 1e-9) bm |= 1u << j;
+          }
+          if (!bm) { rc = 1; done = true; }
+          else pick = nth_set_bit(bm, (int)g.randbelow((unsigned long long)__builtin_popcount(bm)));
+        } else {
+          double sum = 0.0;                                         // :252
+          for (unsigned c2 = cand; c2; c2 &= c2 - 1) sum = sum + gbcast8_d(attr, __builtin_ctz(c2));
+          if (sum < 1e-9) pick = nth_set_bit(cand, (int)g.randbelow((unsigned long long)ncand));   // :253-254
+          else {
+            double ps = 0.0;                                        // :255-258
+            for (unsigned c2 = cand; c2; c2 &= c2 - 1) ps = ps + gbcast8_d(attr, __builtin_ctz(c2)) / sum;
+            const bool renorm = fabs(ps - 1.0) > 1e-6;
+            const double u = g.random();                            // :259
+            double last = 0.0; bool first = true;
+            for (unsigned c2 = cand; c2; c2 &= c2 - 1) {
+              double pj = gbcast8_d(attr, __builtin_ctz(c2)) / sum; if (renorm) pj = pj / ps;
+              last = first ? pj : last + pj; first = false;
+            }
+            double acc = 0.0; first = true; int idx = 0, seen = 0;
+            for (unsigned c2 = cand; c2; c2 &= c2 - 1) {
+              double pj = gbcast8_d(attr, __builtin_ctz(c2)) / sum; if (renorm) pj = pj / ps;
+              acc = first ? pj : acc + pj; first = false;
+              seen += 1;
+              if (acc / last <= u) idx = seen;
+            }
+            if (idx > ncand - 1) idx = ncand - 1;
+            pick = nth_set_bit(cand, idx);
+          }
+        }
+        if (!done) {
+          plen += gbcast8_d(mcost, pick);                           // :293
+          if (prev_k >= 0 && pick != prev_k) nturn += 1;
+          prev_k = pick;
+          cr += gbcast8_i(mdr, pick); cc += gbcast8_i(mdc, pick);
+          if (n >= p.path_cap) { rc = 3; done = true; }
+          else {
+            if (k == 0) { out[n] = cr * C + cc; visit[cr * C + cc] = epoch; }
+            n += 1; steps += 1;
+          }
+        }
+      }
+    }
+    if (done) {                                                     // emit, then fetch a new ant next round
+      if (rc == 0 && !(cr == tr && cc == tc)) rc = 2;               // :301-302 step cap
+      steps_tot += (unsigned long long)steps;
+      if (k == 0) {
+        p.len[a] = rc == 0 ? n : 0;
+        p.plen[a] = rc == 0 ? plen : PF_INF;
+        p.turns[a] = rc == 0 ? nturn : -1;
+        p.status[a] = rc;
+      }
+      cells_tot += rc == 0 ? n : 0;
+      need = true;
+    }
+  }
+  if (k == 0) {
+    p.slot_epoch[slot] = epoch;
+    atomicAdd(&p.cnt->steps, steps_tot); atomicAdd(&p.cnt->candidates, cand_tot); atomicAdd(&p.cnt->path_cells, cells_tot);
+  }
+}
+
 // ===========================================================================
 // K5: pheromone update (evaporate / ordered deposit / clip)
 // ===========================================================================
@@ -595,11 +748,18 @@ __global__ void k_tau_deposit(double* tau, const uint8_t* occ, int RC, const uns
   if (i >= RC) return;
   double t = tau[i];
   bool touched = false;
-  for (int w = 0; w < nwords; ++w) {
-    unsigned long long b = bits[(size_t)w * RC + i];
-    while (b) {
-      const int j = __builtin_ctzll(b); b &= b - 1;
-      t += dep[w * 64 + j]; touched = true;
+  // the sum must run in ant order, but the (coalesced) word loads need not wait for it: 8 in flight per thread
+  for (int w0 = 0; w0 < nwords; w0 += 8) {
+    unsigned long long b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) b[u] = (w0 + u < nwords) ? bits[(size_t)(w0 + u) * RC + i] : 0ull;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      unsigned long long x = b[u];
+      while (x) {
+        const int j = __builtin_ctzll(x); x &= x - 1;
+        t += dep[(w0 + u) * 64 + j]; touched = true;
+      }
     }
   }
   if (touched && occ[i] != 1) tau[i] = t;
@@ -1004,7 +1164,7 @@ struct pf_handle {
   bool maaco_ready = false;
   pf_maaco_params mp = {};
   double *d_tau = nullptr, *d_taua = nullptr, *d_eta = nullptr, *d_dep = nullptr;
-  unsigned* d_visit = nullptr; unsigned* d_visit_epoch = nullptr;
+  unsigned* d_visit = nullptr; unsigned* d_visit_epoch = nullptr; int maaco_slots = 0;
   unsigned long long* d_bits = nullptr; size_t bits_words = 0; int dep_cap = 0;
   // MPA
   bool mpa_ready = false;
@@ -1111,6 +1271,7 @@ static const int kUse16 = env_int("PF_USE16", 1);      // PF_USE16=0 forces the 
 // Mpops/s on 7168 random G512 pairs: rows idle until the gang's longest search ends, and 512 LDS entries per
 // agent spill heavily) -> off by default; kept, parity-tested, as the base of the per-row state machine
 static int g_use16_min = env_int("PF_USE16_MIN", 0x7fffffff);
+static int g_maaco_pack8_min = env_int("PF_MAACO_PACK8_MIN", 2048);   // ants per batch from which 8 ants share a wavefront
 static const int kLdsS = PF_S;
 static int ensure_slots(pf_handle* h, int allow_diag = 1, int restrict_corner = 1) {
   CK(hipSetDevice(h->device));
@@ -1371,6 +1532,7 @@ extern "C" int pf_debug_stamps(pf_handle* h, uint64_t* out, int reset) {
 int pf_set_option(pf_handle* h, const char* name, int64_t value) {
   if (!name) return failmsg(h, "pf_set_option: bad arguments");
   if (!strcmp(name, "use16_min")) { g_use16_min = (int)value; return 0; }
+  if (!strcmp(name, "maaco_pack8_min")) { g_maaco_pack8_min = (int)value; return 0; }
   return failmsg(h, std::string("pf_set_option: unknown option ") + name);
 }
 int pf_selftest_sqrt(pf_handle* h, int32_t n, const int64_t* d_in, double* d_out) {
@@ -1443,8 +1605,12 @@ int pf_maaco_setup(pf_handle* h, const pf_maaco_params* p) {
   CK(hipStreamSynchronize(h->stream));
   if (!h->d_visit) {
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, h->device));
-    if (!h->nslots) { int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; h->nslots = cus * kSlotsPerCU; }
-    const int vs = h->nslots * 2;   // walk kernel has no LDS: up to 32 waves/CU resident
+    const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (!h->nslots) h->nslots = cus * kSlotsPerCU;
+    // one tabu-stamp array per resident ant: up to 128 ants per CU (16 waves x 8 ants), within 32 GiB
+    int vs = cus * 128;
+    while ((size_t)vs * RC * sizeof(unsigned) > (32ull << 30) && vs > cus * 32) vs /= 2;
+    h->maaco_slots = vs;
     CK(hipMalloc(&h->d_visit, sizeof(unsigned) * (size_t)vs * RC));
     CK(hipMemsetAsync(h->d_visit, 0, sizeof(unsigned) * (size_t)vs * RC, h->stream));
     CK(hipMalloc(&h->d_visit_epoch, sizeof(unsigned) * vs));
@@ -1480,11 +1646,15 @@ int pf_maaco_walk_batch(pf_handle* h, int32_t iter, uint64_t seed, int32_t ant0,
   a.q0 = maaco_q0(iter, h->mp.num_iterations, h->mp.q0_initial);
   a.seed = seed; a.ant0 = ant0; a.n = n; a.path_cap = path_cap;
   a.cells = d_cells; a.len = d_len; a.plen = d_plen; a.turns = d_turns; a.status = d_status;
-  int grid = h->nslots * 2; if (grid > n) grid = n;
+  // eight ants per wavefront (k_maaco_walk8) once the batch can fill the chip that way; else one per wave
+  const bool pack8 = n >= g_maaco_pack8_min;
+  int grid = pack8 ? h->maaco_slots / 8 : (h->maaco_slots < 8192 ? h->maaco_slots : 8192);
+  const int need = pack8 ? (n + 7) / 8 : n; if (grid > need) grid = need;
   CK(hipMemsetAsync(h->d_work, 0, sizeof(int), h->stream));
   CK(hipMemsetAsync(h->d_cnt, 0, sizeof(DevCounters), h->stream));
   CK(hipEventRecord(h->ev0, h->stream));
-  hipLaunchKernelGGL(k_maaco_walk, dim3(grid), dim3(64), 0, h->stream, a);
+  if (pack8) hipLaunchKernelGGL(k_maaco_walk8, dim3(grid), dim3(64), 0, h->stream, a);
+  else hipLaunchKernelGGL(k_maaco_walk, dim3(grid), dim3(64), 0, h->stream, a);
   CK(hipGetLastError());
   CK(hipEventRecord(h->ev1, h->stream));
   DevCounters dc; if (end_batch(h, &dc)) return -1;

@@ -133,7 +133,8 @@ class ShardedMAACO:
         plen, turns = m.walk_iteration(iter_num, self.a0, n)
         allp = c.all_gather_concat(plen, self.counts)
         allt = c.all_gather_concat(turns, self.counts)
-        ib_len, ib_turns, ib_idx = maaco_best_scan_host(allp, allt)
+        scan = getattr(m.engine, "maaco_best_scan", None)     # C twin of maaco_best_scan_host (same sequential rule)
+        ib_len, ib_turns, ib_idx = scan(allp, allt, 0, INF, INF, -1) if scan else maaco_best_scan_host(allp, allt)
         take = ib_len < m.best_path_length_overall or \
             (abs(ib_len - m.best_path_length_overall) < 1e-9 and ib_turns < m.best_path_turns_overall)
         if take and ib_idx >= 0:

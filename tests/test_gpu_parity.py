@@ -246,3 +246,13 @@ def test_four_agents_per_wave_path_matches(which):
          "decode": test_decode_and_score_golden, "decode512": test_decode_random_512_vs_oracle}[which]()
     finally:
         e.set_option("use16_min", 0x7fffffff)
+
+
+def test_maaco_eight_ants_per_wave_path_matches():
+    """k_maaco_walk8 (8 ants per wavefront, in-loop refetch) == goldens: force it on for tiny batches too."""
+    e, _, _, _, _ = eng("fig7")
+    e.set_option("maaco_pack8_min", 1)
+    try:
+        test_maaco_golden_walks_and_pheromone()
+    finally:
+        e.set_option("maaco_pack8_min", 2048)
