@@ -93,6 +93,7 @@ int pf_dev_alloc(pf_handle* h, int64_t bytes, void** d_out);
 int pf_dev_free(pf_handle* h, void* d_ptr);
 int pf_h2d(pf_handle* h, void* d_dst, const void* src, int64_t bytes);
 int pf_d2h(pf_handle* h, void* dst, const void* d_src, int64_t bytes);
+int pf_d2d(pf_handle* h, void* d_dst, const void* d_src, int64_t bytes);
 int pf_memset(pf_handle* h, void* d_dst, int32_t byte, int64_t bytes);
 /* counters of the most recent batch call */
 int pf_get_counters(pf_handle* h, pf_counters* out);

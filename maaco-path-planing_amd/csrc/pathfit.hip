@@ -1256,6 +1256,7 @@ int pf_dev_alloc(pf_handle* h, int64_t bytes, void** d_out) { CK(hipSetDevice(h-
 int pf_dev_free(pf_handle* h, void* p) { CK(hipSetDevice(h->device)); CK(hipFree(p)); return 0; }
 int pf_h2d(pf_handle* h, void* d, const void* s, int64_t n) { CK(hipMemcpyAsync(d, s, (size_t)n, hipMemcpyHostToDevice, h->stream)); CK(hipStreamSynchronize(h->stream)); return 0; }
 int pf_d2h(pf_handle* h, void* d, const void* s, int64_t n) { CK(hipMemcpyAsync(d, s, (size_t)n, hipMemcpyDeviceToHost, h->stream)); CK(hipStreamSynchronize(h->stream)); return 0; }
+int pf_d2d(pf_handle* h, void* d, const void* s, int64_t n) { CK(hipMemcpyAsync(d, s, (size_t)n, hipMemcpyDeviceToDevice, h->stream)); CK(hipStreamSynchronize(h->stream)); return 0; }
 int pf_memset(pf_handle* h, void* d, int32_t b, int64_t n) { CK(hipMemsetAsync(d, b, (size_t)n, h->stream)); CK(hipStreamSynchronize(h->stream)); return 0; }
 int pf_get_counters(pf_handle* h, pf_counters* out) { *out = h->last; return 0; }
 float pf_last_kernel_ms(pf_handle* h) { return h->last_ms; }

@@ -51,6 +51,7 @@ SYMBOLS = {
     "pf_dev_free": (C.c_int, [_vp, _vp]),
     "pf_h2d": (C.c_int, [_vp, _vp, _vp, _i64]),
     "pf_d2h": (C.c_int, [_vp, _vp, _vp, _i64]),
+    "pf_d2d": (C.c_int, [_vp, _vp, _vp, _i64]),
     "pf_memset": (C.c_int, [_vp, _vp, _i32, _i64]),
     "pf_get_counters": (C.c_int, [_vp, C.POINTER(Counters)]),
     "pf_last_kernel_ms": (C.c_float, [_vp]),

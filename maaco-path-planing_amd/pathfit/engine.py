@@ -101,6 +101,10 @@ class Engine:
         a = np.ascontiguousarray(arr, dtype)
         return DevBuf(self, a.shape if a.ndim else (1,), a.dtype).upload(a)
 
+    def d2d(self, dst_ptr, src_ptr, nbytes):
+        if nbytes:
+            self._ck(self.L.pf_d2d(self.h, dst_ptr, src_ptr, int(nbytes)))
+
     def set_option(self, name, value):
         self._ck(self.L.pf_set_option(self.h, name.encode(), int(value)))
 
@@ -190,6 +194,19 @@ class Engine:
     def pso_update(self, n, W, w, c1, c2, max_vel, d_pos, d_vel, d_pbest, d_gbest, seed, it, agent0=0):
         self._ck(self.L.pf_pso_update(self.h, n, W, w, c1, c2, max_vel, d_pos.ptr, d_vel.ptr, d_pbest.ptr,
                                       d_gbest.ptr, int(seed), int(it), int(agent0)))
+
+    def pso_update_raw(self, n, W, w, c1, c2, max_vel, pos_ptr, vel_ptr, pbest_ptr, gbest_ptr, seed, it, agent0):
+        self._ck(self.L.pf_pso_update(self.h, n, W, w, c1, c2, max_vel, pos_ptr, vel_ptr, pbest_ptr, gbest_ptr,
+                                      int(seed), int(it), int(agent0)))
+
+    def decode_raw(self, n, W, start, target, path_cap, cells_ptr, len_ptr, status_ptr, wp_pos_ptr, sp, stats_ptr,
+                   allow_diag=True, restrict_corner=True):
+        self._ck(self.L.pf_decode_batch(self.h, int(allow_diag), int(restrict_corner), n, W, None, wp_pos_ptr,
+                                        int(start), int(target), path_cap, cells_ptr, len_ptr, status_ptr,
+                                        C.byref(sp), stats_ptr))
+
+    def pso_pbest_raw(self, n, W, pos_ptr, stats_ptr, len_ptr, pbest_ptr, pbf_ptr, imp_ptr):
+        self._ck(self.L.pf_pso_pbest(self.h, n, W, pos_ptr, stats_ptr, len_ptr, pbest_ptr, pbf_ptr, imp_ptr))
 
     def pso_pbest(self, n, W, d_pos, d_stats, d_len, d_pbest, d_pbest_fit, d_improved):
         self._ck(self.L.pf_pso_pbest(self.h, n, W, d_pos.ptr, d_stats.ptr, d_len.ptr, d_pbest.ptr, d_pbest_fit.ptr,

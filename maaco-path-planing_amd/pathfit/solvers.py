@@ -288,7 +288,7 @@ class PSOSolver(_WaypointSolver):
     def __init__(self, grid, num_iterations, num_particles, num_waypoints_per_particle, w, c1, c2,
                  turn_penalty_factor=0.1, safety_penalty_factor=0.05, min_safe_distance=1.5, allow_diagonal_moves=True,
                  restrict_diagonal_near_obstacle_policy=True, diagonal_obstacle_penalty_value=1000.0, engine=None,
-                 device=0, seed=0, verbose=False):
+                 device=0, seed=0, verbose=False, asynchronous=True):
         g = np.asarray(grid)
         start_node = find_marker(g, START_NODE_VAL, "PSO")
         target_node = find_marker(g, TARGET_NODE_VAL, "PSO")
@@ -305,6 +305,9 @@ class PSOSolver(_WaypointSolver):
         self.particles = []
         self.gbest_particle_data = {"fitness": INF, "path": [], "position": []}
         self.verbose = verbose
+        # asynchronous=True reproduces pso.py:222-229 exactly (a particle sees the gbest updated by the particles
+        # before it in the same sweep) by speculate-and-repair; False = one batch per sweep (sweep-start gbest)
+        self.asynchronous = bool(asynchronous)
 
     def _reconstruct_path_from_position(self, position_waypoints_float):
         """pso.py:56-94 for one particle."""
@@ -375,25 +378,52 @@ class PSOSolver(_WaypointSolver):
         d_cells, d_len, d_st = e.buf((N, cap), np.int32), e.buf(N, np.int32), e.buf(N, np.int32)
         d_stats, d_imp = e.buf((N, 5), np.float64), e.buf(N, np.int32)
         s_cell, t_cell = self._cell(self.start_node), self._cell(self.target_node)
+        d_pos0, d_vel0 = e.buf((N, W, 2), np.float64), e.buf((N, W, 2), np.float64)
+        st_sz = W * 2 * 8
         for it in range(self.num_iterations):
             # ---- hot path, all resident in HBM: update -> decode/stitch -> score -> pbest ----
-            e.pso_update(N, W, self.w, self.c1, self.c2, self.max_vel, d_pos, d_vel, d_pb, d_gb, self.seed, it, 0)
-            e.decode_batch(N, W, s_cell, t_cell, cap, d_cells, d_len, d_st, None, d_pos, self._sp, d_stats,
-                           self.allow_diagonal_moves, self.restrict_diagonal_near_obstacle_policy)
-            st = d_st.download()
-            if (st == 3).any():
-                raise RuntimeError("pathfit: scratch/path capacity overflow in PSO decode")
-            e.pso_pbest(N, W, d_pos, d_stats, d_len, d_pb, d_pbf, d_imp)
-            stats, lens, imp = d_stats.download(), d_len.download(), d_imp.download()
-            # gbest: first improver with the smallest fitness below the current gbest (pso.py:222 in particle order)
-            cand = np.flatnonzero(imp)
-            if cand.size:
-                j = cand[np.argmin(stats[cand, 4])]
-                if stats[j, 4] < self.gbest_particle_data["fitness"]:
+            # Speculate that no particle of [lo, N) improves gbest: evaluate them in one batch with the current
+            # gbest.  Everything up to and including the first improver p* is exact; gbest moves to p* and the
+            # particles after it are rolled back and re-evaluated (their draws are keyed per particle, so the
+            # re-evaluation consumes the same random numbers).  Synchronous mode commits the whole batch.
+            lo = 0
+            while lo < N:
+                m = N - lo
+                if self.asynchronous:
+                    e.d2d(d_pos0.at(lo * W * 2), d_pos.at(lo * W * 2), m * st_sz)
+                    e.d2d(d_vel0.at(lo * W * 2), d_vel.at(lo * W * 2), m * st_sz)
+                e.pso_update_raw(m, W, self.w, self.c1, self.c2, self.max_vel, d_pos.at(lo * W * 2), d_vel.at(lo * W * 2),
+                                 d_pb.at(lo * W * 2), d_gb.ptr, self.seed, it, lo)
+                e.decode_raw(m, W, s_cell, t_cell, cap, d_cells.at(lo * cap), d_len.at(lo), d_st.at(lo), d_pos.at(lo * W * 2),
+                             self._sp, d_stats.at(lo * 5), self.allow_diagonal_moves, self.restrict_diagonal_near_obstacle_policy)
+                st = d_st.download()
+                if (st[lo:] == 3).any():
+                    raise RuntimeError("pathfit: scratch/path capacity overflow in PSO decode")
+                stats, lens = d_stats.download(), d_len.download()
+                pbf = d_pbf.download()
+                improves = (lens[lo:] > 0) & (stats[lo:, 4] < pbf[lo:]) & (stats[lo:, 4] < self.gbest_particle_data["fitness"])
+                if self.asynchronous:
+                    hit = np.flatnonzero(improves)
+                    upto = lo + int(hit[0]) if hit.size else N - 1          # last particle whose evaluation is final
+                else:
+                    upto = N - 1
+                k = upto - lo + 1
+                e.pso_pbest_raw(k, W, d_pos.at(lo * W * 2), d_stats.at(lo * 5), d_len.at(lo), d_pb.at(lo * W * 2),
+                                d_pbf.at(lo), d_imp.at(lo))                  # pso.py:216-220
+                # gbest (pso.py:222-229): in asynchronous mode the committed range holds at most one improver (its last
+                # particle); in synchronous mode take the first particle with the smallest improving fitness
+                cand = lo + np.flatnonzero(improves[:k])
+                if cand.size:
+                    j = int(cand[np.argmin(stats[cand, 4])])
                     cells = d_cells.download()[j, :lens[j]]
                     pos_j = d_pos.download()[j]
                     self._set_gbest(j, pos_j, CellPath(cells, self.cols), stats[j])
                     d_gb.upload(pos_j)
+                if upto < N - 1:                                             # roll back the not yet final particles
+                    r = upto + 1
+                    e.d2d(d_pos.at(r * W * 2), d_pos0.at(r * W * 2), (N - r) * st_sz)
+                    e.d2d(d_vel.at(r * W * 2), d_vel0.at(r * W * 2), (N - r) * st_sz)
+                lo = upto + 1
             self.convergence_curve.append(self.gbest_particle_data["fitness"])
             if self.verbose and ((it + 1) % 10 == 0 or it == 0 or it == self.num_iterations - 1):
                 b = self.gbest_particle_data

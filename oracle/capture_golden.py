@@ -376,6 +376,11 @@ def cap_e2e(G):
         d[f"ga0_{k}"] = np.asarray(r[k])
     d["ga0_attempts"] = np.array(r["attempts"])
     print("e2e ga fitness", r["stats"][4], "attempts", r["attempts"])
+    pk = dict(num_iterations=8, num_particles=24, num_waypoints_per_particle=5, w=0.7, c1=1.5, c2=1.5, **MAIN_W)
+    r = ref_e2e.pso_solve(G["fig7"], 6, **pk)
+    for k in ("path", "stats", "curve", "pos", "pbest_fit"):
+        d[f"pso0_{k}"] = np.asarray(r[k])
+    print("e2e pso fitness", r["stats"][4], "attempts", r["attempts"], "gbest changes", len(set(r["curve"])))
     np.savez_compressed(os.path.join(OUT, "e2e.npz"), **d, **{"meta_" + k: v for k, v in META.items()})
 
 

@@ -102,3 +102,42 @@ def ga_solve(grid, seed, **kw):
     return dict(path=rh.to_cells(res[0], ga.cols), stats=np.array([res[1], res[2], res[3], res[4], res[5]], float),
                 curve=np.array(ga.convergence_curve, float), attempts=st["attempt"],
                 pop_fitness=np.array([p["fitness"] for p in ga.population]))
+
+
+def pso_solve(grid, seed, **kw):
+    """PSOSolver.solve() of the unmodified reference (asynchronous gbest, pso.py:178-229).  Streams: init attempt k
+    -> (seed, DOM_INIT, 0, k) (re-keyed at the first _generate_random_waypoint call of each attempt); particle p of
+    iteration it -> (seed, DOM_PSO, it, p) (re-keyed right after the previous particle's _reconstruct call)."""
+    m = rh.install()
+    with rh.quiet():
+        ps = m["pso"].PSOSolver(np.array(grid), **kw)
+    W, N = ps.num_waypoints, ps.num_particles
+    st = dict(wp=0, rec=0, run=False)
+    o_wp, o_rec, o_init = ps._generate_random_waypoint, ps._reconstruct_path_from_position, ps._initialize_particles
+
+    def wp():
+        if st["wp"] % W == 0:
+            rh.RNG.rekey(seed, pfrng.DOM_INIT, 0, st["wp"] // W)
+        st["wp"] += 1
+        return o_wp()
+
+    def rec(pos):
+        r = o_rec(pos)
+        if st["run"]:
+            st["rec"] += 1
+            it, p = divmod(st["rec"], N)
+            rh.RNG.rekey(seed, pfrng.DOM_PSO, it, p)
+        return r
+
+    def init():
+        ok = o_init()
+        st["run"] = True
+        rh.RNG.rekey(seed, pfrng.DOM_PSO, 0, 0)
+        return ok
+    ps._generate_random_waypoint, ps._reconstruct_path_from_position, ps._initialize_particles = wp, rec, init
+    with rh.quiet():
+        res = ps.solve()
+    return dict(path=rh.to_cells(res[0], ps.cols), stats=np.array([res[1], res[2], res[3], res[4], res[5]], float),
+                curve=np.array(ps.convergence_curve, float), attempts=st["wp"] // W,
+                pos=np.array([p["position"] for p in ps.particles], float),
+                pbest_fit=np.array([p["pbest_fitness"] for p in ps.particles], float))

@@ -98,3 +98,11 @@ def test_gpu_facades_match_reference_solve_loops():
     res = ga.solve()
     assert [r * 20 + c for r, c in res[0]] == list(z["ga0_path"]) and np.array_equal(np.array(res[1:], float), z["ga0_stats"])
     assert np.array_equal(np.array(ga.convergence_curve), z["ga0_curve"])
+    # PSO with the reference's asynchronous gbest (pso.py:222-229) reproduced by speculate-and-repair
+    ps = pathfit.PSOSolver(g, num_iterations=8, num_particles=24, num_waypoints_per_particle=5, w=0.7, c1=1.5, c2=1.5,
+                           turn_penalty_factor=0.3, safety_penalty_factor=0.8, min_safe_distance=1.8,
+                           diagonal_obstacle_penalty_value=100.0, seed=6)
+    res = ps.solve()
+    assert [r * 20 + c for r, c in res[0]] == list(z["pso0_path"]) and np.array_equal(np.array(res[1:], float), z["pso0_stats"])
+    assert np.array_equal(np.array(ps.convergence_curve), z["pso0_curve"])
+    assert np.array_equal(ps._pos, z["pso0_pos"]) and np.array_equal(ps._pbest_fit, z["pso0_pbest_fit"])

@@ -108,7 +108,7 @@ def test_pso_solve_matches_oracle_loop():
     orc = po.Oracle(g)
     kw = dict(num_iterations=8, num_particles=32, num_waypoints_per_particle=5, w=0.7, c1=1.5, c2=1.5,
               turn_penalty_factor=0.3, safety_penalty_factor=0.8, min_safe_distance=1.8, diagonal_obstacle_penalty_value=100.0,
-              seed=6)
+              seed=6, asynchronous=False)
     a = pathfit.PSOSolver(g, **kw)
     ra = a.solve()
     # oracle loop: same init (host RNG), then synchronous sweeps
