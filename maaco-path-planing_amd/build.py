@@ -12,7 +12,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "pathfit.hip")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("pf_device.h", "pf_astar.h", "pf_score.h")] + \
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(HERE, "csrc"))) if f.endswith(".h")] + \
        [os.path.join(os.path.dirname(HERE), "include", "pathfit.h")]
 OUT = os.path.join(HERE, "lib", "libpathfit.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

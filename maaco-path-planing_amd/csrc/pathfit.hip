@@ -46,13 +46,14 @@ PF_DEV Open make_open(char* smem, int /*S*/, char* tier2) {
   O.lf = (double*)smem;
   O.lg = O.lf + 64 * PF_S;
   O.lc = (int*)(O.lg + 64 * PF_S);
+  O.sx = smem + (size_t)64 * PF_S * 20;
   char* t2 = tier2 + (size_t)blockIdx.x * (64 * PF_T2 * 20);
   O.of = (double*)t2;
   O.og = O.of + 64 * PF_T2;
   O.oc = (int*)(O.og + 64 * PF_T2);
   return O;
 }
-static size_t open_bytes(int S) { return (size_t)64 * S * 20; }
+static size_t open_bytes(int S) { return (size_t)64 * S * 20 + PF_SPEC_LDS; }
 
 PF_DEV Slot slot_load(const Common& c, int RC) {
   Slot s;
@@ -773,6 +774,11 @@ __global__ void k_tau_clip(double* tau, const uint8_t* occ, int RC, double tmin,
 // ===========================================================================
 // K7 + K2b + K1: MPA
 // ===========================================================================
+#ifdef PF_TRACE
+__device__ unsigned long long g_trace[4 * 16384];   // diagnostic build only: per sweep item {t0, t1, pops, wave}
+__device__ unsigned long long g_trace3[4 * 16384];  // phase items {1 + idx, inter, cur, -}; fads items {1, node, -, -}
+__device__ unsigned long long g_trace2[4 * 16384];  // per sweep item {pops A*#1, result A*#1, pops A*#2, result A*#2}
+#endif
 struct MpaDev {
   double P, levy_beta, sigma, fads;
   int N, start, target;
@@ -877,6 +883,9 @@ __device__ void mpa_phase_item(const MpaPhaseArgs& p, int a, Slot& s, const Open
           if (refL > 0) en = ref[(int)g.randbelow((unsigned long long)refL)];   // random.choice :248
           inter = brownian_target(g, G, cur, en, scale);
         }
+#ifdef PF_TRACE
+        if (lane == 0 && a < 8192) { g_trace3[4 * a] = 1 + idx; g_trace3[4 * a + 1] = inter; g_trace3[4 * a + 2] = cur; }
+#endif
         if (idx + 1 > p.path_cap) rc = 3;
         else {
           copy_path(out, mod, idx + 1, lane);                     // :296
@@ -888,7 +897,13 @@ __device__ void mpa_phase_item(const MpaPhaseArgs& p, int a, Slot& s, const Open
             if (seg == 0) { if (!(G.occ[inter] != 1 && inter != astart)) continue; goal = inter; }   // :298
             else { if (astart == p.m.target) continue; goal = p.m.target; }                           // :306
             int mlen = 0;
+#ifdef PF_TRACE
+            const unsigned long long pq0 = tot.pops;
+#endif
             const int r2 = astar<1>(G, s, O, astart, goal, out + n - 1, p.path_cap - (n - 1), mlen, tot, lane);
+#ifdef PF_TRACE
+            if (lane == 0 && a < 8192) { g_trace2[4 * a + 2 * seg] = tot.pops - pq0; g_trace2[4 * a + 2 * seg + 1] = 100 + r2; }
+#endif
             if (r2 == 3) { rc = 3; break; }
             if (r2 == 0 && mlen > 1) {                            // :300-305 / :308-309
               if (seg == 0) { mark_avoid(s, out + n, mlen - 1, lane); astart = inter; }
@@ -969,12 +984,23 @@ __device__ void mpa_fads_item(const MpaFadsArgs& p, int a, Slot& s, const Open& 
         const int node = rr_ * G.C + rc_;
         if (G.occ[node] != 1) {                                    // :393
           int m1 = 0;
+#ifdef PF_TRACE
+          const unsigned long long pq0 = tot.pops;
+          if (lane == 0 && a < 8192) { g_trace3[4 * (p.n + a)] = 1; g_trace3[4 * (p.n + a) + 1] = node; }
+#endif
           int r1 = astar<1>(G, s, O, p.m.start, node, tmp, p.path_cap, m1, tot, lane);   // :394
+#ifdef PF_TRACE
+          if (lane == 0 && a < 8192) { g_trace2[4 * (p.n + a)] = tot.pops - pq0; g_trace2[4 * (p.n + a) + 1] = 100 + r1; }
+          const unsigned long long pq1 = tot.pops;
+#endif
           if (r1 == 3) rc = 3;
           else if (r1 == 0 && m1 > 0) {
             mark_avoid(s, tmp, m1 - 1, lane);                      // set(p1[:-1]) :396
             int m2 = 0;
             int r2 = astar<1>(G, s, O, node, p.m.target, tmp + m1 - 1, p.path_cap - (m1 - 1), m2, tot, lane);
+#ifdef PF_TRACE
+            if (lane == 0 && a < 8192) { g_trace2[4 * (p.n + a) + 2] = tot.pops - pq1; g_trace2[4 * (p.n + a) + 3] = 100 + r2; }
+#endif
             if (r2 == 3) rc = 3;
             else if (r2 == 0 && m2 > 0) { n = m1 + m2 - 1; have = true; }   // :398-400 (last is the target by construction)
           }
@@ -1035,8 +1061,16 @@ __global__ __launch_bounds__(64) void k_mpa_sweep(MpaSweepArgs p) {
   for (;;) {
     const int item = next_agent(p.ph.c, 2 * p.ph.n, lane);
     if (item < 0) break;
+#ifdef PF_TRACE
+    const unsigned long long tr0 = wall_clock64(), pp0 = tot.pops;
+#endif
     if (item < p.ph.n) mpa_phase_item(p.ph, item, s, O, tot, cells, ovf, lane);
     else mpa_fads_item(p.fd, item - p.ph.n, s, O, tot, cells, ovf, lane);
+#ifdef PF_TRACE
+    if (lane == 0 && item < 16384) {
+      g_trace[4 * item] = tr0; g_trace[4 * item + 1] = wall_clock64(); g_trace[4 * item + 2] = tot.pops - pp0; g_trace[4 * item + 3] = blockIdx.x;
+    }
+#endif
   }
   slot_store(p.ph.c, s, lane);
   flush_counters(p.ph.c.cnt, tot, cells, ovf, lane);
@@ -1147,6 +1181,7 @@ struct pf_handle {
   uint8_t *d_occ = nullptr, *d_mm_r1 = nullptr, *d_mm_r0 = nullptr, *d_mm_r1_nd = nullptr, *d_mm_r0_nd = nullptr,
           *d_d2near = nullptr;
   std::vector<uint8_t> h_occ;
+  int* d_comp[4] = {nullptr, nullptr, nullptr, nullptr};   // component labels per move-mask policy (lazy)
   int nslots = 0;
   int rec_policy = -1;   // which move-mask variant the search records currently carry
   Rec* d_rec = nullptr;
@@ -1185,10 +1220,40 @@ static int fail(pf_handle* h, const char* what, hipError_t e) {
 static int failmsg(pf_handle* h, const std::string& m) { if (h) h->err = m; else g_create_err = m; return -2; }
 #define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(h, #call, e_); } while (0)
 
+// Connected components of the free cells under one move-mask policy: host flood fill over the device-built
+// masks (once per policy and grid).  On any failure the labels stay null and the searches simply run in full.
+static const int* ensure_comp(pf_handle* h, int policy, const uint8_t* d_mm) {
+  if (h->d_comp[policy]) return h->d_comp[policy];
+  const int RC = h->RC, C = h->C;
+  std::vector<uint8_t> mm(RC);
+  if (hipMemcpy(mm.data(), d_mm, RC, hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
+  static const int DR[8] = {0, 0, 1, -1, 1, 1, -1, -1}, DC[8] = {1, -1, 0, 0, 1, -1, 1, -1};   // helper.py:38-52 order
+  std::vector<int> comp(RC, -1), stack;
+  int next = 0;
+  for (int s0 = 0; s0 < RC; ++s0) {
+    if (h->h_occ[s0] == 1 || comp[s0] >= 0) continue;
+    comp[s0] = next; stack.push_back(s0);
+    while (!stack.empty()) {
+      const int c = stack.back(); stack.pop_back();
+      const unsigned m = mm[c];
+      for (int k = 0; k < 8; ++k) if ((m >> k) & 1u) {
+        const int n = c + DR[k] * C + DC[k];
+        if (comp[n] < 0) { comp[n] = next; stack.push_back(n); }
+      }
+    }
+    next += 1;
+  }
+  int* d = nullptr;
+  if (hipMalloc(&d, (size_t)RC * sizeof(int)) != hipSuccess) return nullptr;
+  if (hipMemcpy(d, comp.data(), (size_t)RC * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+  h->d_comp[policy] = d;
+  return d;
+}
 static Grid make_grid(pf_handle* h, int allow_diag, int restrict_corner) {
   Grid G;
   G.occ = h->d_occ;
   G.mm = allow_diag ? (restrict_corner ? h->d_mm_r1 : h->d_mm_r0) : (restrict_corner ? h->d_mm_r1_nd : h->d_mm_r0_nd);
+  G.comp = ensure_comp(h, (allow_diag ? 2 : 0) | (restrict_corner ? 1 : 0), G.mm);
   G.d2near = h->d_d2near; G.R = h->R; G.C = h->C;
   G.magicC = ((1ull << 40) / (uint64_t)h->C) + 1;
   return G;
@@ -1244,7 +1309,8 @@ void pf_destroy(pf_handle* h) {
   (void)hipSetDevice(h->device);
   void* ptrs[] = {h->d_occ, h->d_mm_r1, h->d_mm_r0, h->d_mm_r1_nd, h->d_mm_r0_nd, h->d_d2near, h->d_rec, h->d_slot_state,
                   h->d_work, h->d_cnt, h->d_pen, h->d_tier2, h->d_tau, h->d_taua, h->d_eta, h->d_dep, h->d_visit, h->d_visit_epoch,
-                  h->d_bits, h->d_tmp, h->d_elite_stats, h->d_init_cells, h->d_init_stats, h->d_est, h->d_queue};
+                  h->d_bits, h->d_tmp, h->d_elite_stats, h->d_init_cells, h->d_init_stats, h->d_est, h->d_queue,
+                  h->d_comp[0], h->d_comp[1], h->d_comp[2], h->d_comp[3]};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1267,6 +1333,7 @@ float pf_last_kernel_ms(pf_handle* h) { return h->last_ms; }
 // resident agent slots per CU and LDS bin capacity; PF_SLOTS_PER_CU / PF_LDS_S override for experiments
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; }
 static const int kSlotsPerCU = 16;                      // 4 waves/CU x 4 agents (16-lane path); 64-lane kernels use <= 8
+static const int kWavesPerCU = env_int("PF_WAVES_PER_CU", 8);   // resident one-agent waves per CU (LDS permitting)
 static const int kUse16 = env_int("PF_USE16", 1);      // PF_USE16=0 forces the one-agent-per-wave kernels
 // measured r01: the lockstep-gang form is SLOWER than one agent per wave on heterogeneous searches (211 vs 450
 // Mpops/s on 7168 random G512 pairs: rows idle until the gang's longest search ends, and 512 LDS entries per
@@ -1391,7 +1458,7 @@ static int launch_with_retry(pf_handle* h, Kern kern, KArgs& args, int n) {
   args.c.S = S; args.c.retry = 0;
   const size_t lds = open_bytes(S);
   CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int per_cu = (int)((160 * 1024) / lds); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;
+  int per_cu = (int)((160 * 1024) / lds); if (per_cu > kWavesPerCU) per_cu = kWavesPerCU; if (per_cu < 1) per_cu = 1;
   int grid = (h->nslots / kSlotsPerCU) * per_cu; if (grid > n) grid = n; if (grid > h->nslots) grid = h->nslots;
   CK(hipMemsetAsync(h->d_work, 0, sizeof(int), h->stream));
   CK(hipMemsetAsync(h->d_cnt, 0, sizeof(DevCounters), h->stream));
@@ -1522,6 +1589,18 @@ int pf_pso_pbest(pf_handle* h, int32_t n, int32_t W, const double* d_pos, const 
   return 0;
 }
 
+#ifdef PF_TRACE
+extern "C" int pf_debug_trace(pf_handle* h, uint64_t* out) {
+  CK(hipSetDevice(h->device));
+  CK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(uint64_t) * 4 * 16384));
+  CK(hipMemcpyFromSymbol(out + 4 * 16384, HIP_SYMBOL(g_trace2), sizeof(uint64_t) * 4 * 16384));
+  CK(hipMemcpyFromSymbol(out + 8 * 16384, HIP_SYMBOL(g_trace3), sizeof(uint64_t) * 4 * 16384));
+  uint64_t* z = (uint64_t*)calloc(4 * 16384, 8);
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(g_trace2), z, sizeof(uint64_t) * 4 * 16384));
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(g_trace3), z, sizeof(uint64_t) * 4 * 16384)); free(z);
+  return 0;
+}
+#endif
 #ifdef PF_STAMPS
 extern "C" int pf_debug_stamps(pf_handle* h, uint64_t* out, int reset) {
   CK(hipSetDevice(h->device));
@@ -1874,7 +1953,7 @@ int pf_mpa_iter_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uint
   a.ph.c.S = S; a.fd.c.S = S; a.ph.c.retry = 0; a.fd.c.retry = 0;
   const size_t lds = open_bytes(S);
   CK(hipFuncSetAttribute((const void*)k_mpa_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int per_cu = (int)((160 * 1024) / lds); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;
+  int per_cu = (int)((160 * 1024) / lds); if (per_cu > kWavesPerCU) per_cu = kWavesPerCU; if (per_cu < 1) per_cu = 1;
   int grid = (h->nslots / kSlotsPerCU) * per_cu; if (grid > 2 * n) grid = 2 * n; if (grid > h->nslots) grid = h->nslots;
   CK(hipMemsetAsync(h->d_work, 0, sizeof(int), h->stream));
   CK(hipMemsetAsync(h->d_cnt, 0, sizeof(DevCounters), h->stream));

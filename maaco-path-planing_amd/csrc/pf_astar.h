@@ -33,7 +33,9 @@
 
 namespace pf {
 
+#ifndef PF_S
 #define PF_S 16 /* LDS slots per bin (compile-time: LDS addresses fold to constants, fewer SGPRs) */
+#endif
 struct Open {
   double* lf;  // [64*S] bin-major; +inf == free slot
   double* lg;
@@ -43,7 +45,11 @@ struct Open {
   double* of;  // [64*PF_T2]
   double* og;
   int* oc;
+  char* sx;    // PF_SPEC_LDS bytes of LDS for the speculative loop's row exchange (pf_astar4.h)
 };
+#ifndef PF_SPEC
+#define PF_SPEC 1 /* 1: four-wide speculative pop loop (pf_astar4.h); 0: one pop per trip (A/B builds) */
+#endif
 
 struct Slot {
   Rec* rec;
@@ -103,6 +109,10 @@ PF_DEV void slot_wipe(Slot& s, int RC, int lane) {
 // helper-order move deltas from the move index without a table lookup
 PF_DEV int move_dr(int d) { return (int)((0x0A25u >> (2 * d)) & 3u) - 1; }   // {0,0,1,-1,1,1,-1,-1} + 1 packed
 PF_DEV int move_dc(int d) { return (int)((0x2252u >> (2 * d)) & 3u) - 1; }   // {1,-1,0,0,1,-1,1,-1} + 1 packed
+
+}  // namespace pf
+#include "pf_astar4.h"
+namespace pf {
 
 // ---------------------------------------------------------------------------
 // Bounded pocket check.  When the goal (or the start) is sealed inside a small pocket by the avoid set, the
@@ -190,6 +200,10 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
     out_n = 1;
     return 0;
   }
+  // Moves are symmetric (a diagonal and its reverse are gated by the same two orthogonal cells), so the free
+  // cells split into components no search can leave, whatever its avoid set.  A goal in another component
+  // makes both references pop the start's whole component and return [] (astar.py:103 / MPA.py:151).
+  if (G.comp && G.comp[start] != G.comp[target]) return 1;
   const uint32_t avm = s.avoid_ep;
   Rec* rec = s.rec;
   // MPA._a_star drops avoid nodes from every neighbour list (MPA.py:82) with no exemption for the goal, so a
@@ -232,6 +246,11 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
     n_open = 1;
   }
   const int max_steps = G.R * C * (VARIANT == 0 ? 3 : 2);   // astar.py:58 / MPA.py:118 (R,C <= 4096)
+#if PF_SPEC
+  (void)occ; (void)occ2; (void)any_t2; (void)mf; (void)mg; (void)mc; (void)ms; (void)rr; (void)n_open; (void)full;
+  const int status4 = pop_loop4<VARIANT>(G, rec, O, tag, avm, start, target, tr, tc, max_steps, st, lane);
+  if (status4 != 0) return status4;
+#else
   int steps = 0;
   unsigned nbr32 = 0, push32 = 1, dk32 = 0;
   int status = 1;
@@ -423,6 +442,7 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
 #endif
   st.pops += (unsigned long long)steps; st.pushes += push32; st.nbr += nbr32; st.deckey += dk32;
   if (status != 0) return status;
+#endif
 
   // ---- walk parents target -> start (astar.py:65-69 / MPA.py:124-130), then reverse in place ----
   int n = 0, cell = target;

@@ -159,6 +159,7 @@ __device__ int astar16(const Grid& G, Slot& s, const Open16& O, int start, int t
     out_n = 1;
     return 0;
   }
+  if (G.comp && G.comp[start] != G.comp[target]) return 1;   // different static components (see astar<>)
   const uint32_t avm = s.avoid_ep;
   Rec* rec = s.rec;
   if (VARIANT == 1 && (rec[target].meta >> PF_AVOID_SHIFT) == avm) return 1;   // goal inside the avoid set (see astar<>)

@@ -45,6 +45,7 @@ struct Grid {
   const uint8_t* occ;     // R*C, 1 = obstacle
   const uint8_t* mm;      // static move mask (helper order) under the call's diagonal policy
   const uint8_t* d2near;  // min(d^2 to nearest obstacle, 255) within radius 7
+  const int* comp;        // connected-component label of every free cell under `mm` (obstacles: -1); may be null
   int R, C;
   uint64_t magicC;        // floor(2^40 / C) + 1 : cell / C == (cell * magicC) >> 40 for cell < 2^24
 };

@@ -1,0 +1,21 @@
+"""Diagnostic: lone-wave speed of the pop loop.  python scripts/probe_lone.py <lib.so> [n]  (-DPF_TRIPS build reports trips)"""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "maaco-path-planing_amd"), os.path.join(ROOT, "tests")]
+import numpy as np
+from pathfit import _lib
+_lib._SO = os.path.abspath(sys.argv[1])
+import golden_io as gio
+from pathfit.engine import Engine
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+g = gio.upsample(gio.grid("g256")[0], 2)
+e = Engine(g)
+rnd = np.random.default_rng(1)
+free = np.flatnonzero(g.reshape(-1) != 1)
+starts = rnd.choice(free, n).astype(np.int32); targets = rnd.choice(free, n).astype(np.int32)
+starts[0], targets[0] = 0, g.size - 1
+for variant in (0, 1):
+    for rep in range(2):
+        paths, st, cnt = e.astar_host(variant, starts, targets, None, path_cap=8192, want_counters=True)
+    pops = cnt[:, 0].sum()
+    print(f"n={n} v{variant}: {e.last_kernel_ms():.2f} ms, pops {pops}, us/pop(lone wave 0) {1e3 * e.last_kernel_ms() / cnt[0, 0] if n == 1 else 0:.3f}, Mpops/s {pops / e.last_kernel_ms() / 1e3:.1f}, trips-or-maxopen[0] {cnt[0, 2]}, pops/trip {cnt[0, 0] / max(cnt[0, 2], 1):.2f}")

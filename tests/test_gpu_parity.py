@@ -99,6 +99,37 @@ def test_astar_random_512_vs_oracle():
             assert cnt[0, 0] == 91044
 
 
+def test_astar_sealed_rooms_vs_oracle():
+    """Goals/starts in free rooms no move can enter (larger than the 512-cell pocket flood): the static component
+    test must give the reference's answer (no path), under every move policy and with avoid sets."""
+    from pathfit.engine import Engine
+    import pf_oracle as po
+    rnd = np.random.default_rng(9)
+    g = (rnd.random((96, 96)) < 0.08).astype(np.uint8)
+    g[20:62, 30] = 1; g[20:62, 71] = 1; g[20, 30:72] = 1; g[61, 30:72] = 1          # sealed 40x40 room
+    g[70:90, 5:8] = 1; g[70, 5:30] = 1; g[89, 5:30] = 1; g[70:90, 29] = 1             # second room, diagonal leak at a corner
+    g[89, 29] = 0; g[88, 29] = 1; g[89, 28] = 1
+    e, o = Engine(g), po.Oracle(g)
+    free = np.flatnonzero(g.reshape(-1) != 1)
+    inside = np.array([c for c in free if 20 < c // 96 < 61 and 30 < c % 96 < 71])
+    room2 = np.array([c for c in free if 70 < c // 96 < 89 and 7 < c % 96 < 29])
+    n = 40
+    starts = np.concatenate([rnd.choice(inside, 10), rnd.choice(free, 10), rnd.choice(room2, 10), rnd.choice(free, 10)])
+    targets = np.concatenate([rnd.choice(free, 10), rnd.choice(inside, 10), rnd.choice(free, 10), rnd.choice(room2, 10)])
+    avoid = [rnd.choice(free, 60) if i % 3 == 0 else None for i in range(n)]
+    for variant in (0, 1):
+        for restrict in (1, 0):
+            paths, st, _ = e.astar_host(variant, starts, targets, avoid, path_cap=4096, restrict_corner=restrict, want_counters=True)
+            fails = 0
+            for i in range(n):
+                o.restrict = restrict
+                want, _ = o.astar(int(starts[i]), int(targets[i]), avoid[i], variant)
+                assert st[i] != 3 and np.array_equal(paths[i], want), (variant, restrict, i)
+                fails += len(want) == 0
+            assert fails >= 10
+    e.close()
+
+
 def test_decode_and_score_golden():
     from pathfit.engine import score_params
     z = gio.load("decode_cases")
