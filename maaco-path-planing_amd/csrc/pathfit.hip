@@ -32,7 +32,7 @@ struct DevCounters {
 struct Common {
   Grid G;
   Rec* rec;              // [nslots][RC]
-  char* tier2;           // [nslots][64*PF_T2*20] open-list overflow
+  char* tier2;           // [nslots][PF_POOL_STRIDE] open-list HBM scratch (bucket pool / tier-2 overflow)
   uint32_t* slot_state;  // [nslots][2] = {tag, avoid_ep}
   int* work;             // dynamic work counter
   const int* queue;      // optional work order (longest-expected-first), else identity
@@ -47,7 +47,7 @@ PF_DEV Open make_open(char* smem, int /*S*/, char* tier2) {
   O.lg = O.lf + 64 * PF_S;
   O.lc = (int*)(O.lg + 64 * PF_S);
   O.sx = smem + (size_t)64 * PF_S * 20;
-  char* t2 = tier2 + (size_t)blockIdx.x * (64 * PF_T2 * 20);
+  char* t2 = tier2 + (size_t)blockIdx.x * PF_POOL_STRIDE;
   O.of = (double*)t2;
   O.og = O.of + 64 * PF_T2;
   O.oc = (int*)(O.og + 64 * PF_T2);
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64) void k_astar_batch16(AstarArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int RC = p.c.G.R * p.c.G.C;
   const int slot = blockIdx.x * 4 + rgrp();
-  Open16 O = make_open16(smem, p.c.tier2 + (size_t)slot * (64 * PF_T2 * 20));
+  Open16 O = make_open16(smem, p.c.tier2 + (size_t)slot * PF_POOL_STRIDE);
   Slot s = slot_load16(p.c, RC);
   AStat tot = {0, 0, 0, 0, 0};
   unsigned long long cells = 0, ovf = 0;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(64) void k_decode_batch16(DecodeArgs p) {
   const int RC = G.R * G.C;
   const int L = rlane();
   const int slot = blockIdx.x * 4 + rgrp();
-  Open16 O = make_open16(smem, p.c.tier2 + (size_t)slot * (64 * PF_T2 * 20));
+  Open16 O = make_open16(smem, p.c.tier2 + (size_t)slot * PF_POOL_STRIDE);
   Slot s = slot_load16(p.c, RC);
   AStat tot = {0, 0, 0, 0, 0};
   unsigned long long cells = 0, ovf = 0;
@@ -1352,7 +1352,7 @@ static int ensure_slots(pf_handle* h, int allow_diag = 1, int restrict_corner = 
     while (bytes > (64ull << 30) && h->nslots > cus) { h->nslots /= 2; bytes = (size_t)h->nslots * h->RC * sizeof(Rec); }
     CK(hipMalloc(&h->d_rec, bytes));
     CK(hipMalloc(&h->d_slot_state, sizeof(uint32_t) * 2 * h->nslots));
-    CK(hipMalloc(&h->d_tier2, (size_t)h->nslots * 64 * PF_T2 * 20));
+    CK(hipMalloc(&h->d_tier2, (size_t)h->nslots * PF_POOL_STRIDE));
   }
   const int policy = (allow_diag ? 2 : 0) | (restrict_corner ? 1 : 0);
   if (h->rec_policy != policy) {

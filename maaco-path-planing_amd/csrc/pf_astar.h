@@ -47,8 +47,9 @@ struct Open {
   int* oc;
   char* sx;    // PF_SPEC_LDS bytes of LDS for the speculative loop's row exchange (pf_astar4.h)
 };
-#ifndef PF_SPEC
-#define PF_SPEC 1 /* 1: four-wide speculative pop loop (pf_astar4.h); 0: one pop per trip (A/B builds) */
+#ifndef PF_LOOP
+#define PF_LOOP 2 /* pop loop: 2 sorted window over a bucket pool (pf_astar_sw.h), 1 four-wide speculative pops over lane-owned
+                     bins (pf_astar4.h), 0 one pop per trip over lane-owned bins; 0/1 are kept for A/B builds */
 #endif
 
 struct Slot {
@@ -112,6 +113,7 @@ PF_DEV int move_dc(int d) { return (int)((0x2252u >> (2 * d)) & 3u) - 1; }   // 
 
 }  // namespace pf
 #include "pf_astar4.h"
+#include "pf_astar_sw.h"
 namespace pf {
 
 // ---------------------------------------------------------------------------
@@ -232,9 +234,11 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
   int n_open = 0;
 
   // seed: (h(start), 0, start) into bin 0; record g(start) = 0
+  double h0_seed;
   {
     long dr0 = sr - tr, dc0 = sc_ - tc;
     double h0 = __builtin_sqrt((double)(dr0 * dr0 + dc0 * dc0));
+    h0_seed = h0;
     if (lane == 0) {
       O.lf[0] = h0; O.lg[0] = 0.0; O.lc[0] = (sr << 16) | sc_;
       mf = h0; mg = 0.0; mc = (sr << 16) | sc_; ms = 0; occ = 1;
@@ -246,9 +250,13 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
     n_open = 1;
   }
   const int max_steps = G.R * C * (VARIANT == 0 ? 3 : 2);   // astar.py:58 / MPA.py:118 (R,C <= 4096)
-#if PF_SPEC
-  (void)occ; (void)occ2; (void)any_t2; (void)mf; (void)mg; (void)mc; (void)ms; (void)rr; (void)n_open; (void)full;
+#if PF_LOOP != 0
+  (void)occ; (void)occ2; (void)any_t2; (void)mf; (void)mg; (void)mc; (void)ms; (void)rr; (void)n_open; (void)full; (void)h0_seed;
+#if PF_LOOP == 2
+  const int status4 = pop_loop_sw<VARIANT>(G, rec, O, tag, avm, start, target, tr, tc, max_steps, h0_seed, (sr << 16) | sc_, st, lane);
+#else
   const int status4 = pop_loop4<VARIANT>(G, rec, O, tag, avm, start, target, tr, tc, max_steps, st, lane);
+#endif
   if (status4 != 0) return status4;
 #else
   int steps = 0;

@@ -1,0 +1,304 @@
+// pf_astar_sw.h -- sorted-window pop loop of the one-wavefront A* (included by pf_astar.h; PF_LOOP == 2).
+//
+// The lane-owned-bin loops pay, for every pop, a 64-lane argmin (two DPP reductions), a rescan of the bin the
+// entry left (LDS round trip + another reduction) and a cached-minimum update per push: ~430 instructions a
+// pop, all on one wave's issue port.  Here the open list is a monotone bucket queue with a sorted window:
+//
+//   pool    entries live unsorted in HBM buckets keyed by floor(f * Q) (Q = 64, 256 circular buckets: a push is at
+//           most 2*sqrt(2) above the pop that made it, 182 buckets); an append is one LDS atomic for the slot
+//           index and three fire-and-forget stores -- nothing waits for it;
+//   window  when the window runs dry the next non-empty buckets (<= 64 entries) are loaded one entry per lane and
+//           sorted on the full key (f, g, cell) by a bitonic network over the lanes; lane k then holds the k-th
+//           next pop.  A pop is five v_readlane; no reduction, no rescan;
+//   limit   every pool entry is >= every window entry.  A push whose key is below the window's limit is
+//           inserted in place (one ballot for the position, one wave shift); when the window is full its largest
+//           entry goes back to the pool and becomes the limit;
+//   decrease-key (VARIANT 0, astar.py:96-100) = push the new entry; the old one is recognised when popped (its g
+//           no longer equals the record's g, or the cell is closed) and dropped without being counted -- the same
+//           pop sequence as the reference's in-place update + heapify, whose order depends only on the keys.
+// The bucket function is monotone in f and equal f share a bucket, so taking whole buckets in order and sorting
+// them on (f, g, cell) reproduces the reference's total order exactly (tests compare paths and pop counts).
+#pragma once
+
+namespace pf {
+
+#define PF_SW_Q 64.0
+#define PF_SW_NBK 256
+#define PF_SW_CAP 1024
+
+PF_DEV bool key_lt(double f1, double g1, int c1, double f2, double g2, int c2) {   // branch-free (f, g, cell) order
+  return (f1 < f2) | ((f1 == f2) & ((g1 < g2) | ((g1 == g2) & (c1 < c2))));
+}
+PF_DEV int bperm_i(int src_lane, int v) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+PF_DEV double bperm_d(int src_lane, double v) {
+  const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+// lane i <- lane i-1 (lane 0 keeps its value) / lane i <- lane i+1 (lane 63 keeps its value)
+PF_DEV int wave_up_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xF, 0xF, false); }     // wave_shr:1
+PF_DEV int wave_down_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xF, 0xF, false); }   // wave_shl:1
+PF_DEV double wave_up_d(double v) { return __hiloint2double(wave_up_i(__double2hiint(v)), wave_up_i(__double2loint(v))); }
+PF_DEV double wave_down_d(double v) { return __hiloint2double(wave_down_i(__double2hiint(v)), wave_down_i(__double2loint(v))); }
+
+// one compare-exchange stage of a bitonic network: partner = lane ^ j, ascending where `up`
+PF_DEV void cmpx(double& f, double& g, int& c, int lane, int j, bool up) {
+  const int p = lane ^ j;
+  const double pf_ = bperm_d(p, f), pg_ = bperm_d(p, g);
+  const int pc_ = bperm_i(p, c);
+  const bool lower = (lane & j) == 0;
+  const bool take = (lower == up) ? key_lt(pf_, pg_, pc_, f, g, c) : key_lt(f, g, c, pf_, pg_, pc_);
+  if (take) { f = pf_; g = pg_; c = pc_; }
+}
+// sort the first n2 (power of two) lanes ascending; unused lanes must hold f = +inf
+PF_DEV void sort_lanes(double& f, double& g, int& c, int lane, int n2) {
+  for (int k = 2; k <= n2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) cmpx(f, g, c, lane, j, (lane & k) == 0);
+}
+// 64 lanes holding a bitonic sequence -> ascending
+PF_DEV void merge_lanes(double& f, double& g, int& c, int lane) {
+  for (int j = 32; j > 0; j >>= 1) cmpx(f, g, c, lane, j, true);
+}
+
+struct SwPool {
+  int* cnt;      // LDS [NBK + 1] entries per bucket; bucket NBK is the FRONT bucket: entries above the window's limit
+                 // but below every regular bucket (window evictions, late low pushes of MPA._a_star's stale pops)
+  double* bf;    // HBM [(NBK + 1)*CAP]
+  double* bg;
+  int* bc;
+};
+// append one entry (uniform values): to the front bucket when it sorts before every regular bucket
+// (f below the boundary of bucket bcur), else to its f bucket; returns false on a full bucket
+PF_DEV bool pool_put1(const SwPool& P, double f, double g, int c, int bcur, int lane) {
+  const int ba = (int)(f * PF_SW_Q);
+  const int b = ba < bcur ? PF_SW_NBK : (ba & (PF_SW_NBK - 1));
+  PF_LDS_ORDER();
+  const int n = P.cnt[b];
+  if (n >= PF_SW_CAP || ba - bcur >= PF_SW_NBK) return false;
+  if (lane == 0) { P.bf[b * PF_SW_CAP + n] = f; P.bg[b * PF_SW_CAP + n] = g; P.bc[b * PF_SW_CAP + n] = c; P.cnt[b] = n + 1; }
+  PF_LDS_ORDER();
+  return true;
+}
+// A bucket larger than the window: leave its 64 smallest entries sorted in the lanes, compact the rest in place.
+PF_DEV void take_smallest64(const SwPool& P, int bi, int c0, double& wf, double& wg, int& wc, int lane) {
+  constexpr int CAP = PF_SW_CAP;
+  wf = P.bf[bi * CAP + lane]; wg = P.bg[bi * CAP + lane]; wc = P.bc[bi * CAP + lane];
+  sort_lanes(wf, wg, wc, lane, 64);
+  int wr = 0;
+  for (int rd = 64; rd < c0; rd += 64) {
+    const int m = c0 - rd < 64 ? c0 - rd : 64;
+    double cf = PF_INF, cg = 0.0; int cc = 0;
+    if (lane < m) { cf = P.bf[bi * CAP + rd + lane]; cg = P.bg[bi * CAP + rd + lane]; cc = P.bc[bi * CAP + rd + lane]; }
+    sort_lanes(cf, cg, cc, lane, 64);
+    const double rf = bperm_d(63 - lane, cf), rg = bperm_d(63 - lane, cg);   // chunk reversed: window ++ reversed chunk is bitonic
+    const int rc_ = bperm_i(63 - lane, cc);
+    const bool sw = key_lt(rf, rg, rc_, wf, wg, wc);
+    const double hf = sw ? wf : rf, hg = sw ? wg : rg;                       // the larger of each pair goes back
+    const int hc = sw ? wc : rc_;
+    if (sw) { wf = rf; wg = rg; wc = rc_; }
+    merge_lanes(wf, wg, wc, lane);
+    const unsigned long long fin = __ballot(hf != PF_INF);
+    if (hf != PF_INF) {
+      const int at = wr + __builtin_popcountll(fin & ((1ull << lane) - 1ull));
+      P.bf[bi * CAP + at] = hf; P.bg[bi * CAP + at] = hg; P.bc[bi * CAP + at] = hc;
+    }
+    wr += __builtin_popcountll(fin);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                   // write-back before the next chunk is read
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+  if (lane == 0) P.cnt[bi] = wr;
+}
+
+template <int VARIANT>
+__device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& O, uint32_t tag, uint32_t avm, int start, int target,
+                                           int tr, int tc, int max_steps, double h0, int src, AStat& st, int lane) {
+  constexpr int NBK = PF_SW_NBK, CAP = PF_SW_CAP;
+  const int C = G.C, RC = G.R * G.C;
+  SwPool P;
+  P.cnt = (int*)O.lf; P.bf = O.of; P.bg = P.bf + (NBK + 1) * CAP; P.bc = (int*)(P.bg + (NBK + 1) * CAP);
+  for (int k = lane; k <= NBK; k += 64) P.cnt[k] = 0;
+  PF_LDS_ORDER();
+
+  // the window: lane k in [wp, wn) holds the (k - wp)-th next pop
+  double wf = PF_INF, wg = 0.0;
+  int wc = 0;
+  if (lane == 0) { wf = h0; wg = 0.0; wc = src; }
+  int wp = 0, wn = 1;
+  int bcur = (int)(h0 * PF_SW_Q) + 1;                 // first bucket (absolute index) not yet taken into the window
+  double lf = (double)bcur * (1.0 / PF_SW_Q), lg = -PF_INF;   // keys below (lf, lg, lc) belong to the window
+  int lc = 0;
+  int n_pool = 0;                                      // entries in the pool
+  int steps = 0, status = 1;
+  unsigned nbr32 = 0, push32 = 1, dk32 = 0;
+  int n_max = 1;
+
+  // per-lane constants: lanes 0..7 relax move `lane`, lane 8 reads the popped cell itself
+  const int d = lane & 7;
+  const int ddr = move_dr(d), ddc = move_dc(d);
+  const int doff = lane < 8 ? ddr * C + ddc : 0;
+  const double cost = d < 4 ? 1.0 : PF_SQRT2;
+
+  for (;;) {
+    if (wp == wn) {
+      // ---- refill: the front bucket if it holds anything, else the next non-empty buckets (<= 64 entries); sorted ----
+      if (n_pool == 0) { status = 1; break; }
+      const int cF = P.cnt[NBK];
+      wf = PF_INF; wg = 0.0; wc = 0;
+      if (cF > 0) {
+        if (cF <= 64) {
+          if (lane < cF) { wf = P.bf[NBK * CAP + lane]; wg = P.bg[NBK * CAP + lane]; wc = P.bc[NBK * CAP + lane]; }
+          if (lane == 0) P.cnt[NBK] = 0;
+          int n2 = 1; while (n2 < cF) n2 <<= 1;
+          sort_lanes(wf, wg, wc, lane, n2);
+          wp = 0; wn = cF; n_pool -= cF;
+          lf = (double)bcur * (1.0 / PF_SW_Q); lg = -PF_INF; lc = 0;
+        } else {
+          take_smallest64(P, NBK, cF, wf, wg, wc, lane);
+          wp = 0; wn = 64; n_pool -= 64;
+          lf = bcast_d(wf, 63); lg = bcast_d(wg, 63); lc = bcast_i(wc, 63);        // the rest of the front bucket is above this key
+        }
+      } else {
+        int b0 = -1;
+        for (int base = 0; base < NBK; base += 64) {
+          const int c_ = P.cnt[(bcur + base + lane) & (NBK - 1)];
+          const unsigned long long nz = __ballot(c_ > 0);
+          if (nz) { b0 = bcur + base + __builtin_ctzll(nz); break; }
+        }
+        if (b0 < 0) { status = 3; break; }             // cannot happen (n_pool > 0): never loop silently
+        const int cb = P.cnt[(b0 + lane) & (NBK - 1)]; // lane k: size of the k-th bucket from b0 (wraps onto empty ones)
+        const int c0 = bcast_i(cb, 0);
+        if (c0 <= 64) {
+          int total = 0, k = 0;
+          for (; k < 64; ++k) {
+            const int ck = bcast_i(cb, k);
+            if (total + ck > 64) break;
+            if (ck > 0) {
+              const int bi = (b0 + k) & (NBK - 1);
+              const int j = lane - total;
+              if (j >= 0 && j < ck) { wf = P.bf[bi * CAP + j]; wg = P.bg[bi * CAP + j]; wc = P.bc[bi * CAP + j]; }
+              if (lane == 0) P.cnt[bi] = 0;
+              total += ck;
+            }
+          }
+          int n2 = 1; while (n2 < total) n2 <<= 1;
+          sort_lanes(wf, wg, wc, lane, n2);
+          wp = 0; wn = total; n_pool -= total;
+          bcur = b0 + k;
+          lf = (double)bcur * (1.0 / PF_SW_Q); lg = -PF_INF; lc = 0;
+        } else {
+          take_smallest64(P, b0 & (NBK - 1), c0, wf, wg, wc, lane);
+          wp = 0; wn = 64; n_pool -= 64;
+          bcur = b0;
+          lf = bcast_d(wf, 63); lg = bcast_d(wg, 63); lc = bcast_i(wc, 63);        // the rest of the bucket is above the window's last key
+        }
+      }
+      PF_LDS_ORDER();
+    }
+    if (steps >= max_steps) { status = 2; break; }
+    // ---- pop: the window's first live lane ----
+    const double pg = bcast_d(wg, wp);
+    const int prc = bcast_i(wc, wp);
+    wp += 1;
+    const int pr = prc >> 16, pc = prc & 0xFFFF;
+    const int cur = pr * C + pc;
+    // ---- one batch of loads: 8 neighbour records, the cell's own record, its move mask ----
+    int nidx = cur + doff;
+    nidx = nidx < 0 ? 0 : (nidx >= RC ? RC - 1 : nidx);        // the move mask rejects what the clamp invents
+    Rec rn; rn.g = 0.0; rn.tagmm = 0; rn.meta = 0;
+    unsigned M = 0;
+    if (lane < 9) { rn = rec[nidx]; M = G.mm[cur]; }
+    const int nr = pr + ddr, nc = pc + ddc;
+    const long hdr = nr - tr, hdc = nc - tc;
+    const double hn = __builtin_sqrt((double)(hdr * hdr + hdc * hdc));   // astar.py:90 / MPA.py:140
+    const double cur_g = bcast_d(rn.g, 8);
+    const uint32_t cur_meta = (uint32_t)bcast_i((int)rn.meta, 8);
+    if (VARIANT == 0) {
+      // an entry superseded by a decrease-key (astar.py:96-100 rewrites it in place): not a pop of the reference
+      if ((cur_meta & PF_M_CLOSED) || cur_g != pg) continue;
+    }
+    steps += 1;
+    if (cur == target) { status = 0; break; }                  // astar.py:64 / MPA.py:123
+    if (lane == 8)                                              // astar.py:74 closed.add / leave the open list
+      rec[cur].meta = VARIANT == 0 ? (cur_meta | PF_M_CLOSED) : (cur_meta & ~PF_M_INOPEN);
+    // ---- relax the 8 neighbours in parallel ----
+    const double base_g = VARIANT == 0 ? pg : cur_g;           // astar.py:85 popped g / MPA.py:135 g_score[current]
+    const bool rvalid = (rn.tagmm >> PF_TAG_SHIFT) == tag;
+    const bool avoided = (rn.meta >> PF_AVOID_SHIFT) == avm;
+    const bool closed = rvalid && (rn.meta & PF_M_CLOSED);
+    bool ok = lane < 8 && ((M >> d) & 1u);
+    if (VARIANT == 0) ok = ok && !closed && !(avoided && nidx != start && nidx != target);
+    else ok = ok && !avoided;
+    const double tent = base_g + cost;
+    const bool better = ok && (!rvalid || tent < rn.g);       // astar.py:87 / MPA.py:137
+    const bool in_open = VARIANT == 0 ? rvalid : (rvalid && (rn.meta & PF_M_INOPEN));
+    const bool push = VARIANT == 0 ? better : (better && !in_open);
+    const double fnew = tent + hn;                             // astar.py:90 / MPA.py:140
+    const int nrc = (nr << 16) | nc;
+    nbr32 += (unsigned)__builtin_popcountll(__ballot(ok));
+    if (VARIANT == 0) dk32 += (unsigned)__builtin_popcountll(__ballot(better && in_open));
+    if (better) {
+      Rec wv; wv.g = tent; wv.tagmm = (tag << PF_TAG_SHIFT) | (rn.tagmm & 0xFFu);
+      wv.meta = (rn.meta & PF_AVOID_KEEP) | (unsigned)d | (VARIANT == 1 ? PF_M_INOPEN : 0u);
+      rec[nidx] = wv;
+    }
+    // ---- pushes: below the limit -> into the window, else -> pool bucket ----
+    const bool tow = push && key_lt(fnew, tent, nrc, lf, lg, lc);
+    bool bad = false;
+    if (push && !tow) {
+      const int ba = (int)(fnew * PF_SW_Q);
+      const int b = ba < bcur ? NBK : (ba & (NBK - 1));         // below every regular bucket: the front bucket
+      const int at = __hip_atomic_fetch_add(&P.cnt[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (at < CAP && ba - bcur < NBK) { P.bf[b * CAP + at] = fnew; P.bg[b * CAP + at] = tent; P.bc[b * CAP + at] = nrc; }
+      else bad = true;
+    }
+    const unsigned long long pm = __ballot(push), im0 = __ballot(tow);
+    if (__ballot(bad)) { status = 3; break; }                  // a bucket is full (or out of the circular range)
+    n_pool += __builtin_popcountll(pm & ~im0);
+    push32 += (unsigned)__builtin_popcountll(VARIANT == 0 ? __ballot(push && !in_open) : pm);   // heappush calls of the reference
+    unsigned long long im = im0;
+    while (im) {
+      const int l = __builtin_ctzll(im); im &= im - 1;
+      const double kf = bcast_d(fnew, l), kg = bcast_d(tent, l);
+      const int kc = bcast_i(nrc, l);
+      if (!key_lt(kf, kg, kc, lf, lg, lc)) {                   // an eviction inside this loop lowered the limit
+        if (!pool_put1(P, kf, kg, kc, bcur, lane)) { status = 3; break; }
+        n_pool += 1;
+        continue;
+      }
+      const bool live = lane >= wp && lane < wn;
+      const int p = wp + __builtin_popcountll(__ballot(live && key_lt(wf, wg, wc, kf, kg, kc)));   // first live lane not below the key
+      if (wn < 64) {
+        const double sf = wave_up_d(wf), sg = wave_up_d(wg); const int sc = wave_up_i(wc);
+        if (lane > p && lane <= wn) { wf = sf; wg = sg; wc = sc; }
+        if (lane == p) { wf = kf; wg = kg; wc = kc; }
+        wn += 1;
+      } else if (wp > 0) {
+        const double sf = wave_down_d(wf), sg = wave_down_d(wg); const int sc = wave_down_i(wc);
+        if (lane >= wp - 1 && lane < p - 1) { wf = sf; wg = sg; wc = sc; }
+        if (lane == p - 1) { wf = kf; wg = kg; wc = kc; }
+        wp -= 1;
+      } else {
+        // 64 live entries: the largest key (the new one, or lane 63's) returns to the pool and becomes the limit
+        double ef = kf, eg = kg; int ec = kc;
+        if (p < 64) {
+          ef = bcast_d(wf, 63); eg = bcast_d(wg, 63); ec = bcast_i(wc, 63);
+          const double sf = wave_up_d(wf), sg = wave_up_d(wg); const int sc = wave_up_i(wc);
+          if (lane > p) { wf = sf; wg = sg; wc = sc; }
+          if (lane == p) { wf = kf; wg = kg; wc = kc; }
+        }
+        if (!pool_put1(P, ef, eg, ec, bcur, lane)) { status = 3; break; }
+        n_pool += 1;
+        lf = ef; lg = eg; lc = ec;
+      }
+    }
+    if (status == 3) break;
+    PF_LDS_ORDER();
+    const int n_open = n_pool + (wn - wp);
+    if (n_open > n_max) n_max = n_open;
+  }
+  if (n_max > st.max_open) st.max_open = n_max;
+  st.pops += (unsigned long long)steps; st.pushes += push32; st.nbr += nbr32; st.deckey += dk32;
+  return status;
+}
+
+}  // namespace pf
