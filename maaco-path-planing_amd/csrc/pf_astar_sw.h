@@ -132,11 +132,13 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
   unsigned nbr32 = 0, push32 = 1, dk32 = 0;
   int n_max = 1;
 
-  // per-lane constants: lanes 0..7 relax move `lane`, lane 8 reads the popped cell itself
-  const int d = lane & 7;
+  // per-lane constants: in every 16-lane row, lanes 0..7 relax move `sub`, lane 8 reads the popped cell itself
+  const int grp = lane >> 4, sub = lane & 15;
+  const int d = sub & 7;
   const int ddr = move_dr(d), ddc = move_dc(d);
-  const int doff = lane < 8 ? ddr * C + ddc : 0;
+  const int doff = sub < 8 ? ddr * C + ddc : 0;
   const double cost = d < 4 ? 1.0 : PF_SQRT2;
+  const int trc = (tr << 16) | tc;
 
   for (;;) {
     if (wp == wn) {
@@ -194,49 +196,91 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
       }
       PF_LDS_ORDER();
     }
-    if (steps >= max_steps) { status = 2; break; }
-    // ---- pop: the window's first live lane ----
-    const double pg = bcast_d(wg, wp);
-    const int prc = bcast_i(wc, wp);
-    wp += 1;
+    // ---- pop: up to four heads of the window at once, one per 16-lane row ----
+    // The window is sorted, so the next pops are known.  Row h relaxes head h in registers; head h takes effect
+    // (and counts as a pop) iff every earlier head did, no earlier head pushed a key below head h's, head h lies
+    // more than 2 cells (Chebyshev) from every earlier head -- so its loads saw none of their writes -- and no
+    // earlier head was the target: exactly the pops, in order, that the sequential loop would make.  A head that
+    // does not qualify simply stays in the window.  (CPU simulation of this rule on G512: ~3 pops per trip.)
+    const int nh = wn - wp < 4 ? wn - wp : 4;
+    double hf[4], hg[4]; int hc[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int l = wp + h < 64 ? wp + h : 63;
+      hf[h] = bcast_d(wf, l); hg[h] = bcast_d(wg, l); hc[h] = bcast_i(wc, l);
+    }
+    const double pg = grp == 0 ? hg[0] : (grp == 1 ? hg[1] : (grp == 2 ? hg[2] : hg[3]));
+    const int prc = grp == 0 ? hc[0] : (grp == 1 ? hc[1] : (grp == 2 ? hc[2] : hc[3]));
+    const bool have = grp < nh && sub < 9;
     const int pr = prc >> 16, pc = prc & 0xFFFF;
     const int cur = pr * C + pc;
-    // ---- one batch of loads: 8 neighbour records, the cell's own record, its move mask ----
+    // ---- one batch of loads: 8 neighbour records, the cell's own record, its move mask (and g, MPA variant) ----
     int nidx = cur + doff;
     nidx = nidx < 0 ? 0 : (nidx >= RC ? RC - 1 : nidx);        // the move mask rejects what the clamp invents
     Rec rn; rn.g = 0.0; rn.tagmm = 0; rn.meta = 0;
     unsigned M = 0;
-    if (lane < 9) { rn = rec[nidx]; M = G.mm[cur]; }
+    double cur_g = 0.0;
+    if (have) { rn = rec[nidx]; M = G.mm[cur]; if (VARIANT == 1) cur_g = rec[cur].g; }
     const int nr = pr + ddr, nc = pc + ddc;
     const long hdr = nr - tr, hdc = nc - tc;
-    const double hn = __builtin_sqrt((double)(hdr * hdr + hdc * hdc));   // astar.py:90 / MPA.py:140
-    const double cur_g = bcast_d(rn.g, 8);
-    const uint32_t cur_meta = (uint32_t)bcast_i((int)rn.meta, 8);
-    if (VARIANT == 0) {
-      // an entry superseded by a decrease-key (astar.py:96-100 rewrites it in place): not a pop of the reference
-      if ((cur_meta & PF_M_CLOSED) || cur_g != pg) continue;
-    }
-    steps += 1;
-    if (cur == target) { status = 0; break; }                  // astar.py:64 / MPA.py:123
-    if (lane == 8)                                              // astar.py:74 closed.add / leave the open list
-      rec[cur].meta = VARIANT == 0 ? (cur_meta | PF_M_CLOSED) : (cur_meta & ~PF_M_INOPEN);
-    // ---- relax the 8 neighbours in parallel ----
+    double hn = __builtin_sqrt((double)(hdr * hdr + hdc * hdc));   // astar.py:90 / MPA.py:140
+    asm volatile("" : "+v"(hn));                               // computed in the shadow of the loads
+    // ---- relax the 8 neighbours of each head in registers ----
+    const uint32_t cur_meta = rn.meta;                          // meaningful in the self lanes (sub == 8)
+    // VARIANT 0: an entry superseded by a decrease-key (astar.py:96-100 rewrites it in place) is not a pop of the
+    // reference: its head is consumed without effect and without being counted
+    const bool self_stale = VARIANT == 0 && sub == 8 && ((cur_meta & PF_M_CLOSED) || rn.g != pg);
+    const unsigned long long stm = __ballot(have && self_stale);
+    const bool my_stale = (stm >> ((lane & 48) + 8)) & 1ull;
     const double base_g = VARIANT == 0 ? pg : cur_g;           // astar.py:85 popped g / MPA.py:135 g_score[current]
     const bool rvalid = (rn.tagmm >> PF_TAG_SHIFT) == tag;
     const bool avoided = (rn.meta >> PF_AVOID_SHIFT) == avm;
     const bool closed = rvalid && (rn.meta & PF_M_CLOSED);
-    bool ok = lane < 8 && ((M >> d) & 1u);
+    bool ok = have && sub < 8 && ((M >> d) & 1u) && !my_stale && cur != target;
     if (VARIANT == 0) ok = ok && !closed && !(avoided && nidx != start && nidx != target);
     else ok = ok && !avoided;
     const double tent = base_g + cost;
     const bool better = ok && (!rvalid || tent < rn.g);       // astar.py:87 / MPA.py:137
     const bool in_open = VARIANT == 0 ? rvalid : (rvalid && (rn.meta & PF_M_INOPEN));
-    const bool push = VARIANT == 0 ? better : (better && !in_open);
+    const bool push0 = VARIANT == 0 ? better : (better && !in_open);
     const double fnew = tent + hn;                             // astar.py:90 / MPA.py:140
     const int nrc = (nr << 16) | nc;
-    nbr32 += (unsigned)__builtin_popcountll(__ballot(ok));
-    if (VARIANT == 0) dk32 += (unsigned)__builtin_popcountll(__ballot(better && in_open));
-    if (better) {
+    // ---- which heads take effect ----
+    unsigned viol = 0;                                          // bit h: an earlier row pushes a key below head h
+#pragma unroll
+    for (int h = 1; h < 4; ++h)
+      if (__ballot(push0 && grp < h && key_lt(fnew, tent, nrc, hf[h], hg[h], hc[h]))) viol |= 1u << h;
+    unsigned E = 0;                                             // heads whose relaxation takes effect
+    int consumed = 0;
+    bool hit = false;
+    {
+      unsigned seen = 0;                                        // earlier heads that were real pops
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        if (h >= nh) break;
+        if ((stm >> (16 * h + 8)) & 1ull) { consumed += 1; continue; }
+        bool okh = steps < max_steps && !((viol >> h) & 1u);
+#pragma unroll
+        for (int e = 0; e < h; ++e)
+          if ((seen >> e) & 1u) {
+            const int dr_ = (hc[e] >> 16) - (hc[h] >> 16), dc_ = (hc[e] & 0xFFFF) - (hc[h] & 0xFFFF);
+            if ((unsigned)(dr_ + 2) <= 4u && (unsigned)(dc_ + 2) <= 4u) okh = false;
+          }
+        if (!okh) break;
+        consumed += 1; steps += 1; seen |= 1u << h;
+        if (hc[h] == trc) { hit = true; break; }                // astar.py:64 / MPA.py:123: nothing is relaxed
+        E |= 1u << h;
+      }
+    }
+    if (consumed == 0) { status = 2; break; }                   // only the step cap can stop head 0
+    wp += consumed;
+    const bool eff = (E >> grp) & 1u;
+    if (eff && sub == 8)                                        // astar.py:74 closed.add / leave the open list
+      rec[cur].meta = VARIANT == 0 ? (cur_meta | PF_M_CLOSED) : (cur_meta & ~PF_M_INOPEN);
+    const bool push = push0 && eff;
+    nbr32 += (unsigned)__builtin_popcountll(__ballot(ok && eff));
+    if (VARIANT == 0) dk32 += (unsigned)__builtin_popcountll(__ballot(better && in_open && eff));
+    if (better && eff) {
       Rec wv; wv.g = tent; wv.tagmm = (tag << PF_TAG_SHIFT) | (rn.tagmm & 0xFFu);
       wv.meta = (rn.meta & PF_AVOID_KEEP) | (unsigned)d | (VARIANT == 1 ? PF_M_INOPEN : 0u);
       rec[nidx] = wv;
@@ -292,6 +336,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
       }
     }
     if (status == 3) break;
+    if (hit) { status = 0; break; }
     PF_LDS_ORDER();
     const int n_open = n_pool + (wn - wp);
     if (n_open > n_max) n_max = n_open;
