@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <queue>
 #include <string>
 #include <vector>
 
@@ -26,7 +27,7 @@ using namespace pf;
 // device-side launch parameter blocks
 // ===========================================================================
 struct DevCounters {
-  unsigned long long pops, pushes, nbr, path_cells, steps, candidates, deckey, overflow;
+  unsigned long long pops, pushes, nbr, path_cells, steps, candidates, deckey, overflow, pruned;
 };
 
 struct Common {
@@ -86,7 +87,8 @@ PF_DEV int next_agent(const Common& c, int n, int lane) {
 PF_DEV void flush_counters(DevCounters* c, const AStat& st, unsigned long long cells, unsigned long long ovf, int lane) {
   if (lane == 0) {
     atomicAdd(&c->pops, st.pops); atomicAdd(&c->pushes, st.pushes); atomicAdd(&c->nbr, st.nbr);
-    atomicAdd(&c->deckey, st.deckey); atomicAdd(&c->path_cells, cells); atomicAdd(&c->overflow, ovf);
+    atomicAdd(&c->deckey, st.deckey); atomicAdd(&c->path_cells, cells); atomicAdd(&c->overflow, ovf & 0xFFFFFFFFull);
+    if (ovf >> 32) atomicAdd(&c->pruned, ovf >> 32);           // MPA items count pruned rebuilds in the upper half
   }
 }
 
@@ -782,6 +784,9 @@ __device__ unsigned long long g_trace2[4 * 16384];  // per sweep item {pops A*#1
 struct MpaDev {
   double P, levy_beta, sigma, fads;
   int N, start, target;
+  // exact shortest-path length of every cell from the start / to the target on the static grid (no avoid set),
+  // or null: admissible lower bounds on the length of any path through a cell (see mpa_phase_item / mpa_fads_item)
+  const double* ds; const double* dt;
 };
 PF_DEV long py_round(double x) { return (long)__builtin_rint(x); }
 PF_DEV int clampi(long v, int lo, int hi) { return (int)(v < lo ? lo : (v > hi ? hi : v)); }
@@ -886,7 +891,33 @@ __device__ void mpa_phase_item(const MpaPhaseArgs& p, int a, Slot& s, const Open
 #ifdef PF_TRACE
         if (lane == 0 && a < 8192) { g_trace3[4 * a] = 1 + idx; g_trace3[4 * a + 1] = inter; g_trace3[4 * a + 2] = cur; }
 #endif
-        if (idx + 1 > p.path_cap) rc = 3;
+        // Exact pruning.  The memory step keeps this candidate only if its fitness is BELOW the prey's (:382), and
+        // fitness >= length (the penalty terms are non-negative).  Whatever the two searches find, the rebuilt path
+        // runs prefix -> cur -> (inter ->) target, so its length is at least len(prefix) + min(|cur,inter| +
+        // dt[inter], dt[cur]) with dt the static shortest distance to the target (avoid sets only lengthen paths).
+        // If that bound already reaches the prey's fitness the candidate cannot be accepted; if the rebuild failed
+        // instead (:316-317) the candidate would be the unmodified path, which is no better either when it is the
+        // prey itself or not fitter than the prey.  Same population, none of the work.
+        bool pruned = false;
+        if (p.m.dt && !p.ex_idx) {
+          double pre = 0.0;
+          for (int i = lane; i < idx; i += 64) {
+            const int dd = mod[i + 1] - mod[i];
+            pre += (dd == 1 || dd == -1 || dd == G.C || dd == -G.C) ? 1.0 : PF_SQRT2;
+          }
+          pre = wave_sum_d(pre);
+          double lb = p.m.dt[cur];
+          if (G.occ[inter] != 1 && inter != cur) {
+            const int r0 = row_of(G, cur), r1 = row_of(G, inter);
+            const long dr_ = r1 - r0, dc_ = (inter - r1 * G.C) - (cur - r0 * G.C);
+            lb = fmin(lb, __builtin_sqrt((double)(dr_ * dr_ + dc_ * dc_)) + p.m.dt[inter]);
+          }
+          lb = (pre + lb) * (1.0 - 1e-9);
+          const double prey_fit = prey_stats[4];
+          pruned = lb >= prey_fit && (mod == prey || mod_stats[4] >= prey_fit);
+        }
+        if (pruned) ovf += 1ull << 32;
+        else if (idx + 1 > p.path_cap) rc = 3;
         else {
           copy_path(out, mod, idx + 1, lane);                     // :296
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -982,7 +1013,15 @@ __device__ void mpa_fads_item(const MpaFadsArgs& p, int a, Slot& s, const Open& 
         const int rr_ = (int)g.randint(0, G.R - 1);                // :391
         const int rc_ = (int)g.randint(0, G.C - 1);
         const int node = rr_ * G.C + rc_;
-        if (G.occ[node] != 1) {                                    // :393
+        // Exact pruning (see mpa_phase_item): any path start -> node -> target is at least ds[node] + dt[node] long,
+        // and the candidate is kept only if its fitness is below the predator's (:402), which is at most the fitness
+        // read here (the memory step can only lower it).
+        bool pruned = false;
+        if (p.m.dt && G.occ[node] != 1) {
+          pruned = (p.m.ds[node] + p.m.dt[node]) * (1.0 - 1e-9) >= p.pop_stats[(size_t)slot * 5 + 4];
+          if (pruned) ovf += 1ull << 32;
+        }
+        if (G.occ[node] != 1 && !pruned) {                         // :393
           int m1 = 0;
 #ifdef PF_TRACE
           const unsigned long long pq0 = tot.pops;
@@ -1208,6 +1247,7 @@ struct pf_handle {
   int* d_tmp = nullptr; int tmp_cap = 0;
   double* d_elite_stats = nullptr;
   int* d_init_cells = nullptr; int init_len = 0; int init_cap = 0; double* d_init_stats = nullptr;
+  double* d_ds = nullptr; double* d_dt = nullptr;   // static shortest distances from the start / to the target (pruning bounds)
   float* d_est = nullptr; int* d_queue = nullptr; int est_cap = 0;
 };
 
@@ -1310,7 +1350,7 @@ void pf_destroy(pf_handle* h) {
   void* ptrs[] = {h->d_occ, h->d_mm_r1, h->d_mm_r0, h->d_mm_r1_nd, h->d_mm_r0_nd, h->d_d2near, h->d_rec, h->d_slot_state,
                   h->d_work, h->d_cnt, h->d_pen, h->d_tier2, h->d_tau, h->d_taua, h->d_eta, h->d_dep, h->d_visit, h->d_visit_epoch,
                   h->d_bits, h->d_tmp, h->d_elite_stats, h->d_init_cells, h->d_init_stats, h->d_est, h->d_queue,
-                  h->d_comp[0], h->d_comp[1], h->d_comp[2], h->d_comp[3]};
+                  h->d_comp[0], h->d_comp[1], h->d_comp[2], h->d_comp[3], h->d_ds, h->d_dt};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1339,6 +1379,7 @@ static const int kUse16 = env_int("PF_USE16", 1);      // PF_USE16=0 forces the 
 // Mpops/s on 7168 random G512 pairs: rows idle until the gang's longest search ends, and 512 LDS entries per
 // agent spill heavily) -> off by default; kept, parity-tested, as the base of the per-row state machine
 static int g_use16_min = env_int("PF_USE16_MIN", 0x7fffffff);
+static int g_mpa_prune = 1;   // exact bound pruning of MPA rebuilds (pf_set_option "mpa_prune")
 static int g_maaco_pack8_min = env_int("PF_MAACO_PACK8_MIN", 2048);   // ants per batch from which 8 ants share a wavefront
 static const int kLdsS = PF_S;
 static int ensure_slots(pf_handle* h, int allow_diag = 1, int restrict_corner = 1) {
@@ -1384,6 +1425,7 @@ static int end_batch(pf_handle* h, DevCounters* dc) {
   CK(hipStreamSynchronize(h->stream));
   h->last.pops = dc->pops; h->last.pushes = dc->pushes; h->last.nbr_examined = dc->nbr; h->last.path_cells = dc->path_cells;
   h->last.steps = dc->steps; h->last.candidates = dc->candidates; h->last.decrease_keys = dc->deckey; h->last.overflow_agents = dc->overflow;
+  h->last.pruned_rebuilds = dc->pruned;
   return 0;
 }
 
@@ -1613,6 +1655,7 @@ int pf_set_option(pf_handle* h, const char* name, int64_t value) {
   if (!name) return failmsg(h, "pf_set_option: bad arguments");
   if (!strcmp(name, "use16_min")) { g_use16_min = (int)value; return 0; }
   if (!strcmp(name, "maaco_pack8_min")) { g_maaco_pack8_min = (int)value; return 0; }
+  if (!strcmp(name, "mpa_prune")) { g_mpa_prune = value != 0; return 0; }
   return failmsg(h, std::string("pf_set_option: unknown option ") + name);
 }
 int pf_selftest_sqrt(pf_handle* h, int32_t n, const int64_t* d_in, double* d_out) {
@@ -1814,6 +1857,43 @@ int pf_maaco_best_scan(int32_t n, const double* plen, const int32_t* turns, int3
 // ---------------------------------------------------------------------------
 // MPA host side
 // ---------------------------------------------------------------------------
+// Exact shortest-path lengths from the start and to the target on the static grid (Dijkstra on the host over the
+// device-built move masks; the graph is symmetric).  They are admissible bounds for the MPA pruning tests: every
+// avoid set only removes cells.  Skipped (no pruning) for grids above 4 Mi cells or penalty weights below zero.
+static int dijkstra_host(const pf_handle* h, const std::vector<uint8_t>& mm, int src, std::vector<double>& dist) {
+  static const int DR[8] = {0, 0, 1, -1, 1, 1, -1, -1}, DC[8] = {1, -1, 0, 0, 1, -1, 1, -1};   // helper.py:38-52 order
+  const int C = h->C;
+  dist.assign(h->RC, __builtin_huge_val());
+  if (h->h_occ[src] == 1) return 0;
+  typedef std::pair<double, int> QE;
+  std::priority_queue<QE, std::vector<QE>, std::greater<QE>> pq;
+  dist[src] = 0.0; pq.push(QE(0.0, src));
+  while (!pq.empty()) {
+    const QE e = pq.top(); pq.pop();
+    if (e.first > dist[e.second]) continue;
+    const unsigned m = mm[e.second];
+    for (int k = 0; k < 8; ++k) if ((m >> k) & 1u) {
+      const int n = e.second + DR[k] * C + DC[k];
+      const double t = e.first + (k < 4 ? 1.0 : PF_SQRT2);
+      if (t < dist[n]) { dist[n] = t; pq.push(QE(t, n)); }
+    }
+  }
+  return 0;
+}
+static int mpa_bounds(pf_handle* h) {
+  if (h->d_ds) { (void)hipFree(h->d_ds); h->d_ds = nullptr; }
+  if (h->d_dt) { (void)hipFree(h->d_dt); h->d_dt = nullptr; }
+  if (h->RC > (1 << 22) || h->mps.w_turn < 0.0 || h->mps.w_safe < 0.0 || h->mps.diag_pen < 0.0) return 0;
+  const Grid G = make_grid(h, h->mpp.allow_diag, h->mpp.restrict_corner);
+  std::vector<uint8_t> mm(h->RC);
+  CK(hipMemcpy(mm.data(), G.mm, h->RC, hipMemcpyDeviceToHost));
+  std::vector<double> ds, dt;
+  dijkstra_host(h, mm, h->mpp.start, ds); dijkstra_host(h, mm, h->mpp.target, dt);
+  CK(hipMalloc(&h->d_ds, sizeof(double) * (size_t)h->RC)); CK(hipMalloc(&h->d_dt, sizeof(double) * (size_t)h->RC));
+  CK(hipMemcpy(h->d_ds, ds.data(), sizeof(double) * (size_t)h->RC, hipMemcpyHostToDevice));
+  CK(hipMemcpy(h->d_dt, dt.data(), sizeof(double) * (size_t)h->RC, hipMemcpyHostToDevice));
+  return 0;
+}
 int pf_mpa_setup(pf_handle* h, const pf_mpa_params* p, const pf_score_params* sp) {
   if (!h) return -2;
   if (!p || !sp || p->start < 0 || p->start >= h->RC || p->target < 0 || p->target >= h->RC) return failmsg(h, "pf_mpa_setup: bad arguments");
@@ -1838,11 +1918,14 @@ int pf_mpa_setup(pf_handle* h, const pf_mpa_params* p, const pf_score_params* sp
     rc = pf_score_batch(h, sp, 1, cap, h->d_init_cells, d_l, h->d_init_stats);
   }
   (void)hipFree(d_s);
+  if (rc == 0) rc = mpa_bounds(h);
   return rc;
 }
 static MpaDev mpa_dev(const pf_handle* h) {
   MpaDev m; m.P = h->mpp.P_const; m.levy_beta = h->mpp.levy_beta; m.sigma = h->mpp.levy_sigma; m.fads = h->mpp.FADs_rate;
   m.N = h->mpp.num_predators; m.start = h->mpp.start; m.target = h->mpp.target;
+  const bool on = g_mpa_prune && h->d_ds && h->d_dt;
+  m.ds = on ? h->d_ds : nullptr; m.dt = on ? h->d_dt : nullptr;
   return m;
 }
 

@@ -338,8 +338,12 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     if (status == 3) break;
     if (hit) { status = 0; break; }
     PF_LDS_ORDER();
+#ifdef PF_TRIPS
+    n_max += 1;                                                 // diagnostic build: trips instead of the open-list high-water mark
+#else
     const int n_open = n_pool + (wn - wp);
     if (n_open > n_max) n_max = n_open;
+#endif
   }
   if (n_max > st.max_open) st.max_open = n_max;
   st.pops += (unsigned long long)steps; st.pushes += push32; st.nbr += nbr32; st.deckey += dk32;

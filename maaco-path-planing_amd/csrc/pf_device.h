@@ -129,6 +129,16 @@ PF_DEV int wave_sum_i(int v) {
   return s;
 }
 
+// sum over the 64 lanes of a double (fixed DPP pattern: deterministic, but NOT the reference's left-to-right order --
+// use only where a tolerance is applied); result uniform
+PF_DEV double wave_sum_d(double v) {
+  v += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x111, 0xF, 0xF, true), __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x111, 0xF, 0xF, true));
+  v += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x112, 0xF, 0xF, true), __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x112, 0xF, 0xF, true));
+  v += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x114, 0xF, 0xF, true), __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x114, 0xF, 0xF, true));
+  v += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x118, 0xF, 0xF, true), __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x118, 0xF, 0xF, true));
+  return (bcast_d(v, 15) + bcast_d(v, 31)) + (bcast_d(v, 47) + bcast_d(v, 63));   // lane 15 of each row = the row's sum
+}
+
 // ---------------------------------------------------------------------------
 // keyed counter RNG (twin of pathfit/rng.py AgentRandom) + CPython derivations
 // ---------------------------------------------------------------------------

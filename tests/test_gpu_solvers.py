@@ -45,6 +45,30 @@ def test_mpa_main_params_with_levy_phases():
     assert m.convergence_curve_data == ref.curve
 
 
+@pytest.mark.parametrize("fused", [True, False])
+def test_mpa_bound_pruning_changes_nothing(fused):
+    """The exact length-bound pruning of rebuilds must leave every predator, every iteration, every
+    phase exactly as without it -- and must actually fire on a 256 x 256 map."""
+    import pathfit
+    g, s, t = gio.grid("g256")
+    kw = dict(FADs_rate=0.2, P_const=0.5, levy_beta=2.0, turn_penalty_factor=0.1, safety_penalty_factor=0.8,
+              min_safe_distance=1.8, diagonal_obstacle_penalty=100.0)
+    runs = []
+    for prune in (1, 0):
+        m = pathfit.MPA(g, 96, 9, seed=11, fused=fused, **kw)      # 3 iterations in each phase
+        m.engine.set_option("mpa_prune", prune)
+        pruned = 0
+        for it in range(1, 10):
+            m.step(it)
+            pruned += m.engine.counters()["pruned_rebuilds"]
+        pop = m.population
+        runs.append(([list(p["path"].cells) for p in pop], [p["fitness"] for p in pop], list(m.convergence_curve_data), pruned))
+        m.engine.set_option("mpa_prune", 1)
+        m.engine.close()
+    assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1] and runs[0][2] == runs[1][2]
+    assert runs[0][3] > 0 and runs[1][3] == 0
+
+
 @pytest.mark.parametrize("beta", [7.0, 2.0])
 def test_maaco_solve_matches_oracle_loop(beta):
     import pathfit, pf_oracle as po, pf_loops
