@@ -13,7 +13,7 @@ every rank owns 4096 predators (weak scaling); the only exchange is the
 fitness all_gather + elite broadcast per iteration (pathfit/dist.py).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`
-for the dominant kernel (k_mpa_sweep / k_maaco_walk / k_decode_batch; HIP-event
+for the dominant kernel (k_mpa_sweep / k_maaco_walk8 / k_decode_batch; HIP-event
 timed inside the library on its own stream) and `cpu_baseline` (the CPU oracle
 port, bounded sample, 1 core).
 """
@@ -114,7 +114,9 @@ def main():
             def timed_iter(*args, **kw):
                 nonlocal kern_ms, kern_bytes, launches
                 orig(*args, **kw)
-                kern_ms += e.last_kernel_ms(); kern_bytes += astar_bytes(e.counters()); launches += 1
+                c = e.counters()
+                kern_ms += e.last_kernel_ms(); kern_bytes += astar_bytes(c); launches += 1
+                cfg["rebuilds_proven_rejected_and_skipped"] = cfg.get("rebuilds_proven_rejected_and_skipped", 0) + int(c["pruned_rebuilds"])
             e.mpa_iter = timed_iter
             try:
                 sm.step(it)
@@ -126,7 +128,7 @@ def main():
         per_gpu = per_gpu or 16384
         total = per_gpu * world
         sm = ShardedMAACO(comm, lambda: pathfit.MAACO(grid, total, 100, engine=eng, seed=a.seed, **MAACO_MAIN), total)
-        dominant = "k_maaco_walk"
+        dominant = "k_maaco_walk8"          # 16384 ants/GPU >= the 8-ants-per-wavefront threshold
         it = 0
 
         def step():
@@ -180,6 +182,7 @@ def main():
     for _ in range(W):
         step()
     kern_ms, kern_bytes, launches = 0.0, 0.0, 0
+    cfg.pop("rebuilds_proven_rejected_and_skipped", None)
     sync_all()
     t0 = time.perf_counter()
     for _ in range(K):
