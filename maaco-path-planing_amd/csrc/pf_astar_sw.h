@@ -203,14 +203,15 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     // earlier head was the target: exactly the pops, in order, that the sequential loop would make.  A head that
     // does not qualify simply stays in the window.  (CPU simulation of this rule on G512: ~3 pops per trip.)
     const int nh = wn - wp < 4 ? wn - wp : 4;
-    double hf[4], hg[4]; int hc[4];
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      const int l = wp + h < 64 ? wp + h : 63;
-      hf[h] = bcast_d(wf, l); hg[h] = bcast_d(wg, l); hc[h] = bcast_i(wc, l);
-    }
-    const double pg = grp == 0 ? hg[0] : (grp == 1 ? hg[1] : (grp == 2 ? hg[2] : hg[3]));
-    const int prc = grp == 0 ? hc[0] : (grp == 1 ? hc[1] : (grp == 2 ? hc[2] : hc[3]));
+    const int hsrc = wp + grp < 64 ? wp + grp : 63;            // my row's head lives in this window lane
+    const double pg = bperm_d(hsrc, wg);
+    const int prc = bperm_i(hsrc, wc);
+    // f of heads 1..3 (uniform) for the "did an earlier row push below this head" test
+    const unsigned long long hfb1 = dbits(bcast_d(wf, wp + 1 < 64 ? wp + 1 : 63)), hfb2 = dbits(bcast_d(wf, wp + 2 < 64 ? wp + 2 : 63)),
+                             hfb3 = dbits(bcast_d(wf, wp + 3 < 64 ? wp + 3 : 63));
+    // lanes 0..15 look at the head pair (e, h) = (lane >> 2, lane & 3): too close to be independent?
+    const int pe = (lane >> 2) & 3, ph = lane & 3;
+    const int rce = bperm_i(wp + pe < 64 ? wp + pe : 63, wc), rch = bperm_i(wp + ph < 64 ? wp + ph : 63, wc);
     const bool have = grp < nh && sub < 9;
     const int pr = prc >> 16, pc = prc & 0xFFFF;
     const int cur = pr * C + pc;
@@ -246,29 +247,29 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     const double fnew = tent + hn;                             // astar.py:90 / MPA.py:140
     const int nrc = (nr << 16) | nc;
     // ---- which heads take effect ----
-    unsigned viol = 0;                                          // bit h: an earlier row pushes a key below head h
-#pragma unroll
-    for (int h = 1; h < 4; ++h)
-      if (__ballot(push0 && grp < h && key_lt(fnew, tent, nrc, hf[h], hg[h], hc[h]))) viol |= 1u << h;
+    unsigned viol = 0;                                          // bit h: an earlier row pushes a key at or below head h's f
+    {
+      const unsigned long long fb = dbits(fnew);                // non-negative doubles order like their bit patterns
+      if (__ballot(push0 && grp < 1 && fb <= hfb1)) viol |= 2u;
+      if (__ballot(push0 && grp < 2 && fb <= hfb2)) viol |= 4u;
+      if (__ballot(push0 && grp < 3 && fb <= hfb3)) viol |= 8u;
+    }
+    const int dr_ = (rce >> 16) - (rch >> 16), dc_ = (rce & 0xFFFF) - (rch & 0xFFFF);
+    const unsigned nearm = (unsigned)__ballot(lane < 16 && pe < ph && (unsigned)(dr_ + 2) <= 4u && (unsigned)(dc_ + 2) <= 4u);   // bit 4e+h
+    const unsigned tgtm = (unsigned)__ballot(lane < 4 && rch == trc);      // bit h: head h is the target
+    const unsigned stale4 = (unsigned)((stm >> 8) & 1ull) | (unsigned)((stm >> 23) & 2ull) | (unsigned)((stm >> 38) & 4ull) | (unsigned)((stm >> 53) & 8ull);
     unsigned E = 0;                                             // heads whose relaxation takes effect
     int consumed = 0;
     bool hit = false;
     {
-      unsigned seen = 0;                                        // earlier heads that were real pops
+      unsigned seen = 0;                                        // bit 4e: earlier head e was a real pop
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
         if (h >= nh) break;
-        if ((stm >> (16 * h + 8)) & 1ull) { consumed += 1; continue; }
-        bool okh = steps < max_steps && !((viol >> h) & 1u);
-#pragma unroll
-        for (int e = 0; e < h; ++e)
-          if ((seen >> e) & 1u) {
-            const int dr_ = (hc[e] >> 16) - (hc[h] >> 16), dc_ = (hc[e] & 0xFFFF) - (hc[h] & 0xFFFF);
-            if ((unsigned)(dr_ + 2) <= 4u && (unsigned)(dc_ + 2) <= 4u) okh = false;
-          }
-        if (!okh) break;
-        consumed += 1; steps += 1; seen |= 1u << h;
-        if (hc[h] == trc) { hit = true; break; }                // astar.py:64 / MPA.py:123: nothing is relaxed
+        if ((stale4 >> h) & 1u) { consumed += 1; continue; }
+        if (steps >= max_steps || ((viol >> h) & 1u) || (nearm & (seen << h))) break;
+        consumed += 1; steps += 1; seen |= 1u << (4 * h);
+        if ((tgtm >> h) & 1u) { hit = true; break; }            // astar.py:64 / MPA.py:123: nothing is relaxed
         E |= 1u << h;
       }
     }
