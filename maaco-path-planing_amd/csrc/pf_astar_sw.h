@@ -109,6 +109,13 @@ PF_DEV void take_smallest64(const SwPool& P, int bi, int c0, double& wf, double&
   if (lane == 0) P.cnt[bi] = wr;
 }
 
+#ifdef PF_STAMPS
+#define SW_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+#define SW_ACC(i, a, b) sw_acc[i] += (b) - (a);
+#else
+#define SW_T(var)
+#define SW_ACC(i, a, b)
+#endif
 template <int VARIANT>
 __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& O, uint32_t tag, uint32_t avm, int start, int target,
                                            int tr, int tc, int max_steps, double h0, int src, AStat& st, int lane) {
@@ -132,15 +139,20 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
   unsigned nbr32 = 0, push32 = 1, dk32 = 0;
   int n_max = 1;
 
-  // per-lane constants: in every 16-lane row, lanes 0..7 relax move `sub`, lane 8 reads the popped cell itself
-  const int grp = lane >> 4, sub = lane & 15;
+  // per-lane constants: seven groups of nine lanes; in a group, lanes 0..7 relax move `sub`, lane 8 reads the
+  // popped cell itself (lane 63 is idle)
+  const int grp = (lane * 57) >> 9, sub = lane - 9 * grp;
   const int d = sub & 7;
   const int ddr = move_dr(d), ddc = move_dc(d);
   const int doff = sub < 8 ? ddr * C + ddc : 0;
   const double cost = d < 4 ? 1.0 : PF_SQRT2;
   const int trc = (tr << 16) | tc;
 
+#ifdef PF_STAMPS
+  unsigned long long sw_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   for (;;) {
+    SW_T(t0)
     if (wp == wn) {
       // ---- refill: the front bucket if it holds anything, else the next non-empty buckets (<= 64 entries); sorted ----
       if (n_pool == 0) { status = 1; break; }
@@ -196,23 +208,32 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
       }
       PF_LDS_ORDER();
     }
-    // ---- pop: up to four heads of the window at once, one per 16-lane row ----
-    // The window is sorted, so the next pops are known.  Row h relaxes head h in registers; head h takes effect
-    // (and counts as a pop) iff every earlier head did, no earlier head pushed a key below head h's, head h lies
-    // more than 2 cells (Chebyshev) from every earlier head -- so its loads saw none of their writes -- and no
-    // earlier head was the target: exactly the pops, in order, that the sequential loop would make.  A head that
-    // does not qualify simply stays in the window.  (CPU simulation of this rule on G512: ~3 pops per trip.)
-    const int nh = wn - wp < 4 ? wn - wp : 4;
-    const int hsrc = wp + grp < 64 ? wp + grp : 63;            // my row's head lives in this window lane
-    const double pg = bperm_d(hsrc, wg);
-    const int prc = bperm_i(hsrc, wc);
-    // f of heads 1..3 (uniform) for the "did an earlier row push below this head" test
-    const unsigned long long hfb1 = dbits(bcast_d(wf, wp + 1 < 64 ? wp + 1 : 63)), hfb2 = dbits(bcast_d(wf, wp + 2 < 64 ? wp + 2 : 63)),
-                             hfb3 = dbits(bcast_d(wf, wp + 3 < 64 ? wp + 3 : 63));
-    // lanes 0..15 look at the head pair (e, h) = (lane >> 2, lane & 3): too close to be independent?
-    const int pe = (lane >> 2) & 3, ph = lane & 3;
+    SW_T(t1)
+    // ---- pop: up to seven heads of the window at once, nine lanes each ----
+    // The window is sorted, so the next pops are known.  Lane group h relaxes head h in registers; head h takes
+    // effect (and counts as a pop) iff every earlier head did, no earlier head pushed a key at or below head h's f,
+    // head h lies more than 2 cells (Chebyshev) from every earlier head -- so its loads saw none of their writes --
+    // and no earlier head was the target: exactly the pops, in order, that the sequential loop would make.  A head
+    // that does not qualify simply stays in the window.
+    constexpr int NH = 7;
+    const int nh = wn - wp < NH ? wn - wp : NH;
+    const int hsrc = wp + grp < 64 ? wp + grp : 63;            // my group's head lives in this window lane
+    const double pg = bperm_d(hsrc, wg);                       // needed only once the loads are back
+    // the head cells feed the load addresses: v_readlane + select has none of the LDS crossbar's latency
+    int prc = bcast_i(wc, wp);
+    unsigned long long hfb[NH];                                 // f of heads 1.. (uniform) for the push test below
+    hfb[0] = 0;
+#pragma unroll
+    for (int h = 1; h < NH; ++h) {
+      const int l = wp + h < 64 ? wp + h : 63;
+      const int c_ = bcast_i(wc, l);
+      prc = grp == h ? c_ : prc;
+      hfb[h] = dbits(bcast_d(wf, l));
+    }
+    // lanes 0..48 look at the head pair (e, h) = (lane / 7, lane % 7): too close to be independent?
+    const int pe = (lane * 37) >> 8, ph = lane - 7 * pe;
     const int rce = bperm_i(wp + pe < 64 ? wp + pe : 63, wc), rch = bperm_i(wp + ph < 64 ? wp + ph : 63, wc);
-    const bool have = grp < nh && sub < 9;
+    const bool have = grp < nh;                                 // (lane 63 is group 7: never)
     const int pr = prc >> 16, pc = prc & 0xFFFF;
     const int cur = pr * C + pc;
     // ---- one batch of loads: 8 neighbour records, the cell's own record, its move mask (and g, MPA variant) ----
@@ -226,13 +247,18 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     const long hdr = nr - tr, hdc = nc - tc;
     double hn = __builtin_sqrt((double)(hdr * hdr + hdc * hdc));   // astar.py:90 / MPA.py:140
     asm volatile("" : "+v"(hn));                               // computed in the shadow of the loads
+    SW_T(t2)
     // ---- relax the 8 neighbours of each head in registers ----
-    const uint32_t cur_meta = rn.meta;                          // meaningful in the self lanes (sub == 8)
+    const uint32_t cur_meta = rn.meta;
+#ifdef PF_STAMPS
+    { unsigned tmp_ = cur_meta; asm volatile("" : "+v"(tmp_)); }   // the loads have arrived
+#endif
+    SW_T(t3)                          // meaningful in the self lanes (sub == 8)
     // VARIANT 0: an entry superseded by a decrease-key (astar.py:96-100 rewrites it in place) is not a pop of the
     // reference: its head is consumed without effect and without being counted
     const bool self_stale = VARIANT == 0 && sub == 8 && ((cur_meta & PF_M_CLOSED) || rn.g != pg);
     const unsigned long long stm = __ballot(have && self_stale);
-    const bool my_stale = (stm >> ((lane & 48) + 8)) & 1ull;
+    const bool my_stale = (stm >> (9 * grp + 8 < 64 ? 9 * grp + 8 : 63)) & 1ull;
     const double base_g = VARIANT == 0 ? pg : cur_g;           // astar.py:85 popped g / MPA.py:135 g_score[current]
     const bool rvalid = (rn.tagmm >> PF_TAG_SHIFT) == tag;
     const bool avoided = (rn.meta >> PF_AVOID_SHIFT) == avm;
@@ -247,32 +273,32 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     const double fnew = tent + hn;                             // astar.py:90 / MPA.py:140
     const int nrc = (nr << 16) | nc;
     // ---- which heads take effect ----
-    unsigned viol = 0;                                          // bit h: an earlier row pushes a key at or below head h's f
+    unsigned viol = 0;                                          // bit h: an earlier group pushes a key at or below head h's f
     {
       const unsigned long long fb = dbits(fnew);                // non-negative doubles order like their bit patterns
-      if (__ballot(push0 && grp < 1 && fb <= hfb1)) viol |= 2u;
-      if (__ballot(push0 && grp < 2 && fb <= hfb2)) viol |= 4u;
-      if (__ballot(push0 && grp < 3 && fb <= hfb3)) viol |= 8u;
+#pragma unroll
+      for (int h = 1; h < NH; ++h)
+        if (__ballot(push0 && grp < h && fb <= hfb[h])) viol |= 1u << h;
     }
     const int dr_ = (rce >> 16) - (rch >> 16), dc_ = (rce & 0xFFFF) - (rch & 0xFFFF);
-    const unsigned nearm = (unsigned)__ballot(lane < 16 && pe < ph && (unsigned)(dr_ + 2) <= 4u && (unsigned)(dc_ + 2) <= 4u);   // bit 4e+h
-    const unsigned tgtm = (unsigned)__ballot(lane < 4 && rch == trc);      // bit h: head h is the target
-    const unsigned stale4 = (unsigned)((stm >> 8) & 1ull) | (unsigned)((stm >> 23) & 2ull) | (unsigned)((stm >> 38) & 4ull) | (unsigned)((stm >> 53) & 8ull);
+    const unsigned long long nearm = __ballot(lane < NH * NH && pe < ph && (unsigned)(dr_ + 2) <= 4u && (unsigned)(dc_ + 2) <= 4u);   // bit 7e+h
+    const unsigned tgtm = (unsigned)__ballot(lane < NH && rch == trc);      // bit h: head h is the target
     unsigned E = 0;                                             // heads whose relaxation takes effect
     int consumed = 0;
     bool hit = false;
     {
-      unsigned seen = 0;                                        // bit 4e: earlier head e was a real pop
+      unsigned long long seen = 0;                              // bit 7e: earlier head e was a real pop
 #pragma unroll
-      for (int h = 0; h < 4; ++h) {
+      for (int h = 0; h < NH; ++h) {
         if (h >= nh) break;
-        if ((stale4 >> h) & 1u) { consumed += 1; continue; }
+        if ((stm >> (9 * h + 8)) & 1ull) { consumed += 1; continue; }
         if (steps >= max_steps || ((viol >> h) & 1u) || (nearm & (seen << h))) break;
-        consumed += 1; steps += 1; seen |= 1u << (4 * h);
+        consumed += 1; steps += 1; seen |= 1ull << (7 * h);
         if ((tgtm >> h) & 1u) { hit = true; break; }            // astar.py:64 / MPA.py:123: nothing is relaxed
         E |= 1u << h;
       }
     }
+    SW_T(t4)
     if (consumed == 0) { status = 2; break; }                   // only the step cap can stop head 0
     wp += consumed;
     const bool eff = (E >> grp) & 1u;
@@ -287,19 +313,19 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
       rec[nidx] = wv;
     }
     // ---- pushes: below the limit -> into the window, else -> pool bucket ----
+    // The slot index of a pool append comes from an LDS atomic; it is requested here and used after the window
+    // inserts, so its latency is covered by them.
     const bool tow = push && key_lt(fnew, tent, nrc, lf, lg, lc);
-    bool bad = false;
-    if (push && !tow) {
-      const int ba = (int)(fnew * PF_SW_Q);
-      const int b = ba < bcur ? NBK : (ba & (NBK - 1));         // below every regular bucket: the front bucket
-      const int at = __hip_atomic_fetch_add(&P.cnt[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (at < CAP && ba - bcur < NBK) { P.bf[b * CAP + at] = fnew; P.bg[b * CAP + at] = tent; P.bc[b * CAP + at] = nrc; }
-      else bad = true;
-    }
+    const bool top = push && !tow;
+    const int pba = (int)(fnew * PF_SW_Q);
+    const int pb = pba < bcur ? NBK : (pba & (NBK - 1));       // below every regular bucket: the front bucket
+    int pat = 0;
+    if (top) pat = __hip_atomic_fetch_add(&P.cnt[pb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const int bcur_at_push = bcur;
     const unsigned long long pm = __ballot(push), im0 = __ballot(tow);
-    if (__ballot(bad)) { status = 3; break; }                  // a bucket is full (or out of the circular range)
     n_pool += __builtin_popcountll(pm & ~im0);
     push32 += (unsigned)__builtin_popcountll(VARIANT == 0 ? __ballot(push && !in_open) : pm);   // heappush calls of the reference
+    SW_T(t5)
     unsigned long long im = im0;
     while (im) {
       const int l = __builtin_ctzll(im); im &= im - 1;
@@ -337,8 +363,19 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
       }
     }
     if (status == 3) break;
+    SW_T(t6)
+    {
+      const bool bad = top && !(pat < CAP && pba - bcur_at_push < NBK);
+      if (top && !bad) { P.bf[pb * CAP + pat] = fnew; P.bg[pb * CAP + pat] = tent; P.bc[pb * CAP + pat] = nrc; }
+      if (__ballot(bad)) { status = 3; break; }                // a bucket is full (or out of the circular range)
+    }
     if (hit) { status = 0; break; }
     PF_LDS_ORDER();
+    SW_T(t7)
+    SW_ACC(0, t0, t1) SW_ACC(1, t1, t2) SW_ACC(2, t2, t3) SW_ACC(3, t3, t4) SW_ACC(4, t4, t5) SW_ACC(5, t5, t6) SW_ACC(6, t6, t7)
+#ifdef PF_STAMPS
+    sw_acc[7] += 1;
+#endif
 #ifdef PF_TRIPS
     n_max += 1;                                                 // diagnostic build: trips instead of the open-list high-water mark
 #else
@@ -346,6 +383,9 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     if (n_open > n_max) n_max = n_open;
 #endif
   }
+#ifdef PF_STAMPS
+  if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_stamps[i], sw_acc[i]);
+#endif
   if (n_max > st.max_open) st.max_open = n_max;
   st.pops += (unsigned long long)steps; st.pushes += push32; st.nbr += nbr32; st.deckey += dk32;
   return status;

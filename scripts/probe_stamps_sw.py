@@ -1,0 +1,26 @@
+"""Diagnostic (-DPF_STAMPS build): shader-clock time per section of a trip of the sorted-window loop, lone wave."""
+import sys, os, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "maaco-path-planing_amd"), os.path.join(ROOT, "tests")]
+import numpy as np
+from pathfit import _lib
+_lib._SO = os.path.join(ROOT, "maaco-path-planing_amd", "lib", "libpathfit_stamps.so")
+import golden_io as gio
+from pathfit.engine import Engine
+g = gio.upsample(gio.grid("g256")[0], 2)
+e = Engine(g)
+e.L.pf_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+names = ["refill", "heads+address+load issue", "wait for the loads", "relax+viol+chain", "meta/record stores+pool atomic", "window inserts", "pool stores+tail"]
+for n in (1, 1792):
+    rnd = np.random.default_rng(1)
+    free = np.flatnonzero(g.reshape(-1) != 1)
+    starts = rnd.choice(free, n).astype(np.int32); targets = rnd.choice(free, n).astype(np.int32)
+    starts[0], targets[0] = 0, g.size - 1
+    for v in (1, 0):
+        out = np.zeros(16, np.uint64)
+        e.L.pf_debug_stamps(e.h, out.ctypes.data, 1)
+        paths, st, cnt = e.astar_host(v, starts, targets, None, path_cap=8192, want_counters=True)
+        e.L.pf_debug_stamps(e.h, out.ctypes.data, 1)
+        trips = int(out[7]); pops = int(cnt[:, 0].sum())
+        print(f"n={n} v{v}: {e.last_kernel_ms():.1f} ms pops {pops} trips {trips} pops/trip {pops / trips:.2f} clocks/trip {out[:7].sum() / trips:.0f}: " +
+              "; ".join(f"{names[i]} {out[i] / trips:.0f}" for i in range(7)))
