@@ -116,6 +116,19 @@ PF_DEV void take_smallest64(const SwPool& P, int bi, int c0, double& wf, double&
 #define SW_T(var)
 #define SW_ACC(i, a, b)
 #endif
+// VARIANT 0, at refill: an entry whose cell is closed or whose g is no longer the record's g was superseded by a
+// decrease-key (astar.py:96-100 rewrites it in place) and can never be a pop of the reference -- g only falls and a
+// closed cell stays closed, so it is dropped here instead of taking a head slot and a batch of loads later.
+// Marks dropped lanes f = +inf (they sort to the end); returns the number of live entries.
+PF_DEV int drop_superseded(const Rec* rec, int C, double& wf, double wg, int wc) {
+  bool live = wf != PF_INF;
+  if (live) {
+    const Rec r = rec[(wc >> 16) * C + (wc & 0xFFFF)];
+    if ((r.meta & PF_M_CLOSED) || r.g != wg) { wf = PF_INF; live = false; }
+  }
+  return __builtin_popcountll(__ballot(live));
+}
+
 template <int VARIANT>
 __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& O, uint32_t tag, uint32_t avm, int start, int target,
                                            int tr, int tc, int max_steps, double h0, int src, AStat& st, int lane) {
@@ -149,7 +162,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
   const int trc = (tr << 16) | tc;
 
 #ifdef PF_STAMPS
-  unsigned long long sw_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long sw_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sw_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   for (;;) {
     SW_T(t0)
@@ -162,11 +175,19 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
         if (cF <= 64) {
           if (lane < cF) { wf = P.bf[NBK * CAP + lane]; wg = P.bg[NBK * CAP + lane]; wc = P.bc[NBK * CAP + lane]; }
           if (lane == 0) P.cnt[NBK] = 0;
+          int live = cF;
+          if (VARIANT == 0) live = drop_superseded(rec, C, wf, wg, wc);
           int n2 = 1; while (n2 < cF) n2 <<= 1;
           sort_lanes(wf, wg, wc, lane, n2);
-          wp = 0; wn = cF; n_pool -= cF;
+#ifdef PF_STAMPS
+          sw_cnt[0] += 1; sw_cnt[1] += cF;
+#endif
+          wp = 0; wn = live; n_pool -= cF;
           lf = (double)bcur * (1.0 / PF_SW_Q); lg = -PF_INF; lc = 0;
         } else {
+#ifdef PF_STAMPS
+          sw_cnt[2] += 1; sw_cnt[3] += cF;
+#endif
           take_smallest64(P, NBK, cF, wf, wg, wc, lane);
           wp = 0; wn = 64; n_pool -= 64;
           lf = bcast_d(wf, 63); lg = bcast_d(wg, 63); lc = bcast_i(wc, 63);        // the rest of the front bucket is above this key
@@ -194,12 +215,20 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
               total += ck;
             }
           }
+          int live = total;
+          if (VARIANT == 0) live = drop_superseded(rec, C, wf, wg, wc);
           int n2 = 1; while (n2 < total) n2 <<= 1;
           sort_lanes(wf, wg, wc, lane, n2);
-          wp = 0; wn = total; n_pool -= total;
+#ifdef PF_STAMPS
+          sw_cnt[6] += 1; sw_cnt[7] += total;
+#endif
+          wp = 0; wn = live; n_pool -= total;
           bcur = b0 + k;
           lf = (double)bcur * (1.0 / PF_SW_Q); lg = -PF_INF; lc = 0;
         } else {
+#ifdef PF_STAMPS
+          sw_cnt[4] += 1; sw_cnt[5] += c0;
+#endif
           take_smallest64(P, b0 & (NBK - 1), c0, wf, wg, wc, lane);
           wp = 0; wn = 64; n_pool -= 64;
           bcur = b0;
@@ -207,6 +236,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
         }
       }
       PF_LDS_ORDER();
+      if (wn == 0) continue;                                    // everything taken was superseded: take the next buckets
     }
     SW_T(t1)
     // ---- pop: up to seven heads of the window at once, nine lanes each ----
@@ -384,7 +414,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
 #endif
   }
 #ifdef PF_STAMPS
-  if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_stamps[i], sw_acc[i]);
+  if (lane == 0) for (int i = 0; i < 8; ++i) { atomicAdd(&g_stamps[i], sw_acc[i]); atomicAdd(&g_stamps[8 + i], sw_cnt[i]); }
 #endif
   if (n_max > st.max_open) st.max_open = n_max;
   st.pops += (unsigned long long)steps; st.pushes += push32; st.nbr += nbr32; st.deckey += dk32;

@@ -11,7 +11,7 @@ g = gio.upsample(gio.grid("g256")[0], 2)
 e = Engine(g)
 e.L.pf_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 names = ["refill", "heads+address+load issue", "wait for the loads", "relax+viol+chain", "meta/record stores+pool atomic", "window inserts", "pool stores+tail"]
-for n in (1, 1792):
+for n in (1,):
     rnd = np.random.default_rng(1)
     free = np.flatnonzero(g.reshape(-1) != 1)
     starts = rnd.choice(free, n).astype(np.int32); targets = rnd.choice(free, n).astype(np.int32)
@@ -24,3 +24,6 @@ for n in (1, 1792):
         trips = int(out[7]); pops = int(cnt[:, 0].sum())
         print(f"n={n} v{v}: {e.last_kernel_ms():.1f} ms pops {pops} trips {trips} pops/trip {pops / trips:.2f} clocks/trip {out[:7].sum() / trips:.0f}: " +
               "; ".join(f"{names[i]} {out[i] / trips:.0f}" for i in range(7)))
+        c = out[8:].astype(float)
+        print(f"      refills: front small {int(c[0])} (avg {c[1] / max(c[0], 1):.1f}), front big {int(c[2])} (avg size {c[3] / max(c[2], 1):.1f}), "
+              f"regular {int(c[6])} (avg {c[7] / max(c[6], 1):.1f}), regular big {int(c[4])} (avg size {c[5] / max(c[4], 1):.1f})")
