@@ -73,6 +73,7 @@ typedef struct {
 /* per-launch counters (roofline numerators) */
 typedef struct {
   int64_t pops, pushes, nbr_examined, path_cells, steps, candidates, decrease_keys, overflow_agents;
+  /* candidates: MAACO candidate cells examined; for the A*-based calls, open-list entries that took the spill list */
   int64_t pruned_rebuilds; /* MPA rebuilds skipped because a length bound proved the candidate could not be accepted */
 } pf_counters;
 

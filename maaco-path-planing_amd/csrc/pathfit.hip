@@ -88,6 +88,7 @@ PF_DEV void flush_counters(DevCounters* c, const AStat& st, unsigned long long c
   if (lane == 0) {
     atomicAdd(&c->pops, st.pops); atomicAdd(&c->pushes, st.pushes); atomicAdd(&c->nbr, st.nbr);
     atomicAdd(&c->deckey, st.deckey); atomicAdd(&c->path_cells, cells); atomicAdd(&c->overflow, ovf & 0xFFFFFFFFull);
+    if (st.spills) atomicAdd(&c->candidates, (unsigned long long)st.spills);   // A* kernels: spilled open-list entries
     if (ovf >> 32) atomicAdd(&c->pruned, ovf >> 32);           // MPA items count pruned rebuilds in the upper half
   }
 }
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(64) void k_astar_batch(AstarArgs p) {
         p.counters[4 * a + 2] = st.max_open; p.counters[4 * a + 3] = (long long)st.nbr;
       }
     }
-    tot.pops += st.pops; tot.pushes += st.pushes; tot.nbr += st.nbr; tot.deckey += st.deckey;
+    tot.pops += st.pops; tot.pushes += st.pushes; tot.nbr += st.nbr; tot.deckey += st.deckey; tot.spills += st.spills;
     cells += rc == 0 ? n : 0; ovf += rc == 3;
   }
   slot_store(p.c, s, lane);
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(64) void k_astar_batch16(AstarArgs p) {
           p.counters[4 * a + 2] = st.max_open; p.counters[4 * a + 3] = (long long)st.nbr;
         }
       }
-      tot.pops += st.pops; tot.pushes += st.pushes; tot.nbr += st.nbr; tot.deckey += st.deckey;
+      tot.pops += st.pops; tot.pushes += st.pushes; tot.nbr += st.nbr; tot.deckey += st.deckey; tot.spills += st.spills;
       cells += rc == 0 ? n : 0; ovf += rc == 3;
     }
   }

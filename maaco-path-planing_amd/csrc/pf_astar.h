@@ -62,6 +62,7 @@ struct Slot {
 struct AStat {
   unsigned long long pops, pushes, nbr, deckey;
   int max_open;
+  unsigned spills;   // open-list entries that went through the spill list (full bucket / beyond the circular range)
 };
 // diagnostic build only (-DPF_STAMPS): shader-clock time per section of the pop loop, never in the product .so
 #ifdef PF_STAMPS

@@ -60,23 +60,92 @@ PF_DEV void merge_lanes(double& f, double& g, int& c, int lane) {
   for (int j = 32; j > 0; j >>= 1) cmpx(f, g, c, lane, j, true);
 }
 
+#define PF_SW_SPILL 16384
 struct SwPool {
   int* cnt;      // LDS [NBK + 1] entries per bucket; bucket NBK is the FRONT bucket: entries above the window's limit
                  // but below every regular bucket (window evictions, late low pushes of MPA._a_star's stale pops)
   double* bf;    // HBM [(NBK + 1)*CAP]
   double* bg;
   int* bc;
+  double* sf;    // HBM [PF_SW_SPILL] spill list: entries whose bucket was full (a plateau of near-equal f on open maps)
+  double* sg;    //   or beyond the circular range; every refill offers them to the window / their bucket again
+  int* sc;
 };
-// append one entry (uniform values): to the front bucket when it sorts before every regular bucket
-// (f below the boundary of bucket bcur), else to its f bucket; returns false on a full bucket
-PF_DEV bool pool_put1(const SwPool& P, double f, double g, int c, int bcur, int lane) {
+// append one entry (uniform values): to the front bucket when it sorts before every regular bucket (f below the
+// boundary of bucket bcur), else to its f bucket, else (bucket full / out of range) to the spill list;
+// false only when the spill list is full too
+PF_DEV bool pool_put1(const SwPool& P, double f, double g, int c, int bcur, int& n_spill, int lane) {
   const int ba = (int)(f * PF_SW_Q);
   const int b = ba < bcur ? PF_SW_NBK : (ba & (PF_SW_NBK - 1));
   PF_LDS_ORDER();
   const int n = P.cnt[b];
-  if (n >= PF_SW_CAP || ba - bcur >= PF_SW_NBK) return false;
+  if (n >= PF_SW_CAP || ba - bcur >= PF_SW_NBK) {
+    if (n_spill >= PF_SW_SPILL) return false;
+    if (lane == 0) { P.sf[n_spill] = f; P.sg[n_spill] = g; P.sc[n_spill] = c; }
+    n_spill += 1;
+    return true;
+  }
   if (lane == 0) { P.bf[b * PF_SW_CAP + n] = f; P.bg[b * PF_SW_CAP + n] = g; P.bc[b * PF_SW_CAP + n] = c; P.cnt[b] = n + 1; }
   PF_LDS_ORDER();
+  return true;
+}
+// the window (one entry per lane, sorted in [wp, wn)) and the bookkeeping that goes with it
+struct SwWin {
+  double wf, wg; int wc;        // this lane's entry
+  int wp, wn;                   // live lanes
+  double lf, lg; int lc;        // keys below this limit belong to the window; every pool entry is at or above it
+  int bcur;                     // first regular bucket (absolute index) not yet taken
+  int n_pool, n_spill;          // entries outside the window (spilled ones included) / in the spill list
+};
+// insert a key that is below the limit; a full window returns its largest entry to the pool, which becomes the limit
+PF_DEV bool win_insert(const SwPool& P, SwWin& W, double kf, double kg, int kc, int lane) {
+  const bool live = lane >= W.wp && lane < W.wn;
+  const int p = W.wp + __builtin_popcountll(__ballot(live && key_lt(W.wf, W.wg, W.wc, kf, kg, kc)));   // first live lane not below the key
+  if (W.wn < 64) {
+    const double sf = wave_up_d(W.wf), sg = wave_up_d(W.wg); const int sc = wave_up_i(W.wc);
+    if (lane > p && lane <= W.wn) { W.wf = sf; W.wg = sg; W.wc = sc; }
+    if (lane == p) { W.wf = kf; W.wg = kg; W.wc = kc; }
+    W.wn += 1;
+  } else if (W.wp > 0) {
+    const double sf = wave_down_d(W.wf), sg = wave_down_d(W.wg); const int sc = wave_down_i(W.wc);
+    if (lane >= W.wp - 1 && lane < p - 1) { W.wf = sf; W.wg = sg; W.wc = sc; }
+    if (lane == p - 1) { W.wf = kf; W.wg = kg; W.wc = kc; }
+    W.wp -= 1;
+  } else {
+    // 64 live entries: the largest key (the new one, or lane 63's) returns to the pool and becomes the limit
+    double ef = kf, eg = kg; int ec = kc;
+    if (p < 64) {
+      ef = bcast_d(W.wf, 63); eg = bcast_d(W.wg, 63); ec = bcast_i(W.wc, 63);
+      const double sf = wave_up_d(W.wf), sg = wave_up_d(W.wg); const int sc = wave_up_i(W.wc);
+      if (lane > p) { W.wf = sf; W.wg = sg; W.wc = sc; }
+      if (lane == p) { W.wf = kf; W.wg = kg; W.wc = kc; }
+    }
+    if (!pool_put1(P, ef, eg, ec, W.bcur, W.n_spill, lane)) return false;
+    W.n_pool += 1;
+    W.lf = ef; W.lg = eg; W.lc = ec;
+  }
+  return true;
+}
+// key below the limit -> window, else -> pool (front bucket / f bucket / spill list)
+PF_DEV bool sw_add(const SwPool& P, SwWin& W, double kf, double kg, int kc, int lane) {
+  if (key_lt(kf, kg, kc, W.lf, W.lg, W.lc)) return win_insert(P, W, kf, kg, kc, lane);
+  if (!pool_put1(P, kf, kg, kc, W.bcur, W.n_spill, lane)) return false;
+  W.n_pool += 1;
+  return true;
+}
+// After a refill: offer every spilled entry to the window (key below the new limit) or to its bucket (room again,
+// or inside the circular range now); what still does not fit stays spilled.
+PF_DEV bool respill(const SwPool& P, SwWin& W, int lane) {
+  const int n = W.n_spill;
+  W.n_spill = 0; W.n_pool -= n;
+  for (int base = 0; base < n; base += 64) {
+    const int m = n - base < 64 ? n - base : 64;
+    double ef = 0.0, eg = 0.0; int ec = 0;
+    if (lane < m) { ef = P.sf[base + lane]; eg = P.sg[base + lane]; ec = P.sc[base + lane]; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       // read this chunk before re-spilled entries overwrite it
+    for (int k = 0; k < m; ++k)
+      if (!sw_add(P, W, bcast_d(ef, k), bcast_d(eg, k), bcast_i(ec, k), lane)) return false;
+  }
   return true;
 }
 // A bucket larger than the window: leave its 64 smallest entries sorted in the lanes, compact the rest in place.
@@ -136,18 +205,17 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
   const int C = G.C, RC = G.R * G.C;
   SwPool P;
   P.cnt = (int*)O.lf; P.bf = O.of; P.bg = P.bf + (NBK + 1) * CAP; P.bc = (int*)(P.bg + (NBK + 1) * CAP);
+  P.sf = (double*)(P.bc + (NBK + 1) * CAP); P.sg = P.sf + PF_SW_SPILL; P.sc = (int*)(P.sg + PF_SW_SPILL);
   for (int k = lane; k <= NBK; k += 64) P.cnt[k] = 0;
   PF_LDS_ORDER();
 
-  // the window: lane k in [wp, wn) holds the (k - wp)-th next pop
-  double wf = PF_INF, wg = 0.0;
-  int wc = 0;
-  if (lane == 0) { wf = h0; wg = 0.0; wc = src; }
-  int wp = 0, wn = 1;
-  int bcur = (int)(h0 * PF_SW_Q) + 1;                 // first bucket (absolute index) not yet taken into the window
-  double lf = (double)bcur * (1.0 / PF_SW_Q), lg = -PF_INF;   // keys below (lf, lg, lc) belong to the window
-  int lc = 0;
-  int n_pool = 0;                                      // entries in the pool
+  SwWin W;                                                   // the window: lane k in [wp, wn) holds the (k - wp)-th next pop
+  W.wf = PF_INF; W.wg = 0.0; W.wc = 0;
+  if (lane == 0) { W.wf = h0; W.wg = 0.0; W.wc = src; }
+  W.wp = 0; W.wn = 1;
+  W.bcur = (int)(h0 * PF_SW_Q) + 1;                           // first bucket (absolute index) not yet taken into the window
+  W.lf = (double)W.bcur * (1.0 / PF_SW_Q); W.lg = -PF_INF; W.lc = 0;   // keys below (lf, lg, lc) belong to the window
+  W.n_pool = 0; W.n_spill = 0;
   int steps = 0, status = 1;
   unsigned nbr32 = 0, push32 = 1, dk32 = 0;
   int n_max = 1;
@@ -166,40 +234,43 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
 #endif
   for (;;) {
     SW_T(t0)
-    if (wp == wn) {
+    if (W.wp == W.wn) {
       // ---- refill: the front bucket if it holds anything, else the next non-empty buckets (<= 64 entries); sorted ----
-      if (n_pool == 0) { status = 1; break; }
+      if (W.n_pool == 0) { status = 1; break; }
       const int cF = P.cnt[NBK];
-      wf = PF_INF; wg = 0.0; wc = 0;
+      W.wf = PF_INF; W.wg = 0.0; W.wc = 0;
       if (cF > 0) {
         if (cF <= 64) {
-          if (lane < cF) { wf = P.bf[NBK * CAP + lane]; wg = P.bg[NBK * CAP + lane]; wc = P.bc[NBK * CAP + lane]; }
+          if (lane < cF) { W.wf = P.bf[NBK * CAP + lane]; W.wg = P.bg[NBK * CAP + lane]; W.wc = P.bc[NBK * CAP + lane]; }
           if (lane == 0) P.cnt[NBK] = 0;
           int live = cF;
-          if (VARIANT == 0) live = drop_superseded(rec, C, wf, wg, wc);
+          if (VARIANT == 0) live = drop_superseded(rec, C, W.wf, W.wg, W.wc);
           int n2 = 1; while (n2 < cF) n2 <<= 1;
-          sort_lanes(wf, wg, wc, lane, n2);
+          sort_lanes(W.wf, W.wg, W.wc, lane, n2);
 #ifdef PF_STAMPS
           sw_cnt[0] += 1; sw_cnt[1] += cF;
 #endif
-          wp = 0; wn = live; n_pool -= cF;
-          lf = (double)bcur * (1.0 / PF_SW_Q); lg = -PF_INF; lc = 0;
+          W.wp = 0; W.wn = live; W.n_pool -= cF;
+          W.lf = (double)W.bcur * (1.0 / PF_SW_Q); W.lg = -PF_INF; W.lc = 0;
         } else {
 #ifdef PF_STAMPS
           sw_cnt[2] += 1; sw_cnt[3] += cF;
 #endif
-          take_smallest64(P, NBK, cF, wf, wg, wc, lane);
-          wp = 0; wn = 64; n_pool -= 64;
-          lf = bcast_d(wf, 63); lg = bcast_d(wg, 63); lc = bcast_i(wc, 63);        // the rest of the front bucket is above this key
+          take_smallest64(P, NBK, cF, W.wf, W.wg, W.wc, lane);
+          W.wp = 0; W.wn = 64; W.n_pool -= 64;
+          W.lf = bcast_d(W.wf, 63); W.lg = bcast_d(W.wg, 63); W.lc = bcast_i(W.wc, 63);        // the rest of the front bucket is above this key
         }
       } else {
         int b0 = -1;
         for (int base = 0; base < NBK; base += 64) {
-          const int c_ = P.cnt[(bcur + base + lane) & (NBK - 1)];
+          const int c_ = P.cnt[(W.bcur + base + lane) & (NBK - 1)];
           const unsigned long long nz = __ballot(c_ > 0);
-          if (nz) { b0 = bcur + base + __builtin_ctzll(nz); break; }
+          if (nz) { b0 = W.bcur + base + __builtin_ctzll(nz); break; }
         }
-        if (b0 < 0) { status = 3; break; }             // cannot happen (n_pool > 0): never loop silently
+        if (b0 < 0) {                                  // only spilled entries are left (their buckets emptied since)
+          if (W.n_spill == 0 || !respill(P, W, lane)) { status = 3; break; }   // (n_pool > 0 without either: never loop silently)
+          continue;
+        }
         const int cb = P.cnt[(b0 + lane) & (NBK - 1)]; // lane k: size of the k-th bucket from b0 (wraps onto empty ones)
         const int c0 = bcast_i(cb, 0);
         if (c0 <= 64) {
@@ -210,33 +281,34 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
             if (ck > 0) {
               const int bi = (b0 + k) & (NBK - 1);
               const int j = lane - total;
-              if (j >= 0 && j < ck) { wf = P.bf[bi * CAP + j]; wg = P.bg[bi * CAP + j]; wc = P.bc[bi * CAP + j]; }
+              if (j >= 0 && j < ck) { W.wf = P.bf[bi * CAP + j]; W.wg = P.bg[bi * CAP + j]; W.wc = P.bc[bi * CAP + j]; }
               if (lane == 0) P.cnt[bi] = 0;
               total += ck;
             }
           }
           int live = total;
-          if (VARIANT == 0) live = drop_superseded(rec, C, wf, wg, wc);
+          if (VARIANT == 0) live = drop_superseded(rec, C, W.wf, W.wg, W.wc);
           int n2 = 1; while (n2 < total) n2 <<= 1;
-          sort_lanes(wf, wg, wc, lane, n2);
+          sort_lanes(W.wf, W.wg, W.wc, lane, n2);
 #ifdef PF_STAMPS
           sw_cnt[6] += 1; sw_cnt[7] += total;
 #endif
-          wp = 0; wn = live; n_pool -= total;
-          bcur = b0 + k;
-          lf = (double)bcur * (1.0 / PF_SW_Q); lg = -PF_INF; lc = 0;
+          W.wp = 0; W.wn = live; W.n_pool -= total;
+          W.bcur = b0 + k;
+          W.lf = (double)W.bcur * (1.0 / PF_SW_Q); W.lg = -PF_INF; W.lc = 0;
         } else {
 #ifdef PF_STAMPS
           sw_cnt[4] += 1; sw_cnt[5] += c0;
 #endif
-          take_smallest64(P, b0 & (NBK - 1), c0, wf, wg, wc, lane);
-          wp = 0; wn = 64; n_pool -= 64;
-          bcur = b0;
-          lf = bcast_d(wf, 63); lg = bcast_d(wg, 63); lc = bcast_i(wc, 63);        // the rest of the bucket is above the window's last key
+          take_smallest64(P, b0 & (NBK - 1), c0, W.wf, W.wg, W.wc, lane);
+          W.wp = 0; W.wn = 64; W.n_pool -= 64;
+          W.bcur = b0;
+          W.lf = bcast_d(W.wf, 63); W.lg = bcast_d(W.wg, 63); W.lc = bcast_i(W.wc, 63);        // the rest of the bucket is above the window's last key
         }
       }
       PF_LDS_ORDER();
-      if (wn == 0) continue;                                    // everything taken was superseded: take the next buckets
+      if (W.n_spill > 0 && !respill(P, W, lane)) { status = 3; break; }
+      if (W.wn == 0) continue;                                    // everything taken was superseded: take the next buckets
     }
     SW_T(t1)
     // ---- pop: up to seven heads of the window at once, nine lanes each ----
@@ -246,23 +318,23 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     // and no earlier head was the target: exactly the pops, in order, that the sequential loop would make.  A head
     // that does not qualify simply stays in the window.
     constexpr int NH = 7;
-    const int nh = wn - wp < NH ? wn - wp : NH;
-    const int hsrc = wp + grp < 64 ? wp + grp : 63;            // my group's head lives in this window lane
-    const double pg = bperm_d(hsrc, wg);                       // needed only once the loads are back
+    const int nh = W.wn - W.wp < NH ? W.wn - W.wp : NH;
+    const int hsrc = W.wp + grp < 64 ? W.wp + grp : 63;            // my group's head lives in this window lane
+    const double pg = bperm_d(hsrc, W.wg);                       // needed only once the loads are back
     // the head cells feed the load addresses: v_readlane + select has none of the LDS crossbar's latency
-    int prc = bcast_i(wc, wp);
+    int prc = bcast_i(W.wc, W.wp);
     unsigned long long hfb[NH];                                 // f of heads 1.. (uniform) for the push test below
     hfb[0] = 0;
 #pragma unroll
     for (int h = 1; h < NH; ++h) {
-      const int l = wp + h < 64 ? wp + h : 63;
-      const int c_ = bcast_i(wc, l);
+      const int l = W.wp + h < 64 ? W.wp + h : 63;
+      const int c_ = bcast_i(W.wc, l);
       prc = grp == h ? c_ : prc;
-      hfb[h] = dbits(bcast_d(wf, l));
+      hfb[h] = dbits(bcast_d(W.wf, l));
     }
     // lanes 0..48 look at the head pair (e, h) = (lane / 7, lane % 7): too close to be independent?
     const int pe = (lane * 37) >> 8, ph = lane - 7 * pe;
-    const int rce = bperm_i(wp + pe < 64 ? wp + pe : 63, wc), rch = bperm_i(wp + ph < 64 ? wp + ph : 63, wc);
+    const int rce = bperm_i(W.wp + pe < 64 ? W.wp + pe : 63, W.wc), rch = bperm_i(W.wp + ph < 64 ? W.wp + ph : 63, W.wc);
     const bool have = grp < nh;                                 // (lane 63 is group 7: never)
     const int pr = prc >> 16, pc = prc & 0xFFFF;
     const int cur = pr * C + pc;
@@ -330,7 +402,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     }
     SW_T(t4)
     if (consumed == 0) { status = 2; break; }                   // only the step cap can stop head 0
-    wp += consumed;
+    W.wp += consumed;
     const bool eff = (E >> grp) & 1u;
     if (eff && sub == 8)                                        // astar.py:74 closed.add / leave the open list
       rec[cur].meta = VARIANT == 0 ? (cur_meta | PF_M_CLOSED) : (cur_meta & ~PF_M_INOPEN);
@@ -345,59 +417,39 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     // ---- pushes: below the limit -> into the window, else -> pool bucket ----
     // The slot index of a pool append comes from an LDS atomic; it is requested here and used after the window
     // inserts, so its latency is covered by them.
-    const bool tow = push && key_lt(fnew, tent, nrc, lf, lg, lc);
+    const bool tow = push && key_lt(fnew, tent, nrc, W.lf, W.lg, W.lc);
     const bool top = push && !tow;
     const int pba = (int)(fnew * PF_SW_Q);
-    const int pb = pba < bcur ? NBK : (pba & (NBK - 1));       // below every regular bucket: the front bucket
+    const int pb = pba < W.bcur ? NBK : (pba & (NBK - 1));       // below every regular bucket: the front bucket
+    const bool inrange = pba - W.bcur < NBK;                   // inside the circular bucket range (front bucket: always)
     int pat = 0;
-    if (top) pat = __hip_atomic_fetch_add(&P.cnt[pb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    const int bcur_at_push = bcur;
+    if (top && inrange) pat = __hip_atomic_fetch_add(&P.cnt[pb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     const unsigned long long pm = __ballot(push), im0 = __ballot(tow);
-    n_pool += __builtin_popcountll(pm & ~im0);
+    W.n_pool += __builtin_popcountll(pm & ~im0);
     push32 += (unsigned)__builtin_popcountll(VARIANT == 0 ? __ballot(push && !in_open) : pm);   // heappush calls of the reference
     SW_T(t5)
     unsigned long long im = im0;
     while (im) {
       const int l = __builtin_ctzll(im); im &= im - 1;
-      const double kf = bcast_d(fnew, l), kg = bcast_d(tent, l);
-      const int kc = bcast_i(nrc, l);
-      if (!key_lt(kf, kg, kc, lf, lg, lc)) {                   // an eviction inside this loop lowered the limit
-        if (!pool_put1(P, kf, kg, kc, bcur, lane)) { status = 3; break; }
-        n_pool += 1;
-        continue;
-      }
-      const bool live = lane >= wp && lane < wn;
-      const int p = wp + __builtin_popcountll(__ballot(live && key_lt(wf, wg, wc, kf, kg, kc)));   // first live lane not below the key
-      if (wn < 64) {
-        const double sf = wave_up_d(wf), sg = wave_up_d(wg); const int sc = wave_up_i(wc);
-        if (lane > p && lane <= wn) { wf = sf; wg = sg; wc = sc; }
-        if (lane == p) { wf = kf; wg = kg; wc = kc; }
-        wn += 1;
-      } else if (wp > 0) {
-        const double sf = wave_down_d(wf), sg = wave_down_d(wg); const int sc = wave_down_i(wc);
-        if (lane >= wp - 1 && lane < p - 1) { wf = sf; wg = sg; wc = sc; }
-        if (lane == p - 1) { wf = kf; wg = kg; wc = kc; }
-        wp -= 1;
-      } else {
-        // 64 live entries: the largest key (the new one, or lane 63's) returns to the pool and becomes the limit
-        double ef = kf, eg = kg; int ec = kc;
-        if (p < 64) {
-          ef = bcast_d(wf, 63); eg = bcast_d(wg, 63); ec = bcast_i(wc, 63);
-          const double sf = wave_up_d(wf), sg = wave_up_d(wg); const int sc = wave_up_i(wc);
-          if (lane > p) { wf = sf; wg = sg; wc = sc; }
-          if (lane == p) { wf = kf; wg = kg; wc = kc; }
-        }
-        if (!pool_put1(P, ef, eg, ec, bcur, lane)) { status = 3; break; }
-        n_pool += 1;
-        lf = ef; lg = eg; lc = ec;
-      }
+      // (an eviction inside this loop may have lowered the limit below this key: sw_add re-checks)
+      if (!sw_add(P, W, bcast_d(fnew, l), bcast_d(tent, l), bcast_i(nrc, l), lane)) { status = 3; break; }
     }
     if (status == 3) break;
     SW_T(t6)
     {
-      const bool bad = top && !(pat < CAP && pba - bcur_at_push < NBK);
-      if (top && !bad) { P.bf[pb * CAP + pat] = fnew; P.bg[pb * CAP + pat] = tent; P.bc[pb * CAP + pat] = nrc; }
-      if (__ballot(bad)) { status = 3; break; }                // a bucket is full (or out of the circular range)
+      const bool fits = inrange && pat < CAP;
+      if (top && fits) { P.bf[pb * CAP + pat] = fnew; P.bg[pb * CAP + pat] = tent; P.bc[pb * CAP + pat] = nrc; }
+      const unsigned long long sm = __ballot(top && !fits);     // bucket full or beyond the circular range: spill list
+      if (sm) {
+        if (top && !fits) {
+          if (inrange) __hip_atomic_fetch_add(&P.cnt[pb], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // a number past the end: give it back
+          const int at = W.n_spill + __builtin_popcountll(sm & ((1ull << lane) - 1ull));
+          if (at < PF_SW_SPILL) { P.sf[at] = fnew; P.sg[at] = tent; P.sc[at] = nrc; }
+        }
+        W.n_spill += __builtin_popcountll(sm);
+        st.spills += (unsigned)__builtin_popcountll(sm);
+        if (W.n_spill > PF_SW_SPILL) { status = 3; break; }     // never silent
+      }
     }
     if (hit) { status = 0; break; }
     PF_LDS_ORDER();
@@ -409,7 +461,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
 #ifdef PF_TRIPS
     n_max += 1;                                                 // diagnostic build: trips instead of the open-list high-water mark
 #else
-    const int n_open = n_pool + (wn - wp);
+    const int n_open = W.n_pool + (W.wn - W.wp);
     if (n_open > n_max) n_max = n_open;
 #endif
   }

@@ -31,7 +31,7 @@ struct __attribute__((aligned(16))) Rec {
 #define PF_AVOID_SHIFT 18
 #define PF_AVOID_KEEP 0xFFFC0000u
 #define PF_T2 64 /* tier-2 (HBM) overflow slots per bin */
-#define PF_POOL_STRIDE (257 * 1024 * 20) /* bytes of open-list HBM scratch per resident agent slot (bucket pool / tier 2) */
+#define PF_POOL_STRIDE ((257 * 1024 + 16384) * 20) /* bytes of open-list HBM scratch per resident agent slot (bucket pool / tier 2) */
 #define PF_TAG_SHIFT 8
 
 // helper.py:30-36 / MPA.py:71-77 move order

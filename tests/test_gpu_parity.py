@@ -130,6 +130,30 @@ def test_astar_sealed_rooms_vs_oracle():
     e.close()
 
 
+def test_astar_open_map_plateaus_vs_oracle():
+    """An empty 1024 x 1024 map: thousands of open entries within 1/64 of f (near-ties along straight runs) overflow
+    single buckets of the open-list pool, so the spill list and its re-offer at refill time are exercised; nothing
+    may overflow and the searches with the largest open lists must match the oracle."""
+    from pathfit.engine import Engine
+    import pf_oracle as po
+    g = np.zeros((1024, 1024), np.uint8)
+    e, o = Engine(g), po.Oracle(g)
+    rnd = np.random.default_rng(7)
+    n = 256
+    starts = rnd.integers(0, g.size, n).astype(np.int32); targets = rnd.integers(0, g.size, n).astype(np.int32)
+    starts[:4] = [0, 0, g.size - 1, 1023]; targets[:4] = [g.size - 1, 1023 * 1024, 0, 1023 * 1024 + 511]
+    for variant in (0, 1):
+        paths, st, cnt = e.astar_host(variant, starts, targets, None, path_cap=16 * 2048, want_counters=True)
+        assert (st == 0).all()
+        assert e.counters()["candidates"] > 0          # for A* calls: entries that went through the spill list
+        check = set(np.argsort(-cnt[:, 2])[:6].tolist()) | {0, 1, 2, 3}
+        for i in sorted(check):
+            want, ost = o.astar(int(starts[i]), int(targets[i]), None, variant)
+            assert np.array_equal(paths[i], want), (variant, i)
+            assert cnt[i, 0] == ost[0]
+    e.close()
+
+
 def test_decode_and_score_golden():
     from pathfit.engine import score_params
     z = gio.load("decode_cases")
