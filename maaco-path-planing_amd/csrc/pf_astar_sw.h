@@ -319,22 +319,13 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     // that does not qualify simply stays in the window.
     constexpr int NH = 7;
     const int nh = W.wn - W.wp < NH ? W.wn - W.wp : NH;
-    const int hsrc = W.wp + grp < 64 ? W.wp + grp : 63;            // my group's head lives in this window lane
-    const double pg = bperm_d(hsrc, W.wg);                       // needed only once the loads are back
     // the head cells feed the load addresses: v_readlane + select has none of the LDS crossbar's latency
     int prc = bcast_i(W.wc, W.wp);
-    unsigned long long hfb[NH];                                 // f of heads 1.. (uniform) for the push test below
-    hfb[0] = 0;
 #pragma unroll
     for (int h = 1; h < NH; ++h) {
-      const int l = W.wp + h < 64 ? W.wp + h : 63;
-      const int c_ = bcast_i(W.wc, l);
+      const int c_ = bcast_i(W.wc, W.wp + h < 64 ? W.wp + h : 63);
       prc = grp == h ? c_ : prc;
-      hfb[h] = dbits(bcast_d(W.wf, l));
     }
-    // lanes 0..48 look at the head pair (e, h) = (lane / 7, lane % 7): too close to be independent?
-    const int pe = (lane * 37) >> 8, ph = lane - 7 * pe;
-    const int rce = bperm_i(W.wp + pe < 64 ? W.wp + pe : 63, W.wc), rch = bperm_i(W.wp + ph < 64 ? W.wp + ph : 63, W.wc);
     const bool have = grp < nh;                                 // (lane 63 is group 7: never)
     const int pr = prc >> 16, pc = prc & 0xFFFF;
     const int cur = pr * C + pc;
@@ -345,6 +336,16 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     unsigned M = 0;
     double cur_g = 0.0;
     if (have) { rn = rec[nidx]; M = G.mm[cur]; if (VARIANT == 1) cur_g = rec[cur].g; }
+    // -- everything below is in the shadow of the loads --
+    const int hsrc = W.wp + grp < 64 ? W.wp + grp : 63;            // my group's head lives in this window lane
+    const double pg = bperm_d(hsrc, W.wg);
+    unsigned long long hfb[NH];                                 // f of heads 1.. (uniform) for the push test below
+    hfb[0] = 0;
+#pragma unroll
+    for (int h = 1; h < NH; ++h) hfb[h] = dbits(bcast_d(W.wf, W.wp + h < 64 ? W.wp + h : 63));
+    // lanes 0..48 look at the head pair (e, h) = (lane / 7, lane % 7): too close to be independent?
+    const int pe = (lane * 37) >> 8, ph = lane - 7 * pe;
+    const int rce = bperm_i(W.wp + pe < 64 ? W.wp + pe : 63, W.wc), rch = bperm_i(W.wp + ph < 64 ? W.wp + ph : 63, W.wc);
     const int nr = pr + ddr, nc = pc + ddc;
     const long hdr = nr - tr, hdc = nc - tc;
     double hn = __builtin_sqrt((double)(hdr * hdr + hdc * hdc));   // astar.py:90 / MPA.py:140
