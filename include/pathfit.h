@@ -43,6 +43,7 @@ extern "C" {
 
 #define PF_ASTAR_REF 0 /* AStarSolver.solve semantics, astar.py:33-101 */
 #define PF_ASTAR_MPA 1 /* MPA._a_star semantics, MPA.py:106-151 */
+#define PF_ASTAR_DIJKSTRA 2 /* DijkstraSolver.solve semantics, dijkstra.py:32-97 (variant 0's loop with h == 0) */
 
 typedef struct pf_handle pf_handle;
 

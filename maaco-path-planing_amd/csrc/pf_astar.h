@@ -186,18 +186,22 @@ PF_DEV int pocket_flood(const Grid& G, const Slot& s, int* lds, int from, int to
 template <int VARIANT>
 __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int target, int* out, int out_cap,
                      int& out_n, AStat& st, int lane) {
+  // VARIANT 0 AStarSolver.solve (astar.py:33-101), 1 MPA._a_star (MPA.py:106-151), 2 DijkstraSolver.solve
+  // (dijkstra.py:32-97: the loop of variant 0 with heap entries (g, node), i.e. h == 0 and key (g, g, node))
+  constexpr int SEM = VARIANT == 1 ? 1 : 0;
+  static_assert(VARIANT != 2 || PF_LOOP == 2, "the Dijkstra variant is built on the sorted-window loop");
   out_n = 0;
   const int C = G.C;
   const int sr = row_of(G, start), sc_ = start - sr * C;
   const int tr = row_of(G, target), tc = target - tr * C;
-  if (VARIANT == 1 && start == target) {                    // MPA.py:107
+  if (SEM == 1 && start == target) {                    // MPA.py:107
     if (out_cap < 1) return 3;
     if (lane == 0) out[0] = start;
     out_n = 1;
     return 0;
   }
   if (G.occ[start] == 1 || G.occ[target] == 1) return 1;     // astar.py:37-39 / MPA.py:109-111 (cells are in bounds)
-  if (VARIANT == 0 && start == target) {                    // astar.py:41
+  if (SEM == 0 && start == target) {                    // astar.py:41
     if (out_cap < 1) return 3;
     if (lane == 0) out[0] = start;
     out_n = 1;
@@ -213,12 +217,12 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
   // goal inside the avoid set can never be pushed: the reference then pops the whole reachable region and
   // returns [] (MPA.py:151).  Same result, none of the work.  (On G512 this case is 44 % of all pops of an
   // MPA sweep: the Brownian target often lands on the predator's own prefix.)
-  if (VARIANT == 1 && (rec[target].meta >> PF_AVOID_SHIFT) == avm) return 1;
+  if (SEM == 1 && (rec[target].meta >> PF_AVOID_SHIFT) == avm) return 1;
   // small-pocket proof of unreachability, from both ends (see pocket_flood)
   {
-    const int ex = VARIANT == 0 ? start : -1;               // VARIANT 0: start/target may sit in the avoid set
+    const int ex = SEM == 0 ? start : -1;               // VARIANT 0: start/target may sit in the avoid set
     if (pocket_flood(G, s, (int*)O.lf, target, start, ex, lane) == 1) return 1;
-    if (pocket_flood(G, s, (int*)O.lf, start, target, VARIANT == 0 ? target : -1, lane) == 1) return 1;
+    if (pocket_flood(G, s, (int*)O.lf, start, target, SEM == 0 ? target : -1, lane) == 1) return 1;
   }
   s.tag += 1;
   const uint32_t tag = s.tag;
@@ -238,19 +242,19 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
   double h0_seed;
   {
     long dr0 = sr - tr, dc0 = sc_ - tc;
-    double h0 = __builtin_sqrt((double)(dr0 * dr0 + dc0 * dc0));
+    double h0 = VARIANT == 2 ? 0.0 : __builtin_sqrt((double)(dr0 * dr0 + dc0 * dc0));
     h0_seed = h0;
     if (lane == 0) {
       O.lf[0] = h0; O.lg[0] = 0.0; O.lc[0] = (sr << 16) | sc_;
       mf = h0; mg = 0.0; mc = (sr << 16) | sc_; ms = 0; occ = 1;
       Rec r0 = rec[start];
       Rec w; w.g = 0.0; w.tagmm = (tag << PF_TAG_SHIFT) | (r0.tagmm & 0xFFu);
-      w.meta = (r0.meta & PF_AVOID_KEEP) | (VARIANT == 1 ? PF_M_INOPEN : 0u);   // position (0,0)
+      w.meta = (r0.meta & PF_AVOID_KEEP) | (SEM == 1 ? PF_M_INOPEN : 0u);   // position (0,0)
       rec[start] = w;
     }
     n_open = 1;
   }
-  const int max_steps = G.R * C * (VARIANT == 0 ? 3 : 2);   // astar.py:58 / MPA.py:118 (R,C <= 4096)
+  const int max_steps = G.R * C * (SEM == 0 ? 3 : 2);   // astar.py:58 / MPA.py:118 (R,C <= 4096)
 #if PF_LOOP != 0
   (void)occ; (void)occ2; (void)any_t2; (void)mf; (void)mg; (void)mc; (void)ms; (void)rr; (void)n_open; (void)full; (void)h0_seed;
 #if PF_LOOP == 2
@@ -336,25 +340,25 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
     PF_T(t5)
     const uint32_t cur_tagmm = (uint32_t)bcast_i((int)rn.tagmm, lcur);
     const uint32_t cur_meta = (uint32_t)bcast_i((int)rn.meta, lcur);
-    const double base_g = VARIANT == 0 ? pg : cur_g;          // astar.py:85 popped g / MPA.py:135 g_score[current]
+    const double base_g = SEM == 0 ? pg : cur_g;          // astar.py:85 popped g / MPA.py:135 g_score[current]
     steps += 1;
     if (cur == target) { status = 0; break; }                // astar.py:64 / MPA.py:123
     if (lane == lcur)                                         // astar.py:74 closed.add / leave the open list
-      rec[cur].meta = VARIANT == 0 ? (cur_meta | PF_M_CLOSED) : (cur_meta & ~PF_M_INOPEN);
+      rec[cur].meta = SEM == 0 ? (cur_meta | PF_M_CLOSED) : (cur_meta & ~PF_M_INOPEN);
     // ---- relax the 8 neighbours in parallel ----
     const unsigned M = cur_tagmm & 0xFFu;
     const bool rvalid = (rn.tagmm >> PF_TAG_SHIFT) == tag;
     const bool avoided = (rn.meta >> PF_AVOID_SHIFT) == avm;
     const bool closed = rvalid && (rn.meta & PF_M_CLOSED);
     bool ok = inb && ((M >> (d & 7)) & 1u);
-    if (VARIANT == 0) ok = ok && !closed && !(avoided && nidx != start && nidx != target);
+    if (SEM == 0) ok = ok && !closed && !(avoided && nidx != start && nidx != target);
     else ok = ok && !avoided;
     const double tent = base_g + (d < 4 ? 1.0 : PF_SQRT2);
     const bool better = ok && (!rvalid || tent < rn.g);      // astar.py:87 / MPA.py:137
     // a valid, unclosed record has a live open entry in VARIANT 0; VARIANT 1 tracks it with a flag
-    const bool in_open = VARIANT == 0 ? rvalid : (rvalid && (rn.meta & PF_M_INOPEN));
+    const bool in_open = SEM == 0 ? rvalid : (rvalid && (rn.meta & PF_M_INOPEN));
     const bool push = better && !in_open;
-    const bool deckey = VARIANT == 0 && better && in_open;   // astar.py:96-100
+    const bool deckey = SEM == 0 && better && in_open;   // astar.py:96-100
     nbr32 += (unsigned)__builtin_popcountll(__ballot(ok));
     double fnew = 0.0;
     unsigned pos = (rn.meta >> PF_POS_SHIFT) & PF_POS_MASK;
@@ -387,14 +391,14 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
       }
       if (!ovf) {
         Rec wv; wv.g = tent; wv.tagmm = (tag << PF_TAG_SHIFT) | (rn.tagmm & 0xFFu);
-        wv.meta = (rn.meta & PF_AVOID_KEEP) | (pos << PF_POS_SHIFT) | (unsigned)(d & 7) | (VARIANT == 1 ? PF_M_INOPEN : 0u);
+        wv.meta = (rn.meta & PF_AVOID_KEEP) | (pos << PF_POS_SHIFT) | (unsigned)(d & 7) | (SEM == 1 ? PF_M_INOPEN : 0u);
         rec[nidx] = wv;
       }
     }
     PF_T(t6)
     const int np = __builtin_popcountll(__ballot(push));
     // ---- decrease-key: the owning lane refreshes its cached minimum ----
-    if (VARIANT == 0) {
+    if (SEM == 0) {
       unsigned long long dm = __ballot(deckey);
       dk32 += (unsigned)__builtin_popcountll(dm);
       while (dm) {
@@ -431,7 +435,7 @@ __device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int targe
         if (mf == PF_INF || ent_lt(f2, g2, prc2, mf, mg, mc)) { mf = f2; mg = g2; mc = prc2; ms = slot; }
         Rec wv; wv.g = g2; wv.tagmm = (tag << PF_TAG_SHIFT) | (tm2 & 0xFFu);
         wv.meta = (me2 & PF_AVOID_KEEP) | ((((unsigned)lane << 7) | (unsigned)slot) << PF_POS_SHIFT) | (unsigned)(dd & 7) |
-                  (VARIANT == 1 ? PF_M_INOPEN : 0u);
+                  (SEM == 1 ? PF_M_INOPEN : 0u);
         rec[r2 * C + c2] = wv;
       }
     }

@@ -65,6 +65,7 @@ PF_DEV unsigned long long one_per_row(unsigned long long m, double g, int c) {
 template <int VARIANT>
 __device__ __forceinline__ int pop_loop4(const Grid& G, Rec* rec, const Open& O, uint32_t tag, uint32_t avm, int start, int target,
                                          int tr, int tc, int max_steps, AStat& st, int lane) {
+  constexpr int SEM = VARIANT == 1 ? 1 : 0;
   constexpr int S = PF_S;
   static_assert(S == 16, "the four-wide loop scans a bin with one 16-lane row");
   constexpr unsigned full = 0xFFFFu;
@@ -123,7 +124,7 @@ __device__ __forceinline__ int pop_loop4(const Grid& G, Rec* rec, const Open& O,
     Rec rn; rn.g = 0.0; rn.tagmm = 0; rn.meta = 0;
     unsigned M = 0; double cur_g = 0.0;
     if (inb || self) rn = rec[inb ? nidx : cur];
-    if (inb) { M = G.mm[cur]; if (VARIANT == 1) cur_g = rec[cur].g; }   // row-uniform addresses: one line each
+    if (inb) { M = G.mm[cur]; if (SEM == 1) cur_g = rec[cur].g; }   // row-uniform addresses: one line each
     const long hdr = nr - tr, hdc = nc - tc;
     double hn = __builtin_sqrt((double)(hdr * hdr + hdc * hdc));       // astar.py:90 / MPA.py:140
     asm volatile("" : "+v"(hn));                              // keep the square root in the shadow of the loads
@@ -173,19 +174,19 @@ __device__ __forceinline__ int pop_loop4(const Grid& G, Rec* rec, const Open& O,
 #endif
     // ---- S4: relax the 8 neighbours of my row's candidate, in registers ----
     const uint32_t cur_meta = rn.meta;                         // meaningful in the self lane
-    const double base_g = VARIANT == 0 ? cg : cur_g;           // astar.py:85 popped g / MPA.py:135 g_score[current]
+    const double base_g = SEM == 0 ? cg : cur_g;           // astar.py:85 popped g / MPA.py:135 g_score[current]
     const bool rvalid = (rn.tagmm >> PF_TAG_SHIFT) == tag;
     const bool avoided = (rn.meta >> PF_AVOID_SHIFT) == avm;
     const bool closed = rvalid && (rn.meta & PF_M_CLOSED);
     const bool goal_here = cur == target;                      // popping the target ends the search before any relaxation
     bool ok = inb && ((M >> (d & 7)) & 1u) && !goal_here;
-    if (VARIANT == 0) ok = ok && !closed && !(avoided && nidx != start && nidx != target);
+    if (SEM == 0) ok = ok && !closed && !(avoided && nidx != start && nidx != target);
     else ok = ok && !avoided;
     const double tent = base_g + (d < 4 ? 1.0 : PF_SQRT2);
     const bool better = ok && (!rvalid || tent < rn.g);       // astar.py:87 / MPA.py:137
-    const bool in_open = VARIANT == 0 ? rvalid : (rvalid && (rn.meta & PF_M_INOPEN));
+    const bool in_open = SEM == 0 ? rvalid : (rvalid && (rn.meta & PF_M_INOPEN));
     const bool push = better && !in_open;
-    const bool deckey = VARIANT == 0 && better && in_open;    // astar.py:96-100
+    const bool deckey = SEM == 0 && better && in_open;    // astar.py:96-100
     const double fnew = tent + hn;                             // astar.py:90 / MPA.py:140
     if (push || deckey) __hip_atomic_fetch_min(&X[row].mp, dbits(fnew), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     // ---- S5: which candidates commit ----
@@ -238,7 +239,7 @@ __device__ __forceinline__ int pop_loop4(const Grid& G, Rec* rec, const Open& O,
       mf = jf; mg = jg; mc = jc; ms = jslot;
     }
     if (self && crel)                                          // astar.py:74 closed.add / leave the open list
-      rec[cur].meta = VARIANT == 0 ? (cur_meta | PF_M_CLOSED) : (cur_meta & ~PF_M_INOPEN);
+      rec[cur].meta = SEM == 0 ? (cur_meta | PF_M_CLOSED) : (cur_meta & ~PF_M_INOPEN);
     nbr32 += (unsigned)__builtin_popcountll(__ballot(ok && crel));
     unsigned pos = (rn.meta >> PF_POS_SHIFT) & PF_POS_MASK;
     bool ovf = false;
@@ -269,12 +270,12 @@ __device__ __forceinline__ int pop_loop4(const Grid& G, Rec* rec, const Open& O,
       }
       if (!ovf) {
         Rec wv; wv.g = tent; wv.tagmm = (tag << PF_TAG_SHIFT) | (rn.tagmm & 0xFFu);
-        wv.meta = (rn.meta & PF_AVOID_KEEP) | (pos << PF_POS_SHIFT) | (unsigned)(d & 7) | (VARIANT == 1 ? PF_M_INOPEN : 0u);
+        wv.meta = (rn.meta & PF_AVOID_KEEP) | (pos << PF_POS_SHIFT) | (unsigned)(d & 7) | (SEM == 1 ? PF_M_INOPEN : 0u);
         rec[nidx] = wv;
       }
     }
     const int np = __builtin_popcountll(__ballot(push && crel));
-    if (VARIANT == 0) {                                        // decrease-key: the owning lane refreshes its cached minimum
+    if (SEM == 0) {                                        // decrease-key: the owning lane refreshes its cached minimum
       unsigned long long dm = __ballot(deckey && crel);
       dk32 += (unsigned)__builtin_popcountll(dm);
       while (dm) {
@@ -311,7 +312,7 @@ __device__ __forceinline__ int pop_loop4(const Grid& G, Rec* rec, const Open& O,
           if ((mf == PF_INF) | ent_lt_nb(f2_, g2_, prc2, mf, mg, mc)) { mf = f2_; mg = g2_; mc = prc2; ms = slot; }
           Rec wv; wv.g = g2_; wv.tagmm = (tag << PF_TAG_SHIFT) | (tm2 & 0xFFu);
           wv.meta = (me2 & PF_AVOID_KEEP) | ((((unsigned)lane << 7) | (unsigned)slot) << PF_POS_SHIFT) | (unsigned)(dd & 7) |
-                    (VARIANT == 1 ? PF_M_INOPEN : 0u);
+                    (SEM == 1 ? PF_M_INOPEN : 0u);
           rec[r2 * C + c2] = wv;
         }
       }

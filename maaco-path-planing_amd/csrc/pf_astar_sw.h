@@ -201,6 +201,7 @@ PF_DEV int drop_superseded(const Rec* rec, int C, double& wf, double wg, int wc)
 template <int VARIANT>
 __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& O, uint32_t tag, uint32_t avm, int start, int target,
                                            int tr, int tc, int max_steps, double h0, int src, AStat& st, int lane) {
+  constexpr int SEM = VARIANT == 1 ? 1 : 0;                   // 0: closed set + decrease-key (A*, Dijkstra), 1: MPA._a_star
   constexpr int NBK = PF_SW_NBK, CAP = PF_SW_CAP;
   const int C = G.C, RC = G.R * G.C;
   SwPool P;
@@ -244,7 +245,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
           if (lane < cF) { W.wf = P.bf[NBK * CAP + lane]; W.wg = P.bg[NBK * CAP + lane]; W.wc = P.bc[NBK * CAP + lane]; }
           if (lane == 0) P.cnt[NBK] = 0;
           int live = cF;
-          if (VARIANT == 0) live = drop_superseded(rec, C, W.wf, W.wg, W.wc);
+          if (SEM == 0) live = drop_superseded(rec, C, W.wf, W.wg, W.wc);
           int n2 = 1; while (n2 < cF) n2 <<= 1;
           sort_lanes(W.wf, W.wg, W.wc, lane, n2);
 #ifdef PF_STAMPS
@@ -287,7 +288,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
             }
           }
           int live = total;
-          if (VARIANT == 0) live = drop_superseded(rec, C, W.wf, W.wg, W.wc);
+          if (SEM == 0) live = drop_superseded(rec, C, W.wf, W.wg, W.wc);
           int n2 = 1; while (n2 < total) n2 <<= 1;
           sort_lanes(W.wf, W.wg, W.wc, lane, n2);
 #ifdef PF_STAMPS
@@ -335,7 +336,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     Rec rn; rn.g = 0.0; rn.tagmm = 0; rn.meta = 0;
     unsigned M = 0;
     double cur_g = 0.0;
-    if (have) { rn = rec[nidx]; M = G.mm[cur]; if (VARIANT == 1) cur_g = rec[cur].g; }
+    if (have) { rn = rec[nidx]; M = G.mm[cur]; if (SEM == 1) cur_g = rec[cur].g; }
     // -- everything below is in the shadow of the loads --
     const int hsrc = W.wp + grp < 64 ? W.wp + grp : 63;            // my group's head lives in this window lane
     const double pg = bperm_d(hsrc, W.wg);
@@ -348,7 +349,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     const int rce = bperm_i(W.wp + pe < 64 ? W.wp + pe : 63, W.wc), rch = bperm_i(W.wp + ph < 64 ? W.wp + ph : 63, W.wc);
     const int nr = pr + ddr, nc = pc + ddc;
     const long hdr = nr - tr, hdc = nc - tc;
-    double hn = __builtin_sqrt((double)(hdr * hdr + hdc * hdc));   // astar.py:90 / MPA.py:140
+    double hn = VARIANT == 2 ? 0.0 : __builtin_sqrt((double)(hdr * hdr + hdc * hdc));   // astar.py:90 / MPA.py:140 / dijkstra.py:89
     asm volatile("" : "+v"(hn));                               // computed in the shadow of the loads
     SW_T(t2)
     // ---- relax the 8 neighbours of each head in registers ----
@@ -359,20 +360,20 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     SW_T(t3)                          // meaningful in the self lanes (sub == 8)
     // VARIANT 0: an entry superseded by a decrease-key (astar.py:96-100 rewrites it in place) is not a pop of the
     // reference: its head is consumed without effect and without being counted
-    const bool self_stale = VARIANT == 0 && sub == 8 && ((cur_meta & PF_M_CLOSED) || rn.g != pg);
+    const bool self_stale = SEM == 0 && sub == 8 && ((cur_meta & PF_M_CLOSED) || rn.g != pg);
     const unsigned long long stm = __ballot(have && self_stale);
     const bool my_stale = (stm >> (9 * grp + 8 < 64 ? 9 * grp + 8 : 63)) & 1ull;
-    const double base_g = VARIANT == 0 ? pg : cur_g;           // astar.py:85 popped g / MPA.py:135 g_score[current]
+    const double base_g = SEM == 0 ? pg : cur_g;           // astar.py:85 popped g / MPA.py:135 g_score[current]
     const bool rvalid = (rn.tagmm >> PF_TAG_SHIFT) == tag;
     const bool avoided = (rn.meta >> PF_AVOID_SHIFT) == avm;
     const bool closed = rvalid && (rn.meta & PF_M_CLOSED);
     bool ok = have && sub < 8 && ((M >> d) & 1u) && !my_stale && cur != target;
-    if (VARIANT == 0) ok = ok && !closed && !(avoided && nidx != start && nidx != target);
+    if (SEM == 0) ok = ok && !closed && !(avoided && nidx != start && nidx != target);
     else ok = ok && !avoided;
     const double tent = base_g + cost;
     const bool better = ok && (!rvalid || tent < rn.g);       // astar.py:87 / MPA.py:137
-    const bool in_open = VARIANT == 0 ? rvalid : (rvalid && (rn.meta & PF_M_INOPEN));
-    const bool push0 = VARIANT == 0 ? better : (better && !in_open);
+    const bool in_open = SEM == 0 ? rvalid : (rvalid && (rn.meta & PF_M_INOPEN));
+    const bool push0 = SEM == 0 ? better : (better && !in_open);
     const double fnew = tent + hn;                             // astar.py:90 / MPA.py:140
     const int nrc = (nr << 16) | nc;
     // ---- which heads take effect ----
@@ -406,13 +407,13 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     W.wp += consumed;
     const bool eff = (E >> grp) & 1u;
     if (eff && sub == 8)                                        // astar.py:74 closed.add / leave the open list
-      rec[cur].meta = VARIANT == 0 ? (cur_meta | PF_M_CLOSED) : (cur_meta & ~PF_M_INOPEN);
+      rec[cur].meta = SEM == 0 ? (cur_meta | PF_M_CLOSED) : (cur_meta & ~PF_M_INOPEN);
     const bool push = push0 && eff;
     nbr32 += (unsigned)__builtin_popcountll(__ballot(ok && eff));
-    if (VARIANT == 0) dk32 += (unsigned)__builtin_popcountll(__ballot(better && in_open && eff));
+    if (SEM == 0) dk32 += (unsigned)__builtin_popcountll(__ballot(better && in_open && eff));
     if (better && eff) {
       Rec wv; wv.g = tent; wv.tagmm = (tag << PF_TAG_SHIFT) | (rn.tagmm & 0xFFu);
-      wv.meta = (rn.meta & PF_AVOID_KEEP) | (unsigned)d | (VARIANT == 1 ? PF_M_INOPEN : 0u);
+      wv.meta = (rn.meta & PF_AVOID_KEEP) | (unsigned)d | (SEM == 1 ? PF_M_INOPEN : 0u);
       rec[nidx] = wv;
     }
     // ---- pushes: below the limit -> into the window, else -> pool bucket ----
@@ -427,7 +428,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     if (top && inrange) pat = __hip_atomic_fetch_add(&P.cnt[pb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     const unsigned long long pm = __ballot(push), im0 = __ballot(tow);
     W.n_pool += __builtin_popcountll(pm & ~im0);
-    push32 += (unsigned)__builtin_popcountll(VARIANT == 0 ? __ballot(push && !in_open) : pm);   // heappush calls of the reference
+    push32 += (unsigned)__builtin_popcountll(SEM == 0 ? __ballot(push && !in_open) : pm);   // heappush calls of the reference
     SW_T(t5)
     unsigned long long im = im0;
     while (im) {

@@ -9,6 +9,6 @@ from .rng import AgentRandom  # noqa: F401
 from ._lib import PathfitError  # noqa: F401
 from .engine import Engine, DevBuf, score_params  # noqa: F401
 from .paths import CellPath  # noqa: F401
-from .solvers import AStarSolver, GASolver, PSOSolver, BasePathfinder  # noqa: F401
+from .solvers import AStarSolver, DijkstraSolver, GASolver, PSOSolver, BasePathfinder  # noqa: F401
 from .maaco import MAACO  # noqa: F401
 from .mpa import MPA  # noqa: F401

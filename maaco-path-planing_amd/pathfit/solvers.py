@@ -92,6 +92,41 @@ class AStarSolver(BasePathfinder):
         return res
 
 
+class DijkstraSolver(BasePathfinder):
+    def __init__(self, grid, turn_penalty_factor=0.1, safety_penalty_factor=0.05, min_safe_distance=1.5,
+                 allow_diagonal_moves=True, restrict_diagonal_near_obstacle_policy=True,
+                 diagonal_obstacle_penalty_value=1000.0, engine=None, device=0, seed=0):
+        g = np.asarray(grid)
+        start_node = find_marker(g, START_NODE_VAL, "Dijkstra")
+        target_node = find_marker(g, TARGET_NODE_VAL, "Dijkstra")
+        super().__init__(grid, start_node, target_node, turn_penalty_factor, safety_penalty_factor, min_safe_distance,
+                         allow_diagonal_moves, restrict_diagonal_near_obstacle_policy, diagonal_obstacle_penalty_value,
+                         engine, device, seed)
+        self.dijkstra_strictly_restricts_corners = self.restrict_diagonal_near_obstacle_policy
+
+    def solve(self, start_node_override=None, target_node_override=None, nodes_to_avoid=None):
+        """dijkstra.py:32-97 for one query: AStarSolver's loop with heap entries (g, node) (batched form: Engine.astar_host, variant 2)."""
+        s = start_node_override if start_node_override else self.start_node
+        t = target_node_override if target_node_override else self.target_node
+        inb = lambda n: 0 <= n[0] < self.rows and 0 <= n[1] < self.cols
+        if not inb(s) or not inb(t):
+            return self._calculate_stats_for_path([])
+        avoid = [np.array([self._cell(a) for a in nodes_to_avoid if inb(a)], np.int32)] if nodes_to_avoid else None
+        paths, st = self.engine.astar_host(2, [self._cell(s)], [self._cell(t)], avoid,
+                                           path_cap=self.rows * self.cols if self.rows * self.cols <= 1 << 16 else None,
+                                           allow_diag=self.allow_diagonal_moves,
+                                           restrict_corner=self.dijkstra_strictly_restricts_corners)
+        if st[0] == 3:
+            paths, st = self.engine.astar_host(2, [self._cell(s)], [self._cell(t)], avoid, path_cap=self.rows * self.cols,
+                                               allow_diag=self.allow_diagonal_moves,
+                                               restrict_corner=self.dijkstra_strictly_restricts_corners)
+        path = CellPath(paths[0], self.cols).tolist()
+        res = self._calculate_stats_for_path(path)
+        if len(path) > 1:
+            self.convergence_curve.append(res[1])      # dijkstra.py:67: g of the goal == path length
+        return res
+
+
 class _WaypointSolver(BasePathfinder):
     """Shared decode + score batch for GA / PSO."""
 

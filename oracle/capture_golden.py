@@ -349,6 +349,58 @@ def cap_rng():
     np.savez_compressed(os.path.join(OUT, "rng.npz"), **d, **{"meta_" + k: v for k, v in META.items()})
 
 
+def cap_dijkstra(G):
+    """dijkstra.DijkstraSolver.solve (dijkstra.py:32-97): same (start, target, avoid) recipe as cap_astar, fewer cases."""
+    rnd = random.Random(4321)
+    rows = []
+    for name, n in [("fig7", 40), ("fig13", 30), ("img2", 30), ("g128crop", 8), ("g256", 3)]:
+        g = G[name]
+        R, C = g.shape
+        rd = rh.RefDijkstra(g)
+        free = [tuple(int(v) for v in x) for x in np.argwhere(g != 1)]
+        obst = [tuple(int(v) for v in x) for x in np.argwhere(g == 1)]
+        S, T = st_of(g)
+        for t in range(n):
+            s, e = rnd.choice(free), rnd.choice(free)
+            if max(R, C) > 20:
+                s = rnd.choice(free)
+                near = [f for f in free if abs(f[0] - s[0]) <= 20 and abs(f[1] - s[1]) <= 20]
+                e = rnd.choice(near)
+                if t == 0 and R <= 128:
+                    s, e = S, T
+            if t % 9 == 1:
+                e = s
+            if t % 13 == 2 and obst:
+                s = rnd.choice(obst)
+            if t % 17 == 3 and obst:
+                e = rnd.choice(obst)
+            avoid = None
+            if t % 3 != 0:
+                avoid = rnd.sample(free, rnd.randint(0, max(1, len(free) // 12)))
+                if t % 6 == 1:
+                    avoid.append(e)
+                if t % 6 == 2:
+                    avoid.append(s)
+            if t % 19 == 4:
+                avoid = [(e[0] + a, e[1] + b) for a in (-1, 0, 1) for b in (-1, 0, 1) if (a or b)]
+                avoid = [a for a in avoid if 0 <= a[0] < R and 0 <= a[1] < C]
+            pc, res, cnt = rd.solve(s, e, avoid)
+            rows.append(dict(grid=name, start=s[0] * C + s[1], target=e[0] * C + e[1],
+                             avoid=[a[0] * C + a[1] for a in avoid] if avoid is not None else [],
+                             has_avoid=avoid is not None, path=pc, pops=cnt["pops"], pushes=cnt["pushes"],
+                             stats=[float(x) for x in res[1:6]]))
+    names = sorted(set(r["grid"] for r in rows))
+    ao, af = csr([r["avoid"] for r in rows])
+    po_, pf = csr([r["path"] for r in rows])
+    np.savez_compressed(
+        os.path.join(OUT, "dijkstra_cases.npz"), grid_names=np.array(names),
+        grid_id=np.array([names.index(r["grid"]) for r in rows]),
+        start=np.array([r["start"] for r in rows]), target=np.array([r["target"] for r in rows]),
+        has_avoid=np.array([r["has_avoid"] for r in rows]), avoid_off=ao, avoid=af, path_off=po_, path=pf,
+        pops=np.array([r["pops"] for r in rows]), pushes=np.array([r["pushes"] for r in rows]),
+        stats=np.array([r["stats"] for r in rows]), **{"meta_" + k: v for k, v in META.items()})
+
+
 def cap_e2e(G):
     """Full solve loops of the unmodified reference under the per-agent stream contract (oracle/ref_e2e.py)."""
     import ref_e2e
@@ -389,7 +441,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     rh.install()
     G = grids()
-    which = sys.argv[1:] or ["grids", "rng", "astar", "decode", "maaco", "mpa", "pso", "e2e"]
+    which = sys.argv[1:] or ["grids", "rng", "astar", "decode", "maaco", "mpa", "pso", "dijkstra", "e2e"]
     if "grids" in which: cap_grids(G)
     if "rng" in which: cap_rng()
     if "astar" in which: cap_astar(G)
@@ -397,5 +449,6 @@ if __name__ == "__main__":
     if "maaco" in which: cap_maaco(G)
     if "mpa" in which: cap_mpa(G)
     if "pso" in which: cap_pso_update(G)
+    if "dijkstra" in which: cap_dijkstra(G)
     if "e2e" in which: cap_e2e(G)
     print("golden fixtures written to", OUT)

@@ -206,7 +206,7 @@ static int64_t reconstruct(orc_ws* w, int start, int target, int32_t* out, int64
  * per-cell byte mask (or NULL).  Returns path length in cells, 0 for [],
  * -1 if `cap` is too small. */
 static int64_t astar_v0(orc_ws* w, const uint8_t* occ, int R, int C, int allow_diag, int restrict_corner,
-                        int start, int target, const uint8_t* avoid, int32_t* out, int64_t cap, int64_t* st) {
+                        int start, int target, const uint8_t* avoid, int32_t* out, int64_t cap, int64_t* st, int hzero) {
   int sr = start / C, sc = start % C, tr = target / C, tc = target % C;
   st[5] = 1;
   if (!orc_free(occ, R, C, sr, sc) || !orc_free(occ, R, C, tr, tc)) return 0;   /* :37-39 */
@@ -214,7 +214,8 @@ static int64_t astar_v0(orc_ws* w, const uint8_t* occ, int R, int C, int allow_d
   w->epoch++; w->h.n = 0; w->h.max_n = 0;
   ws_touch(w, start);
   w->g[start] = 0.0;
-  orc_ent e0 = {orc_dist(sr, sc, tr, tc), 0.0, start};                              /* :45 */
+  /* hzero: DijkstraSolver.solve (dijkstra.py:32-97) is the same loop with heap entries (g, node): key (g, g, node) */
+  orc_ent e0 = {hzero ? 0.0 : orc_dist(sr, sc, tr, tc), 0.0, start};               /* :45 / dijkstra.py:45 */
   heap_push(&w->h, e0); st[1]++;
   int64_t max_steps = (int64_t)R * C * 3, steps = 0;                               /* :58 */
   int32_t nb[8];
@@ -244,7 +245,7 @@ static int64_t astar_v0(orc_ws* w, const uint8_t* occ, int R, int C, int allow_d
       double tentative = cur.g + orc_dist(r, c, nr, nc);                           /* :84-85 */
       if (tentative < w->g[n]) {                                                   /* :87 */
         w->parent[n] = cur.cell; w->g[n] = tentative;
-        orc_ent e = {tentative + orc_dist(nr, nc, tr, tc), tentative, n};          /* :90 */
+        orc_ent e = {hzero ? tentative : tentative + orc_dist(nr, nc, tr, tc), tentative, n};   /* :90 / dijkstra.py:89 */
         if (w->pos[n] < 0) { heap_push(&w->h, e); st[1]++; }                       /* :92-94 */
         else {                                                                     /* :96-100: replace + heapify */
           int i = w->pos[n]; w->h.e[i] = e; heap_up(&w->h, i); st[3]++;
@@ -310,8 +311,9 @@ ORC_API int64_t orc_astar(orc_ws* w, const uint8_t* occ, int R, int C, int varia
                           int restrict_corner, int start, int target, const uint8_t* avoid,
                           int32_t* out, int64_t cap, int64_t* stats) {
   int64_t st[6] = {0, 0, 0, 0, 0, 0};
-  int64_t n = variant ? astar_v1(w, occ, R, C, allow_diag, restrict_corner, start, target, avoid, out, cap, st)
-                      : astar_v0(w, occ, R, C, allow_diag, restrict_corner, start, target, avoid, out, cap, st);
+  /* variant 0 AStarSolver.solve, 1 MPA._a_star, 2 DijkstraSolver.solve */
+  int64_t n = variant == 1 ? astar_v1(w, occ, R, C, allow_diag, restrict_corner, start, target, avoid, out, cap, st)
+                           : astar_v0(w, occ, R, C, allow_diag, restrict_corner, start, target, avoid, out, cap, st, variant == 2);
   if (stats) memcpy(stats, st, sizeof(st));
   return n;
 }

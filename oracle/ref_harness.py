@@ -39,8 +39,8 @@ def mods():
         sys.dont_write_bytecode = True
         if REF not in sys.path:
             sys.path.insert(0, REF)
-        import env, helper, astar, ga_solver, pso, MAACO, MPA  # noqa: E401
-        _mods.update(env=env, helper=helper, astar=astar, ga_solver=ga_solver, pso=pso, MAACO=MAACO, MPA=MPA)
+        import env, helper, astar, dijkstra, ga_solver, pso, MAACO, MPA  # noqa: E401
+        _mods.update(env=env, helper=helper, astar=astar, dijkstra=dijkstra, ga_solver=ga_solver, pso=pso, MAACO=MAACO, MPA=MPA)
     return _mods
 
 
@@ -94,6 +94,7 @@ def install():
         for name in ("MAACO", "MPA", "pso", "ga_solver"):
             m[name].random = RNG
         m["astar"].heapq = HQ
+        m["dijkstra"].heapq = HQ
         m["MPA"].heapq = HQ
         np.random.choice = _np_choice_shim
         _installed = True
@@ -124,6 +125,24 @@ class RefAStar:
         m = install()
         with quiet():
             self.s = m["astar"].AStarSolver(np.array(grid), **kw)
+        self.C = self.s.cols
+
+    def solve(self, start_rc, target_rc, avoid_rc=None):
+        HQ.reset()
+        with quiet():
+            res = self.s.solve(tuple(start_rc), tuple(target_rc), set(avoid_rc) if avoid_rc else None)
+        self.s.convergence_curve.clear()
+        return to_cells(res[0], self.C), res, dict(pops=HQ.pops, pushes=HQ.pushes, heapifies=HQ.heapifies,
+                                                   max_open=HQ.max_open)
+
+
+class RefDijkstra:
+    """dijkstra.DijkstraSolver with pop/push counters."""
+
+    def __init__(self, grid, **kw):
+        m = install()
+        with quiet():
+            self.s = m["dijkstra"].DijkstraSolver(np.array(grid), **kw)
         self.C = self.s.cols
 
     def solve(self, start_rc, target_rc, avoid_rc=None):

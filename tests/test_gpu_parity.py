@@ -80,6 +80,35 @@ def test_astar_golden_both_variants():
                     assert cnt[j, 3] == ost[4]
 
 
+def test_dijkstra_golden_and_facade():
+    """DijkstraSolver (dijkstra.py:32-97): HIP variant 2 == golden paths / pops / pushes of the unmodified reference; the
+    facade returns the reference's 6-tuple."""
+    import pathfit
+    z = gio.load("dijkstra_cases")
+    names = [str(s) for s in z["grid_names"]]
+    for gid, gname in enumerate(names):
+        e, o, _, _, g = eng(gname)
+        idx = [i for i in range(len(z["start"])) if z["grid_id"][i] == gid]
+        avoid = [gio.csr_get(z["avoid_off"], z["avoid"], i) if z["has_avoid"][i] else None for i in idx]
+        paths, st, cnt = e.astar_host(2, z["start"][idx], z["target"][idx], avoid, want_counters=True)
+        for j, i in enumerate(idx):
+            want = gio.csr_get(z["path_off"], z["path"], i)
+            assert st[j] != 3 and np.array_equal(paths[j], want), (gname, i)
+            if len(want) > 1:
+                assert cnt[j, 0] == z["pops"][i] and cnt[j, 1] == z["pushes"][i], (gname, i, cnt[j], z["pops"][i], z["pushes"][i])
+        if g.shape[0] <= 20:
+            C = g.shape[1]
+            d = pathfit.DijkstraSolver(g, engine=e)
+            for j, i in enumerate(idx[:12]):
+                s_, t_ = int(z["start"][i]), int(z["target"][i])
+                av = {(int(a) // C, int(a) % C) for a in avoid[j]} if avoid[j] is not None else None
+                res = d.solve((s_ // C, s_ % C), (t_ // C, t_ % C), av)
+                want = gio.csr_get(z["path_off"], z["path"], i)
+                assert [r * C + c for r, c in res[0]] == list(want)
+                ws = z["stats"][i]
+                assert all((a == b) or (math.isinf(a) and math.isinf(b)) for a, b in zip(res[1:6], ws)), (gname, i, res[1:], ws)
+
+
 def test_astar_random_512_vs_oracle():
     e, o, s, t, g = eng("up2:g256")
     rnd = np.random.default_rng(5)

@@ -60,6 +60,22 @@ def test_astar_both_variants():
             assert st[0] == z["pops"][i] and st[1] == z["pushes"][i], i
 
 
+def test_dijkstra_solver():
+    """DijkstraSolver.solve (dijkstra.py:32-97) = variant 2 of the restated connector."""
+    z = gio.load("dijkstra_cases")
+    names = [str(s) for s in z["grid_names"]]
+    n = len(z["start"])
+    assert n > 100
+    for i in range(n):
+        o, _, _ = orc(names[int(z["grid_id"][i])])
+        avoid = gio.csr_get(z["avoid_off"], z["avoid"], i) if z["has_avoid"][i] else None
+        path, st = o.astar(int(z["start"][i]), int(z["target"][i]), avoid, 2)
+        want = gio.csr_get(z["path_off"], z["path"], i)
+        assert np.array_equal(path, want), (i, names[int(z["grid_id"][i])])
+        if len(want) != 1 and not (len(want) == 0 and z["pops"][i] == 0):
+            assert st[0] == z["pops"][i] and st[1] == z["pushes"][i], i
+
+
 def test_decode_and_score():
     z = gio.load("decode_cases")
     names = [str(s) for s in z["grid_names"]]
