@@ -760,9 +760,17 @@ __global__ void k_tau_deposit(double* tau, const uint8_t* occ, int RC, const uns
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       unsigned long long x = b[u];
+      const double* dw = dep + (w0 + u) * 64;
+      touched |= x != 0;
       while (x) {
-        const int j = __builtin_ctzll(x); x &= x - 1;
-        t += dep[(w0 + u) * 64 + j]; touched = true;
+        // four deposits per trip: the loads go out together, the adds stay in ant order (adding the 0.0 of an
+        // absent fourth/third/second ant leaves the positive sum unchanged)
+        const int j0 = __builtin_ctzll(x); x &= x - 1;
+        const bool h1 = x != 0; const int j1 = h1 ? __builtin_ctzll(x) : j0; x &= x - 1;
+        const bool h2 = x != 0; const int j2 = h2 ? __builtin_ctzll(x) : j0; x &= x - 1;
+        const bool h3 = x != 0; const int j3 = h3 ? __builtin_ctzll(x) : j0; x &= x - 1;
+        const double d0 = dw[j0], d1 = dw[j1], d2 = dw[j2], d3 = dw[j3];
+        t += d0; t += h1 ? d1 : 0.0; t += h2 ? d2 : 0.0; t += h3 ? d3 : 0.0;
       }
     }
   }
