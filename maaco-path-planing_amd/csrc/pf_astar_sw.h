@@ -319,6 +319,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     // and no earlier head was the target: exactly the pops, in order, that the sequential loop would make.  A head
     // that does not qualify simply stays in the window.
     constexpr int NH = 7;
+    static_assert(NH == 7, "the lane <-> (group, sub) and lane <-> (head pair) maps below are written for 7 x 9 lanes");
     const int nh = W.wn - W.wp < NH ? W.wn - W.wp : NH;
     // the head cells feed the load addresses: v_readlane + select has none of the LDS crossbar's latency
     int prc = bcast_i(W.wc, W.wp);
