@@ -41,24 +41,51 @@ PF_DEV int wave_down_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 
 PF_DEV double wave_up_d(double v) { return __hiloint2double(wave_up_i(__double2hiint(v)), wave_up_i(__double2loint(v))); }
 PF_DEV double wave_down_d(double v) { return __hiloint2double(wave_down_i(__double2hiint(v)), wave_down_i(__double2loint(v))); }
 
-// one compare-exchange stage of a bitonic network: partner = lane ^ j, ascending where `up`
-PF_DEV void cmpx(double& f, double& g, int& c, int lane, int j, bool up) {
-  const int p = lane ^ j;
-  const double pf_ = bperm_d(p, f), pg_ = bperm_d(p, g);
-  const int pc_ = bperm_i(p, c);
-  const bool lower = (lane & j) == 0;
+// value of lane ^ J: inside a 16-lane row by DPP (no LDS crossbar round trip), across rows by ds_bpermute
+template <int J>
+PF_DEV int xor_lane_i(int v, int lane) {
+  if (J == 1) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
+  if (J == 2) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);        // quad_perm [2,3,0,1]
+  if (J == 4) {
+    const int up = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xF, 0xF, false);         // row_shl:4  lane i <- i + 4
+    const int dn = __builtin_amdgcn_update_dpp(v, v, 0x114, 0xF, 0xF, false);         // row_shr:4  lane i <- i - 4
+    return (lane & 4) ? dn : up;
+  }
+  if (J == 8) return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xF, false);       // row_ror:8
+  return __builtin_amdgcn_ds_bpermute((lane ^ J) << 2, v);
+}
+// one compare-exchange stage of a bitonic network: partner = lane ^ J, ascending where `up`
+template <int J>
+PF_DEV void cmpx(double& f, double& g, int& c, int lane, bool up) {
+  const double pf_ = __hiloint2double(xor_lane_i<J>(__double2hiint(f), lane), xor_lane_i<J>(__double2loint(f), lane));
+  const double pg_ = __hiloint2double(xor_lane_i<J>(__double2hiint(g), lane), xor_lane_i<J>(__double2loint(g), lane));
+  const int pc_ = xor_lane_i<J>(c, lane);
+  const bool lower = (lane & J) == 0;
   const bool take = (lower == up) ? key_lt(pf_, pg_, pc_, f, g, c) : key_lt(f, g, c, pf_, pg_, pc_);
   if (take) { f = pf_; g = pg_; c = pc_; }
 }
+// bitonic merge of blocks of K lanes (compile-time strides: the lane masks fold to constants)
+template <int K>
+PF_DEV void merge_block(double& f, double& g, int& c, int lane) {
+  const bool up = (lane & K) == 0;
+  if (K >= 64) cmpx<32>(f, g, c, lane, up);
+  if (K >= 32) cmpx<16>(f, g, c, lane, up);
+  if (K >= 16) cmpx<8>(f, g, c, lane, up);
+  if (K >= 8) cmpx<4>(f, g, c, lane, up);
+  if (K >= 4) cmpx<2>(f, g, c, lane, up);
+  cmpx<1>(f, g, c, lane, up);
+}
 // sort the first n2 (power of two) lanes ascending; unused lanes must hold f = +inf
 PF_DEV void sort_lanes(double& f, double& g, int& c, int lane, int n2) {
-  for (int k = 2; k <= n2; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) cmpx(f, g, c, lane, j, (lane & k) == 0);
+  if (n2 >= 2) merge_block<2>(f, g, c, lane);
+  if (n2 >= 4) merge_block<4>(f, g, c, lane);
+  if (n2 >= 8) merge_block<8>(f, g, c, lane);
+  if (n2 >= 16) merge_block<16>(f, g, c, lane);
+  if (n2 >= 32) merge_block<32>(f, g, c, lane);
+  if (n2 >= 64) merge_block<64>(f, g, c, lane);
 }
 // 64 lanes holding a bitonic sequence -> ascending
-PF_DEV void merge_lanes(double& f, double& g, int& c, int lane) {
-  for (int j = 32; j > 0; j >>= 1) cmpx(f, g, c, lane, j, true);
-}
+PF_DEV void merge_lanes(double& f, double& g, int& c, int lane) { merge_block<64>(f, g, c, lane); }
 
 #define PF_SW_SPILL 16384
 struct SwPool {
