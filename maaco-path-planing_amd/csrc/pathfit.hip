@@ -1381,7 +1381,7 @@ float pf_last_kernel_ms(pf_handle* h) { return h->last_ms; }
 // ---- scratch / launch helpers ----------------------------------------------
 // resident agent slots per CU and LDS bin capacity; PF_SLOTS_PER_CU / PF_LDS_S override for experiments
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; }
-static const int kSlotsPerCU = 16;                      // 4 waves/CU x 4 agents (16-lane path); 64-lane kernels use <= 8
+static const int kSlotsPerCU = 8;                       // resident one-agent waves per CU at most (the 4-agents-per-wave experiment runs 2 waves/CU on them)
 static const int kWavesPerCU = env_int("PF_WAVES_PER_CU", 8);   // resident one-agent waves per CU (LDS permitting)
 static const int kUse16 = env_int("PF_USE16", 1);      // PF_USE16=0 forces the one-agent-per-wave kernels
 // measured r01: the lockstep-gang form is SLOWER than one agent per wave on heterogeneous searches (211 vs 450
