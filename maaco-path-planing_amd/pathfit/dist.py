@@ -197,12 +197,16 @@ class ShardedMPA:
         # global list order (position -> global storage id); starts as the identity like the reference's list
         self.gorder = np.arange(self.N)
         self._fit_all = None
+        self._sorted = False              # gorder reflects the current stats (set by the sort that ends a step)
 
     def _resort(self):
+        if self._sorted:                  # MPA.py:333 right after :412 of the previous iteration: nothing changed
+            return
         m, c = self.local, self.comm
         fit_local = m._stats_host[:, 4]
         self._fit_all = c.all_gather_concat(fit_local, self.counts)
         self.gorder = self.gorder[np.argsort(self._fit_all[self.gorder], kind="stable")]
+        self._sorted = True
 
     def _local_view(self):
         """gidx / slot arrays of the predators stored on this rank, in global-position order."""
@@ -237,5 +241,6 @@ class ShardedMPA:
                    m.d_cand_cells, m.d_cand_len, m.d_cand_stats, m.d_c2_cells, m.d_c2_len, m.d_c2_stats, m.d_status)
         m._check_overflow()
         m._stats_host = m.d_stats.download()
+        self._sorted = False
         self._resort()                                                # :412
         return self._fit_all[self.gorder[0]]
