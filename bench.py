@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- agent-fitness-evals/sec on a 512x512 grid (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--workload mpa512|maaco512|pso512|ga512]
+    python bench.py --gpus N --steps K --warmup W [--workload mpa512|maaco512|pso512|ga512|maaco128|maaco1024]
 
 Workload at N=1 (default `mpa512`) = BASELINE.json configs[2]: MPA, 4096
 predators on G512 (np.kron 2x of the reference's 256x256 map), main.py:44-52
@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="mpa512", choices=["mpa512", "maaco512", "pso512", "ga512"])
+    ap.add_argument("--workload", default="mpa512", choices=["mpa512", "maaco512", "pso512", "ga512", "maaco128", "maaco1024"])
     ap.add_argument("--agents", type=int, default=0, help="agents per GPU (default: the config's)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
@@ -84,7 +84,8 @@ def main():
     from pathfit.dist import Comm, ShardedMPA, ShardedMAACO
 
     comm = Comm(dist, torch.device("cuda", local_rank) if (dist is not None and a.backend == "nccl") else None)
-    grid = env.bench_grid(512)
+    gsize = 128 if a.workload.endswith("128") else (1024 if a.workload.endswith("1024") else 512)
+    grid = env.bench_grid(gsize)
     eng = pathfit.Engine(grid, device=local_rank)
     K, W = a.steps, a.warmup
 
@@ -124,11 +125,13 @@ def main():
                 e.mpa_iter = orig
         cfg = {"workload": "MPA 4096 predators/GPU, 512x512 G512 (BASELINE.json configs[2]), main.py:44-52 params, phase-1 iterations",
                "agents_per_gpu": per_gpu, "grid": "G512=kron2(G256)", "grid_sha256": env.grid_hash(grid)[:16]}
-    elif a.workload == "maaco512":
-        per_gpu = per_gpu or 16384
+    elif a.workload.startswith("maaco"):
+        # maaco512: 16384 ants/GPU; maaco128 = BASELINE.json configs[1] (256 ants, G128); maaco1024 = configs[4]'s per-GPU
+        # share (8192 ants, G1024)
+        per_gpu = per_gpu or {128: 256, 512: 16384, 1024: 8192}[gsize]
         total = per_gpu * world
         sm = ShardedMAACO(comm, lambda: pathfit.MAACO(grid, total, 100, engine=eng, seed=a.seed, **MAACO_MAIN), total)
-        dominant = "k_maaco_walk8"          # 16384 ants/GPU >= the 8-ants-per-wavefront threshold
+        dominant = "k_maaco_walk8" if per_gpu >= 2048 else "k_maaco_walk"   # 8 ants per wavefront from 2048 ants up
         it = 0
 
         def step():
@@ -148,8 +151,9 @@ def main():
                 sm.step(it)
             finally:
                 eng.maaco_walk = orig
-        cfg = {"workload": "MAACO ants/GPU on 512x512 G512, main.py:34-38 params (walk + ordered pheromone update)",
-               "agents_per_gpu": per_gpu, "grid": "G512=kron2(G256)", "grid_sha256": env.grid_hash(grid)[:16]}
+        cfg = {"workload": f"MAACO ants/GPU on {gsize}x{gsize}, main.py:34-38 params (walk + ordered pheromone update)",
+               "agents_per_gpu": per_gpu, "grid": {128: "G128=random_blocks(seed 128)", 512: "G512=kron2(G256)", 1024: "G1024=kron4(G256)"}[gsize],
+               "grid_sha256": env.grid_hash(grid)[:16]}
     else:
         per_gpu = per_gpu or 2048                     # BASELINE.json configs[3]: 16384 over 8 GPUs
         Wp = 5
@@ -251,7 +255,7 @@ def cpu_baseline(workload, grid, seed, budget_s):
             ref.fads(1, n, ind, CF)
             n += 1
         sample = f"first {n} predators of iteration 1 (phase sweep + memory + FADs), same grid/params/seed"
-    elif workload == "maaco512":
+    elif workload.startswith("maaco"):
         P = po.MaacoParams(alpha=1.0, beta=7.0, rho=0.1, Q=2.5, a_turn=1.0, wh_max=0.9, wh_min=0.2, k_h=0.9, q0_initial=0.5,
                            C0=0.1, num_iterations=100)
         tau, dist = orc.maaco_init(s, t, 0.1)
