@@ -412,24 +412,36 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
       for (int h = 1; h < NH; ++h)
         if (__ballot(push0 && grp < h && fb <= hfb[h])) viol |= 1u << h;
     }
+    // Branch-free form of the sequential rule.  A superseded head (closed-set variants) is transparent: consumed, no
+    // effect, not a pop.  A real head fails if an earlier group pushed at or below its f or it is near an earlier
+    // REAL head; since a head can only take effect when every earlier real head did, testing nearness against all
+    // earlier real heads (not just the committed ones) changes nothing.  Everything below the first failing real head
+    // is consumed; the target, or the step cap, cuts that prefix short.
     const int dr_ = (rce >> 16) - (rch >> 16), dc_ = (rce & 0xFFFF) - (rch & 0xFFFF);
-    const unsigned long long nearm = __ballot(lane < NH * NH && pe < ph && (unsigned)(dr_ + 2) <= 4u && (unsigned)(dc_ + 2) <= 4u);   // bit 7e+h
+    const bool e_stale = SEM == 0 && lane < NH * NH && ((stm >> (9 * pe + 8)) & 1ull);
+    const unsigned long long nearm = __ballot(lane < NH * NH && pe < ph && !e_stale && (unsigned)(dr_ + 2) <= 4u && (unsigned)(dc_ + 2) <= 4u);   // bit 7e+h
     const unsigned tgtm = (unsigned)__ballot(lane < NH && rch == trc);      // bit h: head h is the target
-    unsigned E = 0;                                             // heads whose relaxation takes effect
-    int consumed = 0;
-    bool hit = false;
-    {
-      unsigned long long seen = 0;                              // bit 7e: earlier head e was a real pop
+    unsigned stale7 = 0, na = 0;
 #pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        if (h >= nh) break;
-        if ((stm >> (9 * h + 8)) & 1ull) { consumed += 1; continue; }
-        if (steps >= max_steps || ((viol >> h) & 1u) || (nearm & (seen << h))) break;
-        consumed += 1; steps += 1; seen |= 1ull << (7 * h);
-        if ((tgtm >> h) & 1u) { hit = true; break; }            // astar.py:64 / MPA.py:123: nothing is relaxed
-        E |= 1u << h;
-      }
+    for (int h = 0; h < NH; ++h) {
+      if (SEM == 0) stale7 |= (unsigned)((stm >> (9 * h + 8)) & 1ull) << h;
+      if (h < NH - 1) na |= (unsigned)(nearm >> (7 * h)) & 0x7Fu;
     }
+    const unsigned exist7 = (1u << nh) - 1u;
+    int first = __builtin_ctz((((viol | na) & ~stale7) | ~exist7) | 0x80u);   // first failing real head (or nh)
+    unsigned real = ((1u << first) - 1u) & ~stale7;             // the real pops below it
+    if (real & tgtm) { first = __builtin_ctz(real & tgtm) + 1; real &= (1u << first) - 1u; }   // astar.py:64 / MPA.py:123
+    const int allowed = max_steps - steps;                       // the cap counts real pops (astar.py:58 / MPA.py:118)
+    if (__builtin_popcount(real) > allowed) {
+      unsigned r_ = real; int keep = allowed > 0 ? allowed : 0;
+      while (keep-- > 0) r_ &= r_ - 1;                           // drop the `allowed` lowest real heads ...
+      first = __builtin_ctz(r_);                                 // ... the next one is where the cap stops the loop
+      real &= (1u << first) - 1u;
+    }
+    const int consumed = first;
+    const bool hit = (real & tgtm) != 0;
+    const unsigned E = real & ~tgtm;                            // heads whose relaxation takes effect (nothing is relaxed at the target)
+    steps += __builtin_popcount(real);
     SW_T(t4)
     if (consumed == 0) { status = 2; break; }                   // only the step cap can stop head 0
     W.wp += consumed;
