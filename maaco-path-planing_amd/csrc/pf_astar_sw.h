@@ -471,10 +471,23 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     push32 += (unsigned)__builtin_popcountll(SEM == 0 ? __ballot(push && !in_open) : pm);   // heappush calls of the reference
     SW_T(t5)
     unsigned long long im = im0;
+    const unsigned long long dkm = SEM == 0 ? __ballot(push && in_open) : 0ull;   // decrease-keys among the pushes
     while (im) {
       const int l = __builtin_ctzll(im); im &= im - 1;
+      const int kc = bcast_i(nrc, l);
+      if (SEM == 0 && ((dkm >> l) & 1ull)) {
+        // decrease-key (astar.py:96-100): if the entry it supersedes is in the window, take it out now instead of
+        // dropping it when it reaches the head (it would cost a head slot and a batch of loads)
+        const unsigned long long qm = __ballot(lane >= W.wp && lane < W.wn && W.wc == kc);
+        if (qm) {
+          const int q = __builtin_ctzll(qm);
+          const double sf = wave_down_d(W.wf), sg = wave_down_d(W.wg); const int sc = wave_down_i(W.wc);
+          if (lane >= q && lane < W.wn - 1) { W.wf = sf; W.wg = sg; W.wc = sc; }
+          W.wn -= 1;
+        }
+      }
       // (an eviction inside this loop may have lowered the limit below this key: sw_add re-checks)
-      if (!sw_add(P, W, bcast_d(fnew, l), bcast_d(tent, l), bcast_i(nrc, l), lane)) { status = 3; break; }
+      if (!sw_add(P, W, bcast_d(fnew, l), bcast_d(tent, l), kc, lane)) { status = 3; break; }
     }
     if (status == 3) break;
     SW_T(t6)
