@@ -1099,6 +1099,169 @@ __global__ __launch_bounds__(64) void k_mpa_fads(MpaFadsArgs p) {
 // Fused sweep: phase items [0,n) and FADs candidate items [n,2n) share one longest-first work queue, so an
 // iteration pays ONE tail instead of two (the FADs candidates are population independent).
 struct MpaSweepArgs { MpaPhaseArgs ph; MpaFadsArgs fd; };
+
+// One item of the fused sweep: phase item (item < n) or FADs candidate item.  Same arithmetic as mpa_phase_item /
+// mpa_fads_item (candidate mode), restated so that both kinds run their (up to) two chained searches through ONE
+// astar<1> call site: the pop loop is the kernel's hot code, and three inlined copies of it (one per call site)
+// did not fit the instruction cache shared by the waves of two CUs.
+__device__ void mpa_sweep_item(const MpaSweepArgs& q, int item, Slot& s, const Open& O, AStat& tot,
+                               unsigned long long& cells, unsigned long long& ovf, int lane) {
+  const MpaPhaseArgs& p = q.ph;
+  const MpaFadsArgs& f = q.fd;
+  const Grid& G = p.c.G;
+  const int RC = G.R * G.C;
+  const bool isph = item < p.n;
+  const int a = isph ? item : item - p.n;
+  // ---- the plan: searches astart -> g0 (skipped when g0 < 0) then -> g1, appended at buf[n-1..] ----
+  bool search = false;
+  int astart = 0, g0 = -1, g1 = p.m.target, n = 0, rc = 4;
+  int* buf = nullptr;
+  // phase state
+  const int* mod = nullptr; int modL = 0; const double* mod_stats = nullptr;
+  int* out = nullptr;
+  // FADs state
+  int slot = 0; bool have = false, have_stats = false;
+  if (isph) {
+    const int gi = p.gidx[a];                                    // index in the fitness-sorted population
+    slot = p.slot[a];
+    const int* prey = p.pop_cells + (size_t)slot * p.path_cap;
+    const int preyL = p.pop_len[slot];
+    const double* prey_stats = p.pop_stats + (size_t)slot * 5;
+    out = p.out_cells + (size_t)a * p.path_cap;
+    bool is_levy; double scale; const int* ref; int refL;
+    if (p.phase == 1) { is_levy = false; scale = p.m.P; mod = prey; modL = preyL; mod_stats = prey_stats; ref = p.elite_cells; refL = p.elite_len; }
+    else if (p.phase == 2) {
+      is_levy = gi < p.m.N / 2;                                   // :351
+      scale = is_levy ? p.m.P : p.m.P * p.CF;                     // :354
+      mod = is_levy ? prey : p.elite_cells; modL = is_levy ? preyL : p.elite_len;
+      mod_stats = is_levy ? prey_stats : p.elite_stats;
+      ref = is_levy ? p.elite_cells : prey; refL = is_levy ? p.elite_len : preyL;
+    } else { is_levy = true; scale = p.m.P * p.CF; mod = p.elite_cells; modL = p.elite_len; mod_stats = p.elite_stats; ref = prey; refL = preyL; }
+    const double gate_p = p.phase == 1 ? p.m.P : scale;           // :344 / :359 / :372
+    n = modL;                                                     // default: the unmodified path + its stats
+    Rng g; g.init(p.seed, DOM_MPA, (unsigned long long)p.iter, (unsigned long long)gi);
+    if (modL > 1) {
+      const int idx = (int)g.randint(0, modL - 2);                // :343 / :358 / :371
+      if (g.random() < gate_p) {
+        // ---- _reconstruct_path_segment(mod, ref, idx, is_levy, scale) ----
+        slot_begin_eval(s, RC, lane);
+        const int cur = mod[idx];
+        mark_avoid(s, mod, idx, lane);                            // set(prefix[:-1]) :290
+        int inter;
+        if (is_levy) inter = levy_target(g, G, cur, scale, p.m.levy_beta, p.m.sigma);
+        else {
+          int en = -1;
+          if (refL > 0) en = ref[(int)g.randbelow((unsigned long long)refL)];   // random.choice :248
+          inter = brownian_target(g, G, cur, en, scale);
+        }
+        bool pruned = false;                                      // exact pruning: see mpa_phase_item
+        if (p.m.dt) {
+          double pre = 0.0;
+          for (int i = lane; i < idx; i += 64) {
+            const int dd = mod[i + 1] - mod[i];
+            pre += (dd == 1 || dd == -1 || dd == G.C || dd == -G.C) ? 1.0 : PF_SQRT2;
+          }
+          pre = wave_sum_d(pre);
+          double lb = p.m.dt[cur];
+          if (G.occ[inter] != 1 && inter != cur) {
+            const int r0 = row_of(G, cur), r1 = row_of(G, inter);
+            const long dr_ = r1 - r0, dc_ = (inter - r1 * G.C) - (cur - r0 * G.C);
+            lb = fmin(lb, __builtin_sqrt((double)(dr_ * dr_ + dc_ * dc_)) + p.m.dt[inter]);
+          }
+          lb = (pre + lb) * (1.0 - 1e-9);
+          const double prey_fit = prey_stats[4];
+          pruned = lb >= prey_fit && (mod == prey || mod_stats[4] >= prey_fit);
+        }
+        if (pruned) ovf += 1ull << 32;
+        else if (idx + 1 > p.path_cap) rc = 3;
+        else {
+          copy_path(out, mod, idx + 1, lane);                     // :296
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          search = true; buf = out; n = idx + 1; astart = cur; rc = 0;
+          g0 = (G.occ[inter] != 1 && inter != cur) ? inter : -1;  // :298
+        }
+      }
+    }
+  } else {
+    buf = f.cand_cells + (size_t)a * f.path_cap;
+    const int gi = f.gidx[a];
+    slot = f.slot[a];
+    Rng g; g.init(f.seed, DOM_MPA_FADS, (unsigned long long)f.iter, (unsigned long long)gi);
+    if (g.random() < f.m.fads) {                                   // :389
+      slot_begin_eval(s, RC, lane);
+      if (g.random() < f.CF) {                                     // :390
+        const int rr_ = (int)g.randint(0, G.R - 1);                // :391
+        const int rc_ = (int)g.randint(0, G.C - 1);
+        const int node = rr_ * G.C + rc_;
+        bool pruned = false;                                       // exact pruning: see mpa_fads_item
+        if (f.m.dt && G.occ[node] != 1) {
+          pruned = (f.m.ds[node] + f.m.dt[node]) * (1.0 - 1e-9) >= f.pop_stats[(size_t)slot * 5 + 4];
+          if (pruned) ovf += 1ull << 32;
+        }
+        if (G.occ[node] != 1 && !pruned) { search = true; n = 1; astart = f.m.start; g0 = node; }   // :393-394
+      } else if (f.init_len > 0) {                                 // :405 re-init path (memoised)
+        if (f.init_len > f.path_cap) rc = 3;
+        else { copy_path(buf, f.init_cells, f.init_len, lane); n = f.init_len; have = true; have_stats = true; }
+      }
+    }
+  }
+  // ---- the searches (the one astar<1> call site of the kernel) ----
+  if (search) {
+    const int cap = p.path_cap;
+    for (int seg = 0; seg < 2; ++seg) {
+      if (isph && (seg == 0 ? g0 < 0 : astart == g1)) continue;   // :298 / :306
+      int mlen = 0;
+#ifdef PF_TRACE
+      const unsigned long long pq0 = tot.pops;
+      if (!isph && seg == 0 && lane == 0 && a < 8192) { g_trace3[4 * (p.n + a)] = 1; g_trace3[4 * (p.n + a) + 1] = g0; }
+#endif
+      const int r2 = astar<1>(G, s, O, astart, seg == 0 ? g0 : g1, buf + n - 1, cap - (n - 1), mlen, tot, lane);
+#ifdef PF_TRACE
+      if (lane == 0 && item < 16384) { g_trace2[4 * item + 2 * seg] = tot.pops - pq0; g_trace2[4 * item + 2 * seg + 1] = 100 + r2; }
+#endif
+      if (r2 == 3) { rc = 3; break; }
+      if (isph) {
+        if (r2 == 0 && mlen > 1) {                                // :300-305 / :308-309
+          if (seg == 0) { mark_avoid(s, buf + n, mlen - 1, lane); astart = g0; }
+          n += mlen - 1;
+        }
+      } else {
+        if (!(r2 == 0 && mlen > 0)) break;                        // :395 / :397
+        if (seg == 0) { mark_avoid(s, buf, mlen - 1, lane); astart = g0; n = mlen; }   // set(p1[:-1]) :396
+        else { n += mlen - 1; have = true; }                      // :398-400 (last is the target by construction)
+      }
+    }
+  }
+  // ---- score and hand over ----
+  if (isph) {
+    bool rebuilt = false;
+    if (search && rc != 3) {
+      // :310-315 dedup is a no-op (see k_decode_batch); :316-317 endpoint check
+      const int first = out[0], last = out[n - 1];
+      if (first != p.m.start || last != p.m.target) rc = 4; else { rc = 0; rebuilt = true; }
+    }
+    double sc[5];
+    if (rebuilt) score_path(G, p.sp, out, n, lane, sc);
+    else if (rc != 3) {
+      n = modL;
+      copy_path(out, mod, modL, lane);
+      for (int i = 0; i < 5; ++i) sc[i] = mod_stats[i];
+      if (modL == 0) { sc[0] = PF_INF; sc[1] = 0; sc[2] = 0; sc[3] = 0; sc[4] = PF_INF; }
+    } else n = 0;
+    if (lane == 0) { p.out_len[a] = n; p.status[a] = rc; }
+    if (rc != 3 && lane < 5) p.out_stats[(size_t)a * 5 + lane] = sc[lane];
+  } else {
+    if (!have) n = 0;
+    if (have) {
+      double sc[5];
+      if (have_stats) { for (int i = 0; i < 5; ++i) sc[i] = f.init_stats[i]; }
+      else score_path(G, f.sp, buf, n, lane, sc);
+      if (lane < 5) f.cand_stats[(size_t)a * 5 + lane] = sc[lane];
+    }
+    if (lane == 0) f.cand_len[a] = have ? n : 0;
+  }
+  cells += n; ovf += rc == 3;
+}
 __global__ __launch_bounds__(64) void k_mpa_sweep(MpaSweepArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = lane_id();
@@ -1112,8 +1275,7 @@ __global__ __launch_bounds__(64) void k_mpa_sweep(MpaSweepArgs p) {
 #ifdef PF_TRACE
     const unsigned long long tr0 = wall_clock64(), pp0 = tot.pops;
 #endif
-    if (item < p.ph.n) mpa_phase_item(p.ph, item, s, O, tot, cells, ovf, lane);
-    else mpa_fads_item(p.fd, item - p.ph.n, s, O, tot, cells, ovf, lane);
+    mpa_sweep_item(p, item, s, O, tot, cells, ovf, lane);
 #ifdef PF_TRACE
     if (lane == 0 && item < 16384) {
       g_trace[4 * item] = tr0; g_trace[4 * item + 1] = wall_clock64(); g_trace[4 * item + 2] = tot.pops - pp0; g_trace[4 * item + 3] = blockIdx.x;
