@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64) void k_astar_batch(AstarArgs p) {
   const int RC = p.c.G.R * p.c.G.C;
   Open O = make_open(smem, p.c.S, p.c.tier2);
   Slot s = slot_load(p.c, RC);
-  AStat tot = {0, 0, 0, 0, 0};
+  AStat tot = {0, 0, 0, 0, 0, 0};
   unsigned long long cells = 0, ovf = 0;
   for (;;) {
     const int a = next_agent(p.c, p.n, lane);
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64) void k_astar_batch(AstarArgs p) {
       const long long b = p.avoid_off[a], e = p.avoid_off[a + 1];
       mark_avoid(s, p.avoid_cells + b, (int)(e - b), lane);
     }
-    AStat st = {0, 0, 0, 0, 0};
+    AStat st = {0, 0, 0, 0, 0, 0};
     int n = 0;
     const int rc = astar<VARIANT>(p.c.G, s, O, p.start[a], p.target[a], p.cells + (size_t)a * p.path_cap,
                                   p.path_cap, n, st, lane);
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64) void k_astar_batch16(AstarArgs p) {
   const int slot = blockIdx.x * 4 + rgrp();
   Open16 O = make_open16(smem, p.c.tier2 + (size_t)slot * PF_POOL_STRIDE);
   Slot s = slot_load16(p.c, RC);
-  AStat tot = {0, 0, 0, 0, 0};
+  AStat tot = {0, 0, 0, 0, 0, 0};
   unsigned long long cells = 0, ovf = 0;
   for (;;) {
     const int a = next_agent16(p.c, p.n);
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64) void k_astar_batch16(AstarArgs p) {
         const long long b = p.avoid_off[a], e = p.avoid_off[a + 1];
         mark_avoid16(s, p.avoid_cells + b, (int)(e - b));
       }
-      AStat st = {0, 0, 0, 0, 0};
+      AStat st = {0, 0, 0, 0, 0, 0};
       int n = 0;
       const int rc = astar16<VARIANT>(p.c.G, s, O, p.start[a], p.target[a], p.cells + (size_t)a * p.path_cap, p.path_cap, n, st);
       if (rlane() == 0) {
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64) void k_decode_batch(DecodeArgs p) {
   const int RC = G.R * G.C;
   Open O = make_open(smem, p.c.S, p.c.tier2);
   Slot s = slot_load(p.c, RC);
-  AStat tot = {0, 0, 0, 0, 0};
+  AStat tot = {0, 0, 0, 0, 0, 0};
   unsigned long long cells = 0, ovf = 0;
   for (;;) {
     const int a = next_agent(p.c, p.n, lane);
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(64) void k_decode_batch16(DecodeArgs p) {
   const int slot = blockIdx.x * 4 + rgrp();
   Open16 O = make_open16(smem, p.c.tier2 + (size_t)slot * PF_POOL_STRIDE);
   Slot s = slot_load16(p.c, RC);
-  AStat tot = {0, 0, 0, 0, 0};
+  AStat tot = {0, 0, 0, 0, 0, 0};
   unsigned long long cells = 0, ovf = 0;
   for (;;) {
     const int a = next_agent16(p.c, p.n);
@@ -978,7 +978,7 @@ __global__ __launch_bounds__(64) void k_mpa_phase(MpaPhaseArgs p) {
   const int lane = lane_id();
   Open O = make_open(smem, p.c.S, p.c.tier2);
   Slot s = slot_load(p.c, p.c.G.R * p.c.G.C);
-  AStat tot = {0, 0, 0, 0, 0};
+  AStat tot = {0, 0, 0, 0, 0, 0};
   unsigned long long cells = 0, ovf = 0;
   for (;;) {
     const int a = next_agent(p.c, p.n, lane);
@@ -1085,7 +1085,7 @@ __global__ __launch_bounds__(64) void k_mpa_fads(MpaFadsArgs p) {
   const int lane = lane_id();
   Open O = make_open(smem, p.c.S, p.c.tier2);
   Slot s = slot_load(p.c, p.c.G.R * p.c.G.C);
-  AStat tot = {0, 0, 0, 0, 0};
+  AStat tot = {0, 0, 0, 0, 0, 0};
   unsigned long long cells = 0, ovf = 0;
   for (;;) {
     const int a = next_agent(p.c, p.n, lane);
@@ -1267,7 +1267,7 @@ __global__ __launch_bounds__(64) void k_mpa_sweep(MpaSweepArgs p) {
   const int lane = lane_id();
   Open O = make_open(smem, p.ph.c.S, p.ph.c.tier2);
   Slot s = slot_load(p.ph.c, p.ph.c.G.R * p.ph.c.G.C);
-  AStat tot = {0, 0, 0, 0, 0};
+  AStat tot = {0, 0, 0, 0, 0, 0};
   unsigned long long cells = 0, ovf = 0;
   for (;;) {
     const int item = next_agent(p.ph.c, 2 * p.ph.n, lane);
