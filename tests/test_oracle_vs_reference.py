@@ -19,7 +19,7 @@ def env():
 
 def test_astar_random_triples(env):
     rh, po, g = env
-    ra, mpa, orc = rh.RefAStar(g), rh.make_mpa(g), po.Oracle(g)
+    ra, rd, mpa, orc = rh.RefAStar(g), rh.RefDijkstra(g), rh.make_mpa(g), po.Oracle(g)
     rnd = random.Random(2024)
     free = [tuple(x) for x in np.argwhere(g != 1)]
     for t in range(250):
@@ -33,6 +33,9 @@ def test_astar_random_triples(env):
         assert np.array_equal(pc, oc) and (len(pc) <= 1 or (cnt["pops"], cnt["pushes"]) == (st[0], st[1]))
         pc, _, cnt = rh.mpa_astar(mpa, s, e, avoid)
         oc, st = orc.astar(orc.cell(s), orc.cell(e), ac, 1)
+        assert np.array_equal(pc, oc) and (len(pc) <= 1 or (cnt["pops"], cnt["pushes"]) == (st[0], st[1]))
+        pc, _, cnt = rd.solve(s, e, avoid)                      # dijkstra.DijkstraSolver.solve
+        oc, st = orc.astar(orc.cell(s), orc.cell(e), ac, 2)
         assert np.array_equal(pc, oc) and (len(pc) <= 1 or (cnt["pops"], cnt["pushes"]) == (st[0], st[1]))
 
 
