@@ -856,7 +856,7 @@ struct MpaPhaseArgs {
 };
 
 // One predator of one phase sweep, MPA.py:339-377 + _reconstruct_path_segment :284-318.
-__device__ void mpa_phase_item(const MpaPhaseArgs& p, int a, Slot& s, const Open& O, AStat& tot,
+__device__ __forceinline__ void mpa_phase_item(const MpaPhaseArgs& p, int a, Slot& s, const Open& O, AStat& tot,
                                unsigned long long& cells, unsigned long long& ovf, int lane) {
   const Grid& G = p.c.G;
   const int RC = G.R * G.C;
@@ -1005,7 +1005,7 @@ struct MpaFadsArgs {
   int* cand_cells; int* cand_len; double* cand_stats;
 };
 // One predator of the FADs sweep MPA.py:387-410 (in place on the post-memory population, or candidate mode).
-__device__ void mpa_fads_item(const MpaFadsArgs& p, int a, Slot& s, const Open& O, AStat& tot,
+__device__ __forceinline__ void mpa_fads_item(const MpaFadsArgs& p, int a, Slot& s, const Open& O, AStat& tot,
                               unsigned long long& cells, unsigned long long& ovf, int lane) {
   const Grid& G = p.c.G;
   const int RC = G.R * G.C;
@@ -1104,7 +1104,7 @@ struct MpaSweepArgs { MpaPhaseArgs ph; MpaFadsArgs fd; };
 // mpa_fads_item (candidate mode), restated so that both kinds run their (up to) two chained searches through ONE
 // astar<1> call site: the pop loop is the kernel's hot code, and three inlined copies of it (one per call site)
 // did not fit the instruction cache shared by the waves of two CUs.
-__device__ void mpa_sweep_item(const MpaSweepArgs& q, int item, Slot& s, const Open& O, AStat& tot,
+__device__ __forceinline__ void mpa_sweep_item(const MpaSweepArgs& q, int item, Slot& s, const Open& O, AStat& tot,
                                unsigned long long& cells, unsigned long long& ovf, int lane) {
   const MpaPhaseArgs& p = q.ph;
   const MpaFadsArgs& f = q.fd;
@@ -1208,6 +1208,7 @@ __device__ void mpa_sweep_item(const MpaSweepArgs& q, int item, Slot& s, const O
   // ---- the searches (the one astar<1> call site of the kernel) ----
   if (search) {
     const int cap = p.path_cap;
+#pragma unroll 1                                                  // one inlined copy of the pop loop, not two
     for (int seg = 0; seg < 2; ++seg) {
       if (isph && (seg == 0 ? g0 < 0 : astart == g1)) continue;   // :298 / :306
       int mlen = 0;

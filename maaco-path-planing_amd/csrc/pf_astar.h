@@ -184,7 +184,7 @@ PF_DEV int pocket_flood(const Grid& G, const Slot& s, int* lds, int from, int to
 // Returns status (PF_ST_*).  On PF_ST_OK, out[0..out_n) holds the path cells
 // (r*C+c) start..target.  out_cap is the room available at `out`.
 template <int VARIANT>
-__device__ int astar(const Grid& G, Slot& s, const Open& O, int start, int target, int* out, int out_cap,
+__device__ __forceinline__ int astar(const Grid& G, Slot& s, const Open& O, int start, int target, int* out, int out_cap,
                      int& out_n, AStat& st, int lane) {
   // VARIANT 0 AStarSolver.solve (astar.py:33-101), 1 MPA._a_star (MPA.py:106-151), 2 DijkstraSolver.solve
   // (dijkstra.py:32-97: the loop of variant 0 with heap entries (g, node), i.e. h == 0 and key (g, g, node))
