@@ -12,7 +12,7 @@ import bench
 grid = env.bench_grid(512)
 eng = pathfit.Engine(grid)
 eng.L.pf_debug_trace.argtypes = [C.c_void_p, C.c_void_p]
-N = 4096
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 sm = ShardedMPA(Comm(), lambda n: pathfit.MPA(grid, N, 15, engine=eng, seed=0, n_local=n, **bench.MPA_MAIN), N)
 for it in range(1, 4):
     sm.step(it)
