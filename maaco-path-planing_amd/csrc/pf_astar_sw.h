@@ -296,7 +296,15 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
           if (nz) { b0 = W.bcur + base + __builtin_ctzll(nz); break; }
         }
         if (b0 < 0) {                                  // only spilled entries are left (their buckets emptied since)
-          if (W.n_spill == 0 || !respill(P, W, lane)) { status = 3; break; }   // (n_pool > 0 without either: never loop silently)
+          if (W.n_spill == 0) { status = 3; break; }   // (n_pool > 0 with nothing anywhere: never loop silently)
+          // window, front bucket and every regular bucket are empty: the circular range may start at the smallest
+          // spilled key, which brings the entries that were beyond it back in range
+          unsigned minb = 0xFFFFFFFFu;
+          for (int base = 0; base < W.n_spill; base += 64)
+            if (base + lane < W.n_spill) { const unsigned b_ = (unsigned)(int)(P.sf[base + lane] * PF_SW_Q); minb = b_ < minb ? b_ : minb; }
+          minb = wave_min_u32(minb);
+          if ((int)minb > W.bcur) { W.bcur = (int)minb; W.lf = (double)W.bcur * (1.0 / PF_SW_Q); W.lg = -PF_INF; W.lc = 0; }
+          if (!respill(P, W, lane)) { status = 3; break; }
           continue;
         }
         const int cb = P.cnt[(b0 + lane) & (NBK - 1)]; // lane k: size of the k-th bucket from b0 (wraps onto empty ones)
