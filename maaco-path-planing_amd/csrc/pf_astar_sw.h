@@ -23,8 +23,12 @@
 namespace pf {
 
 #define PF_SW_Q 64.0
-#define PF_SW_NBK 256
-#define PF_SW_CAP 1024
+#ifndef PF_SW_NBK
+#define PF_SW_NBK 256     /* circular buckets, a power of two (a stress build with 64 sends far keys through the spill list) */
+#endif
+#ifndef PF_SW_CAP
+#define PF_SW_CAP 1024   /* entries per bucket (a stress build with -DPF_SW_CAP=8 drives everything through the spill list) */
+#endif
 
 PF_DEV bool key_lt(double f1, double g1, int c1, double f2, double g2, int c2) {   // branch-free (f, g, cell) order
   return (f1 < f2) | ((f1 == f2) & ((g1 < g2) | ((g1 == g2) & (c1 < c2))));

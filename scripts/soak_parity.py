@@ -4,6 +4,9 @@ import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "maaco-path-planing_amd"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
 import numpy as np
+if os.environ.get("PF_LIB"):
+    from pathfit import _lib
+    _lib._SO = os.path.abspath(os.environ["PF_LIB"])
 from pathfit.engine import Engine
 from pathfit import env
 import golden_io as gio
