@@ -191,6 +191,10 @@ __device__ __forceinline__ int astar(const Grid& G, Slot& s, const Open& O, int 
   constexpr int SEM = VARIANT == 1 ? 1 : 0;
   static_assert(VARIANT != 2 || PF_LOOP == 2, "the Dijkstra variant is built on the sorted-window loop");
   out_n = 0;
+  // every argument is the same in all 64 lanes, but callers often compute them with vector instructions (a cell
+  // drawn by the lane-replicated RNG, a value loaded from a path): tell the compiler, so the per-search constants
+  // and everything derived from them live in scalar registers and scalar instructions
+  start = first_i(start); target = first_i(target); out_cap = first_i(out_cap);
   const int C = G.C;
   const int sr = row_of(G, start), sc_ = start - sr * C;
   const int tr = row_of(G, target), tc = target - tr * C;
@@ -211,7 +215,7 @@ __device__ __forceinline__ int astar(const Grid& G, Slot& s, const Open& O, int 
   // cells split into components no search can leave, whatever its avoid set.  A goal in another component
   // makes both references pop the start's whole component and return [] (astar.py:103 / MPA.py:151).
   if (G.comp && G.comp[start] != G.comp[target]) return 1;
-  const uint32_t avm = s.avoid_ep;
+  const uint32_t avm = (uint32_t)first_i((int)s.avoid_ep);
   Rec* rec = s.rec;
   // MPA._a_star drops avoid nodes from every neighbour list (MPA.py:82) with no exemption for the goal, so a
   // goal inside the avoid set can never be pushed: the reference then pops the whole reachable region and
@@ -224,7 +228,7 @@ __device__ __forceinline__ int astar(const Grid& G, Slot& s, const Open& O, int 
     if (pocket_flood(G, s, (int*)O.lf, target, start, ex, lane) == 1) return 1;
     if (pocket_flood(G, s, (int*)O.lf, start, target, SEM == 0 ? target : -1, lane) == 1) return 1;
   }
-  s.tag += 1;
+  s.tag = (uint32_t)first_i((int)s.tag) + 1;
   const uint32_t tag = s.tag;
   constexpr int S = PF_S;
   const unsigned long long full = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
