@@ -249,7 +249,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
   W.lf = (double)W.bcur * (1.0 / PF_SW_Q); W.lg = -PF_INF; W.lc = 0;   // keys below (lf, lg, lc) belong to the window
   W.n_pool = 0; W.n_spill = 0;
   int steps = 0, status = 1;
-  unsigned nbr32 = 0, push32 = 1, dk32 = 0;
+  unsigned nbr_l = 0, push_l = 0, dk_l = 0;                  // per-lane event counts, summed over the wave once at the end
   int n_max = 1;
 
   // per-lane constants: seven groups of nine lanes; in a group, lanes 0..7 relax move `sub`, lane 8 reads the
@@ -461,8 +461,8 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     if (eff && sub == 8)                                        // astar.py:74 closed.add / leave the open list
       rec[cur].meta = SEM == 0 ? (cur_meta | PF_M_CLOSED) : (cur_meta & ~PF_M_INOPEN);
     const bool push = push0 && eff;
-    nbr32 += (unsigned)__builtin_popcountll(__ballot(ok && eff));
-    if (SEM == 0) dk32 += (unsigned)__builtin_popcountll(__ballot(better && in_open && eff));
+    nbr_l += (ok && eff) ? 1u : 0u;
+    if (SEM == 0) dk_l += (better && in_open && eff) ? 1u : 0u;
     if (better && eff) {
       Rec wv; wv.g = tent; wv.tagmm = (tag << PF_TAG_SHIFT) | (rn.tagmm & 0xFFu);
       wv.meta = (rn.meta & PF_AVOID_KEEP) | (unsigned)d | (SEM == 1 ? PF_M_INOPEN : 0u);
@@ -480,7 +480,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     if (top && inrange) pat = __hip_atomic_fetch_add(&P.cnt[pb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     const unsigned long long pm = __ballot(push), im0 = __ballot(tow);
     W.n_pool += __builtin_popcountll(pm & ~im0);
-    push32 += (unsigned)__builtin_popcountll(SEM == 0 ? __ballot(push && !in_open) : pm);   // heappush calls of the reference
+    push_l += (push && !(SEM == 0 && in_open)) ? 1u : 0u;       // heappush calls of the reference
     SW_T(t5)
     unsigned long long im = im0;
     const unsigned long long dkm = SEM == 0 ? __ballot(push && in_open) : 0ull;   // decrease-keys among the pushes
@@ -536,7 +536,8 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
   if (lane == 0) for (int i = 0; i < 8; ++i) { atomicAdd(&g_stamps[i], sw_acc[i]); atomicAdd(&g_stamps[8 + i], sw_cnt[i]); }
 #endif
   if (n_max > st.max_open) st.max_open = n_max;
-  st.pops += (unsigned long long)steps; st.pushes += push32; st.nbr += nbr32; st.deckey += dk32;
+  st.pops += (unsigned long long)steps; st.pushes += 1u + (unsigned)wave_sum_i((int)push_l);
+  st.nbr += (unsigned)wave_sum_i((int)nbr_l); st.deckey += (unsigned)wave_sum_i((int)dk_l);
   return status;
 }
 
