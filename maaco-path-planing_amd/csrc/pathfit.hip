@@ -746,35 +746,48 @@ __global__ __launch_bounds__(64) void k_visit_bits(int n, int path_cap, const in
 }
 // per cell: add the deposits of the ants that visited it, in ant order (MAACO.py:306-311
 // is sequential over ants; a cell is visited at most once per ant because of the tabu set)
-__global__ void k_tau_deposit(double* tau, const uint8_t* occ, int RC, const unsigned long long* bits, int nwords,
-                              const double* dep) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= RC) return;
-  double t = tau[i];
+// The cells every ant crosses (around the start) receive one deposit per ant: that thread's 16 384-long ordered sum is
+// the kernel's critical path, and what it waits for is the deposit value of each ant.  The values of a chunk of
+// PF_DEP_CHUNK ants are therefore staged in LDS (128 KB; one 1024-thread block per CU), where a read costs ~64 cycles
+// instead of an L2 round trip.
+#define PF_DEP_CHUNK 16384
+__global__ __launch_bounds__(1024) void k_tau_deposit(double* tau, const uint8_t* occ, int RC, const unsigned long long* bits, int nwords,
+                                                     const double* dep) {
+  extern __shared__ __attribute__((aligned(16))) double sdep[];    // [PF_DEP_CHUNK]
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < RC;
+  double t = live ? tau[i] : 0.0;
   bool touched = false;
-  // the sum must run in ant order, but the (coalesced) word loads need not wait for it: 8 in flight per thread
-  for (int w0 = 0; w0 < nwords; w0 += 8) {
-    unsigned long long b[8];
+  for (int c0 = 0; c0 < nwords; c0 += PF_DEP_CHUNK / 64) {
+    const int cw = nwords - c0 < PF_DEP_CHUNK / 64 ? nwords - c0 : PF_DEP_CHUNK / 64;   // words of this chunk of ants
+    __syncthreads();
+    for (int k = threadIdx.x; k < cw * 64; k += blockDim.x) sdep[k] = dep[c0 * 64 + k];
+    __syncthreads();
+    if (!live) continue;
+    // the sum must run in ant order, but the (coalesced) word loads need not wait for it: 8 in flight per thread
+    for (int w0 = 0; w0 < cw; w0 += 8) {
+      unsigned long long b[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) b[u] = (w0 + u < nwords) ? bits[(size_t)(w0 + u) * RC + i] : 0ull;
+      for (int u = 0; u < 8; ++u) b[u] = (w0 + u < cw) ? bits[(size_t)(c0 + w0 + u) * RC + i] : 0ull;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      unsigned long long x = b[u];
-      const double* dw = dep + (w0 + u) * 64;
-      touched |= x != 0;
-      while (x) {
-        // four deposits per trip: the loads go out together, the adds stay in ant order (adding the 0.0 of an
-        // absent fourth/third/second ant leaves the positive sum unchanged)
-        const int j0 = __builtin_ctzll(x); x &= x - 1;
-        const bool h1 = x != 0; const int j1 = h1 ? __builtin_ctzll(x) : j0; x &= x - 1;
-        const bool h2 = x != 0; const int j2 = h2 ? __builtin_ctzll(x) : j0; x &= x - 1;
-        const bool h3 = x != 0; const int j3 = h3 ? __builtin_ctzll(x) : j0; x &= x - 1;
-        const double d0 = dw[j0], d1 = dw[j1], d2 = dw[j2], d3 = dw[j3];
-        t += d0; t += h1 ? d1 : 0.0; t += h2 ? d2 : 0.0; t += h3 ? d3 : 0.0;
+      for (int u = 0; u < 8; ++u) {
+        unsigned long long x = b[u];
+        const double* dw = sdep + (w0 + u) * 64;
+        touched |= x != 0;
+        while (x) {
+          // four deposits per trip: the LDS reads go out together, the adds stay in ant order (adding the 0.0 of an
+          // absent ant leaves the positive sum unchanged)
+          const int j0 = __builtin_ctzll(x); x &= x - 1;
+          const bool h1 = x != 0; const int j1 = h1 ? __builtin_ctzll(x) : j0; x &= x - 1;
+          const bool h2 = x != 0; const int j2 = h2 ? __builtin_ctzll(x) : j0; x &= x - 1;
+          const bool h3 = x != 0; const int j3 = h3 ? __builtin_ctzll(x) : j0; x &= x - 1;
+          const double d0 = dw[j0], d1 = dw[j1], d2 = dw[j2], d3 = dw[j3];
+          t += d0; t += h1 ? d1 : 0.0; t += h2 ? d2 : 0.0; t += h3 ? d3 : 0.0;
+        }
       }
     }
   }
-  if (touched && occ[i] != 1) tau[i] = t;
+  if (live && touched && occ[i] != 1) tau[i] = t;
 }
 __global__ void k_tau_clip(double* tau, const uint8_t* occ, int RC, double tmin, double tmax) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1983,7 +1996,8 @@ int pf_maaco_deposit(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d
   CK(hipMemsetAsync(h->d_dep, 0, sizeof(double) * words * 64, h->stream));
   hipLaunchKernelGGL(k_visit_bits, dim3(n), dim3(64), 0, h->stream, n, path_cap, d_cells, d_len, d_plen, h->mp.Q, h->d_bits, h->RC, h->d_dep);
   CK(hipGetLastError());
-  hipLaunchKernelGGL(k_tau_deposit, dim3((h->RC + 255) / 256), dim3(256), 0, h->stream, h->d_tau, h->d_occ, h->RC, h->d_bits, (int)words, h->d_dep);
+  CK(hipFuncSetAttribute((const void*)k_tau_deposit, hipFuncAttributeMaxDynamicSharedMemorySize, PF_DEP_CHUNK * (int)sizeof(double)));
+  hipLaunchKernelGGL(k_tau_deposit, dim3((h->RC + 1023) / 1024), dim3(1024), PF_DEP_CHUNK * sizeof(double), h->stream, h->d_tau, h->d_occ, h->RC, h->d_bits, (int)words, h->d_dep);
   CK(hipGetLastError());
   CK(hipStreamSynchronize(h->stream));
   return 0;

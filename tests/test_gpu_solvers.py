@@ -83,6 +83,20 @@ def test_maaco_solve_matches_oracle_loop(beta):
     assert np.array_equal(m.pheromone_matrix, ref["tau"])
 
 
+def test_maaco_20000_ants_deposit_in_two_chunks():
+    """More than 16 384 ants: the ordered deposit stages the ants' values in LDS one 16 384-ant chunk at a time; the
+    pheromone matrix must still be the sequential sum of MAACO.py:306-311 bit for bit."""
+    import pathfit, pf_oracle as po, pf_loops
+    g, s, t = gio.grid("fig7")
+    kw = dict(alpha=1.0, beta=7.0, rho=0.1, Q=2.5, a_turn_coef=1.0, wh_max=0.9, wh_min=0.2, k_h_adaptive=0.9,
+              q0_initial=0.5)
+    m = pathfit.MAACO(g, 20000, 2, C0_initial_pheromone=0.1, seed=3, **kw)
+    path, length, turns = m.solve_path_planning()
+    ref = pf_loops.maaco_solve(po.Oracle(g), s, t, 20000, 2, C0=0.1, seed=3, **kw)
+    assert [r * 20 + c for r, c in path] == list(ref["path"]) and length == ref["length"] and turns == ref["turns"]
+    assert np.array_equal(m.pheromone_matrix, ref["tau"])
+
+
 def test_maaco_alpha_not_one_uses_host_pow_table():
     import pathfit, pf_oracle as po, pf_loops
     g, s, t = gio.grid("fig13")
