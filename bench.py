@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- agent-fitness-evals/sec on a 512x512 grid (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--workload mpa512|maaco512|pso512|ga512|maaco128|maaco1024]
+    python bench.py --gpus N --steps K --warmup W [--workload mpa512|maaco512|pso512|ga512|maaco128|maaco1024|astar1024]
 
 Workload at N=1 (default `mpa512`) = BASELINE.json configs[2]: MPA, 4096
 predators on G512 (np.kron 2x of the reference's 256x256 map), main.py:44-52
@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="mpa512", choices=["mpa512", "maaco512", "pso512", "ga512", "maaco128", "maaco1024"])
+    ap.add_argument("--workload", default="mpa512", choices=["mpa512", "maaco512", "pso512", "ga512", "maaco128", "maaco1024", "astar1024"])
     ap.add_argument("--agents", type=int, default=0, help="agents per GPU (default: the config's)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
@@ -154,6 +154,23 @@ def main():
         cfg = {"workload": f"MAACO ants/GPU on {gsize}x{gsize}, main.py:34-38 params (walk + ordered pheromone update)",
                "agents_per_gpu": per_gpu, "grid": {128: "G128=random_blocks(seed 128)", 512: "G512=kron2(G256)", 1024: "G1024=kron4(G256)"}[gsize],
                "grid_sha256": env.grid_hash(grid)[:16]}
+    elif a.workload == "astar1024":
+        # BASELINE.json configs[4], second part: a standalone batch of seeded (start, target) pairs on G1024 through the
+        # AStarSolver connector (8192 pairs per GPU = 65536 over 8); one eval = one connector solve + path emit
+        per_gpu = per_gpu or 8192
+        rng = np.random.default_rng(a.seed + rank)
+        free = np.flatnonzero(grid.reshape(-1) != 1)
+        cap = 16 * 1024 + 64
+        d_s, d_t = eng.put(rng.choice(free, per_gpu).astype(np.int32)), eng.put(rng.choice(free, per_gpu).astype(np.int32))
+        d_cells, d_len, d_st = eng.buf((per_gpu, cap), np.int32), eng.buf(per_gpu, np.int32), eng.buf(per_gpu, np.int32)
+        dominant = "k_astar_batch"
+
+        def step():
+            nonlocal kern_ms, kern_bytes, launches
+            eng.astar_batch(0, d_s, d_t, per_gpu, cap, d_cells, d_len, d_st)
+            kern_ms += eng.last_kernel_ms(); kern_bytes += astar_bytes(eng.counters()); launches += 1
+        cfg = {"workload": "A* connector batch (AStarSolver semantics), 8192 uniform free-cell pairs/GPU, G1024 (BASELINE.json configs[4] K2a batch)",
+               "agents_per_gpu": per_gpu, "grid": "G1024=kron4(G256)", "grid_sha256": env.grid_hash(grid)[:16]}
     else:
         per_gpu = per_gpu or 2048                     # BASELINE.json configs[3]: 16384 over 8 GPUs
         Wp = 5
@@ -264,6 +281,15 @@ def cpu_baseline(workload, grid, seed, budget_s):
             orc.maaco_walk(s, t, P, tau, dist, 1, seed, n)
             n += 1
         sample = f"first {n} ant walks of iteration 1, same grid/params/seed"
+    elif workload == "astar1024":
+        rng = np.random.default_rng(seed)
+        free = np.flatnonzero(grid.reshape(-1) != 1)
+        ss, tt = rng.choice(free, 8192), rng.choice(free, 8192)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < budget_s and n < 8192:
+            orc.astar(int(ss[n]), int(tt[n]), None, 0)
+            n += 1
+        sample = f"first {n} pairs (AStarSolver connector), same grid and seed"
     else:
         rng = np.random.default_rng(seed)
         free = np.flatnonzero(grid.reshape(-1) != 1)
