@@ -1741,7 +1741,11 @@ int pf_astar_batch(pf_handle* h, int32_t variant, int32_t allow_diag, int32_t re
   const bool use16 = kUse16 && n >= g_use16_min;                     // small batches are latency bound: one agent per wave
   if (variant == PF_ASTAR_REF) return use16 ? launch16_with_fallback(h, k_astar_batch16<0>, k_astar_batch<0>, a, n) : launch_with_retry(h, k_astar_batch<0>, a, n);
   if (variant == PF_ASTAR_MPA) return use16 ? launch16_with_fallback(h, k_astar_batch16<1>, k_astar_batch<1>, a, n) : launch_with_retry(h, k_astar_batch<1>, a, n);
+#if PF_LOOP == 2
   if (variant == PF_ASTAR_DIJKSTRA) return launch_with_retry(h, k_astar_batch<2>, a, n);
+#else
+  if (variant == PF_ASTAR_DIJKSTRA) return failmsg(h, "pf_astar_batch: the Dijkstra variant needs the default (PF_LOOP=2) build");
+#endif
   return failmsg(h, "pf_astar_batch: unknown variant");
 }
 
