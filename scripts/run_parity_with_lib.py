@@ -1,4 +1,5 @@
-"""Run the A* / decode GPU parity tests against an alternative build of the library (A/B builds: -DPF_LOOP=0|1,\nstress builds): PF_LIB=path/to/lib.so python scripts/run_parity_with_lib.py"""
+"""Run the A* / decode GPU parity tests against an alternative build of the library (A/B builds: -DPF_LOOP=0|1,
+stress builds): PF_LIB=path/to/lib.so python scripts/run_parity_with_lib.py"""
 import os, sys
 sys.path[:0] = ["maaco-path-planing_amd", "tests", "oracle"]
 from pathfit import _lib
