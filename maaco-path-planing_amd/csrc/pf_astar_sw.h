@@ -251,6 +251,9 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
   int steps = 0, status = 1;
   unsigned nbr_l = 0, push_l = 0, dk_l = 0;                  // per-lane event counts, summed over the wave once at the end
   int n_max = 1;
+#ifdef PF_TRIPS
+  unsigned tr_short = 0, tr_full = 0, tr_viol = 0, tr_near = 0, tr_pot = 0;
+#endif
 
   // per-lane constants: seven groups of nine lanes; in a group, lanes 0..7 relax move `sub`, lane 8 reads the
   // popped cell itself (lane 63 is idle)
@@ -361,11 +364,13 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     static_assert(NH == 7, "the lane <-> (group, sub) and lane <-> (head pair) maps below are written for 7 x 9 lanes");
     const int nh = W.wn - W.wp < NH ? W.wn - W.wp : NH;
     // the head cells feed the load addresses: v_readlane + select has none of the LDS crossbar's latency
-    int prc = bcast_i(W.wc, W.wp);
+    int hcell[NH];                                              // (r << 16 | c) of head h, wave-uniform
+    hcell[0] = bcast_i(W.wc, W.wp);
+    int prc = hcell[0];
 #pragma unroll
     for (int h = 1; h < NH; ++h) {
-      const int c_ = bcast_i(W.wc, W.wp + h < 64 ? W.wp + h : 63);
-      prc = grp == h ? c_ : prc;
+      hcell[h] = bcast_i(W.wc, W.wp + h < 64 ? W.wp + h : 63);
+      prc = grp == h ? hcell[h] : prc;
     }
     const bool have = grp < nh;                                 // (lane 63 is group 7: never)
     const int pr = prc >> 16, pc = prc & 0xFFFF;
@@ -391,6 +396,30 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     const long hdr = nr - tr, hdc = nc - tc;
     double hn = VARIANT == 2 ? 0.0 : __builtin_sqrt((double)(hdr * hdr + hdc * hdc));   // astar.py:90 / MPA.py:140 / dijkstra.py:89
     asm volatile("" : "+v"(hn));                               // computed in the shadow of the loads
+    // Heads within 2 cells of each other touch common records.  Instead of stopping the trip there, every lane
+    // replays, in head order, what the earlier heads of this trip do to ITS cell: for an earlier head e the lane that
+    // handles the same cell is fixed by geometry (cell - head e in [-1,1]^2 picks e's move lane, or e's self lane = the
+    // pop of that cell).  Source lanes are worked out here, in the shadow of the loads; rows of the pair matrix
+    // without a near pair are skipped (wave-uniform).
+    const int dr_ = (rce >> 16) - (rch >> 16), dc_ = (rce & 0xFFFF) - (rch & 0xFFFF);
+    const unsigned long long nearg = __ballot(lane < NH * NH && pe < ph && ph < nh && (unsigned)(dr_ + 2) <= 4u && (unsigned)(dc_ + 2) <= 4u);   // bit 7e+h
+    const int vr = sub < 8 ? nr : pr, vc = sub < 8 ? nc : pc;     // the cell this lane handles
+    int fsrc[NH - 1];                                            // bpermute address of the lane of head e on my cell (lane 63: none)
+    unsigned popm = 0;                                            // bit e: head e IS my cell (its pop happens before my relaxation)
+#pragma unroll
+    for (int e = 0; e < NH - 1; ++e) {
+      fsrc[e] = 63 * 4;
+      if ((nearg >> (7 * e)) & 0x7Full) {
+        const int a_ = vr - (hcell[e] >> 16) + 1, b_ = vc - (hcell[e] & 0xFFFF) + 1;
+        const bool in_ = grp > e && (unsigned)a_ < 3u && (unsigned)b_ < 3u;
+        const int k_ = a_ * 3 + b_;                              // 0..8 when in_: (dr+1)*3 + (dc+1)
+        const int m_ = (int)((0x425081637ull >> (4 * (k_ & 15))) & 15ull);   // -> move index in helper.py:30-36 order, 8 = the head itself
+        fsrc[e] = in_ ? (9 * e + m_) * 4 : 63 * 4;
+        popm |= (in_ && k_ == 4) ? 1u << e : 0u;
+        asm volatile("" : "+v"(fsrc[e]));
+      }
+    }
+    asm volatile("" : "+v"(popm));
     SW_T(t2)
     // ---- relax the 8 neighbours of each head in registers ----
     const uint32_t cur_meta = rn.meta;
@@ -411,8 +440,44 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     if (SEM == 0) ok = ok && !closed && !(avoided && nidx != start && nidx != target);
     else ok = ok && !avoided;
     const double tent = base_g + cost;
-    const bool better = ok && (!rvalid || tent < rn.g);       // astar.py:87 / MPA.py:137
-    const bool in_open = SEM == 0 ? rvalid : (rvalid && (rn.meta & PF_M_INOPEN));
+    unsigned stale7 = 0;
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+      if (SEM == 0) stale7 |= (unsigned)((stm >> (9 * h + 8)) & 1ull) << h;
+    // ---- replay the earlier heads' effects on my cell (see above), in head order ----
+    double gmin = rvalid ? rn.g : PF_INF;                       // g_score of my cell as head `grp` will find it
+    bool inop = SEM == 0 ? rvalid : (rvalid && (rn.meta & PF_M_INOPEN));
+    bool clsd = false, imp = false;
+    int pred = 63 * 4;                                          // the last earlier lane that writes my cell's record
+    {
+      const double tent_ok = ok ? tent : PF_INF;               // what my relaxation offers my cell (decided statically)
+      double tf[NH - 1];
+#pragma unroll
+      for (int e = 0; e < NH - 1; ++e) {
+        tf[e] = PF_INF;
+        if ((nearg >> (7 * e)) & 0x7Full) {
+          const unsigned long long b_ = dbits(tent_ok);
+          const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(fsrc[e], (int)(unsigned)b_);
+          const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(fsrc[e], (int)(unsigned)(b_ >> 32));
+          tf[e] = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < NH - 1; ++e) {
+        if ((nearg >> (7 * e)) & 0x7Full) {
+          const bool popev = ((popm >> e) & 1u) && !((stale7 >> e) & 1u);   // head e pops my cell (a superseded head does nothing)
+          const bool rel = tf[e] < gmin && !(SEM == 0 && clsd);             // head e's lane improves my cell
+          gmin = rel ? tf[e] : gmin;
+          if (SEM == 0) clsd = clsd || popev; else inop = popev ? false : inop;
+          inop = rel ? true : inop;
+          imp = imp || rel;
+          pred = (rel || popev) ? fsrc[e] : pred;
+        }
+      }
+    }
+    const bool okd = ok && !(SEM == 0 && clsd);                 // astar.py:83 closed set, incl. this trip's earlier pops
+    const bool better = okd && tent < gmin;                     // astar.py:87 / MPA.py:137
+    const bool in_open = inop;
     const bool push0 = SEM == 0 ? better : (better && !in_open);
     const double fnew = tent + hn;                             // astar.py:90 / MPA.py:140
     const int nrc = (nr << 16) | nc;
@@ -429,18 +494,15 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     // REAL head; since a head can only take effect when every earlier real head did, testing nearness against all
     // earlier real heads (not just the committed ones) changes nothing.  Everything below the first failing real head
     // is consumed; the target, or the step cap, cuts that prefix short.
-    const int dr_ = (rce >> 16) - (rch >> 16), dc_ = (rce & 0xFFFF) - (rch & 0xFFFF);
-    const bool e_stale = SEM == 0 && lane < NH * NH && ((stm >> (9 * pe + 8)) & 1ull);
-    const unsigned long long nearm = __ballot(lane < NH * NH && pe < ph && !e_stale && (unsigned)(dr_ + 2) <= 4u && (unsigned)(dc_ + 2) <= 4u);   // bit 7e+h
     const unsigned tgtm = (unsigned)__ballot(lane < NH && rch == trc);      // bit h: head h is the target
-    unsigned stale7 = 0, na = 0;
+    // an earlier head improved head h's OWN cell: its relaxations would start from another g (MPA.py:135) or its entry
+    // is superseded (astar.py:96-100) -- the one effect that is not replayed; the trip stops there
+    const unsigned long long impm = __ballot(sub == 8 && imp);
+    unsigned c1 = 0;
 #pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      if (SEM == 0) stale7 |= (unsigned)((stm >> (9 * h + 8)) & 1ull) << h;
-      if (h < NH - 1) na |= (unsigned)(nearm >> (7 * h)) & 0x7Fu;
-    }
+    for (int h = 1; h < NH; ++h) c1 |= (unsigned)((impm >> (9 * h + 8)) & 1ull) << h;
     const unsigned exist7 = (1u << nh) - 1u;
-    int first = __builtin_ctz((((viol | na) & ~stale7) | ~exist7) | 0x80u);   // first failing real head (or nh)
+    int first = __builtin_ctz((((viol | c1) & ~stale7) | ~exist7) | 0x80u);   // first failing real head (or nh)
     unsigned real = ((1u << first) - 1u) & ~stale7;             // the real pops below it
     if (real & tgtm) { first = __builtin_ctz(real & tgtm) + 1; real &= (1u << first) - 1u; }   // astar.py:64 / MPA.py:123
     const int allowed = max_steps - steps;                       // the cap counts real pops (astar.py:58 / MPA.py:118)
@@ -458,12 +520,15 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     if (consumed == 0) { status = 2; break; }                   // only the step cap can stop head 0
     W.wp += consumed;
     const bool eff = (E >> grp) & 1u;
-    if (eff && sub == 8)                                        // astar.py:74 closed.add / leave the open list
+    // a record written twice in this trip keeps the LAST write: a lane that writes tells the previous writer of its
+    // cell (forward permute; lanes nobody addresses read 0) to keep quiet -- no two lanes store to one address
+    const bool keep = __builtin_amdgcn_ds_permute((better && eff) ? pred : 63 * 4, 1) == 0;
+    if (eff && sub == 8 && keep)                                // astar.py:74 closed.add / leave the open list
       rec[cur].meta = SEM == 0 ? (cur_meta | PF_M_CLOSED) : (cur_meta & ~PF_M_INOPEN);
     const bool push = push0 && eff;
-    nbr_l += (ok && eff) ? 1u : 0u;
+    nbr_l += (okd && eff) ? 1u : 0u;
     if (SEM == 0) dk_l += (better && in_open && eff) ? 1u : 0u;
-    if (better && eff) {
+    if (better && eff && keep) {
       Rec wv; wv.g = tent; wv.tagmm = (tag << PF_TAG_SHIFT) | (rn.tagmm & 0xFFu);
       wv.meta = (rn.meta & PF_AVOID_KEEP) | (unsigned)d | (SEM == 1 ? PF_M_INOPEN : 0u);
       rec[nidx] = wv;
@@ -527,6 +592,14 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
 #endif
 #ifdef PF_TRIPS
     n_max += 1;                                                 // diagnostic build: trips instead of the open-list high-water mark
+    {                                                           // ... and why each trip stopped where it did
+      const int f0 = __builtin_ctz((((viol | c1) & ~stale7) | ~exist7) | 0x80u);
+      if (f0 >= nh) { if (nh < NH) tr_short += 1; else tr_full += 1; }
+      else if ((viol >> f0) & 1u) tr_viol += 1; else tr_near += 1;      // tr_near: an earlier head improved the head's own cell
+      // how far the trip could go if nearness were resolved by forwarding and only an earlier head improving
+      // head h's own cell stopped it (decisions taken from the loaded state: an estimate)
+      tr_pot += (unsigned)f0;
+    }
 #else
     const int n_open = W.n_pool + (W.wn - W.wp);
     if (n_open > n_max) n_max = n_open;
@@ -537,7 +610,11 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
 #endif
   if (n_max > st.max_open) st.max_open = n_max;
   st.pops += (unsigned long long)steps; st.pushes += 1u + (unsigned)wave_sum_i((int)push_l);
+#ifdef PF_TRIPS
+  st.nbr += tr_viol; st.deckey += tr_near; st.spills += tr_pot; (void)tr_full; (void)tr_short; (void)nbr_l; (void)dk_l;
+#else
   st.nbr += (unsigned)wave_sum_i((int)nbr_l); st.deckey += (unsigned)wave_sum_i((int)dk_l);
+#endif
   return status;
 }
 

@@ -19,3 +19,7 @@ for variant in (0, 1):
         paths, st, cnt = e.astar_host(variant, starts, targets, None, path_cap=8192, want_counters=True)
     pops = cnt[:, 0].sum()
     print(f"n={n} v{variant}: {e.last_kernel_ms():.2f} ms, pops {pops}, us/pop(lone wave 0) {1e3 * e.last_kernel_ms() / cnt[0, 0] if n == 1 else 0:.3f}, Mpops/s {pops / e.last_kernel_ms() / 1e3:.1f}, trips-or-maxopen[0] {cnt[0, 2]}, pops/trip {cnt[0, 0] / max(cnt[0, 2], 1):.2f}")
+    if os.environ.get("PF_TRIPS"):      # -DPF_TRIPS build: why trips stopped short of 7 heads
+        c = e.counters()
+        print(f"   trips stopped by: earlier push at/below the head's f {c['nbr_examined']}, head near an earlier head {c['decrease_keys']}, "
+              f"heads per trip if nearness were forwarded (estimate): {c['candidates'] / max(cnt[:, 2].sum(), 1):.2f}")
