@@ -65,7 +65,9 @@ PF_DEV void cmpx(double& f, double& g, int& c, int lane, bool up) {
   const double pg_ = __hiloint2double(xor_lane_i<J>(__double2hiint(g), lane), xor_lane_i<J>(__double2loint(g), lane));
   const int pc_ = xor_lane_i<J>(c, lane);
   const bool lower = (lane & J) == 0;
-  const bool take = (lower == up) ? key_lt(pf_, pg_, pc_, f, g, c) : key_lt(f, g, c, pf_, pg_, pc_);
+  // live keys are distinct (one entry per (cell, g)), so "mine < partner's" is the complement of "partner's < mine";
+  // between two identical padding entries (f = +inf) either answer leaves the lanes unchanged
+  const bool take = key_lt(pf_, pg_, pc_, f, g, c) == (lower == up);
   if (take) { f = pf_; g = pg_; c = pc_; }
 }
 // bitonic merge of blocks of K lanes (compile-time strides: the lane masks fold to constants)
@@ -255,12 +257,12 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
   unsigned tr_short = 0, tr_full = 0, tr_viol = 0, tr_near = 0, tr_pot = 0;
 #endif
 
-  // per-lane constants: seven groups of nine lanes; in a group, lanes 0..7 relax move `sub`, lane 8 reads the
-  // popped cell itself (lane 63 is idle)
-  const int grp = (lane * 57) >> 9, sub = lane - 9 * grp;
-  const int d = sub & 7;
+  // per-lane roles: lane h < 7 reads head h's own record (sub = 8: the "self" lane, so ballots over the self lanes are
+  // 7-bit head masks as they stand); lanes 7 + 8h .. 14 + 8h relax move `sub` of head h; lane 63 is idle (group 7)
+  const int grp0 = lane < 7 ? lane : (lane - 7) >> 3, sub0 = lane < 7 ? 8 : ((lane - 7) & 7);
+  const int d = sub0 & 7;
   const int ddr = move_dr(d), ddc = move_dc(d);
-  const int doff = sub < 8 ? ddr * C + ddc : 0;
+  const int doff = sub0 < 8 ? ddr * C + ddc : 0;
   const double cost = d < 4 ? 1.0 : PF_SQRT2;
   const int trc = (tr << 16) | tc;
 
@@ -363,6 +365,11 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     constexpr int NH = 7;
     static_assert(NH == 7, "the lane <-> (group, sub) and lane <-> (head pair) maps below are written for 7 x 9 lanes");
     const int nh = W.wn - W.wp < NH ? W.wn - W.wp : NH;
+    // The lane-role predicates (grp == h, sub < 8, ...) are recomputed where they are used (one v_cmp each): as
+    // loop invariants they sat in ~25 SGPR pairs, overflowed the scalar register file and came back through two
+    // v_readlane each, >100 instructions per trip.
+    int grp = grp0, sub = sub0, lane_t = lane;
+    asm volatile("" : "+v"(grp), "+v"(sub), "+v"(lane_t));
     // the head cells feed the load addresses: v_readlane + select has none of the LDS crossbar's latency
     int hcell[NH];                                              // (r << 16 | c) of head h, wave-uniform
     hcell[0] = bcast_i(W.wc, W.wp);
@@ -390,10 +397,10 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
 #pragma unroll
     for (int h = 1; h < NH; ++h) hfb[h] = dbits(bcast_d(W.wf, W.wp + h < 64 ? W.wp + h : 63));
     // lanes 0..48 look at the head pair (e, h) = (lane / 7, lane % 7): too close to be independent?
-    const int pe = (lane * 37) >> 8, ph = lane - 7 * pe;
+    const int pe = (lane_t * 37) >> 8, ph = lane_t - 7 * pe;
     const int rce = bperm_i(W.wp + pe < 64 ? W.wp + pe : 63, W.wc), rch = bperm_i(W.wp + ph < 64 ? W.wp + ph : 63, W.wc);
     const int nr = pr + ddr, nc = pc + ddc;
-    const long hdr = nr - tr, hdc = nc - tc;
+    const int hdr = nr - tr, hdc = nc - tc;                    // |.| < 2^15: the squares fit 32 bits
     double hn = VARIANT == 2 ? 0.0 : __builtin_sqrt((double)(hdr * hdr + hdc * hdc));   // astar.py:90 / MPA.py:140 / dijkstra.py:89
     asm volatile("" : "+v"(hn));                               // computed in the shadow of the loads
     // Heads within 2 cells of each other touch common records.  Instead of stopping the trip there, every lane
@@ -402,10 +409,9 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     // pop of that cell).  Source lanes are worked out here, in the shadow of the loads; rows of the pair matrix
     // without a near pair are skipped (wave-uniform).
     const int dr_ = (rce >> 16) - (rch >> 16), dc_ = (rce & 0xFFFF) - (rch & 0xFFFF);
-    const unsigned long long nearg = __ballot(lane < NH * NH && pe < ph && ph < nh && (unsigned)(dr_ + 2) <= 4u && (unsigned)(dc_ + 2) <= 4u);   // bit 7e+h
+    const unsigned long long nearg = __ballot(lane_t < NH * NH && pe < ph && ph < nh && (unsigned)(dr_ + 2) <= 4u && (unsigned)(dc_ + 2) <= 4u);   // bit 7e+h
     const int vr = sub < 8 ? nr : pr, vc = sub < 8 ? nc : pc;     // the cell this lane handles
     int fsrc[NH - 1];                                            // bpermute address of the lane of head e on my cell (lane 63: none)
-    unsigned popm = 0;                                            // bit e: head e IS my cell (its pop happens before my relaxation)
 #pragma unroll
     for (int e = 0; e < NH - 1; ++e) {
       fsrc[e] = 63 * 4;
@@ -413,13 +419,12 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
         const int a_ = vr - (hcell[e] >> 16) + 1, b_ = vc - (hcell[e] & 0xFFFF) + 1;
         const bool in_ = grp > e && (unsigned)a_ < 3u && (unsigned)b_ < 3u;
         const int k_ = a_ * 3 + b_;                              // 0..8 when in_: (dr+1)*3 + (dc+1)
-        const int m_ = (int)((0x425081637ull >> (4 * (k_ & 15))) & 15ull);   // -> move index in helper.py:30-36 order, 8 = the head itself
-        fsrc[e] = in_ ? (9 * e + m_) * 4 : 63 * 4;
-        popm |= (in_ && k_ == 4) ? 1u << e : 0u;
+        const int m_ = (int)((0x425001637ull >> (4 * (k_ & 15))) & 15ull);   // -> move index in helper.py:30-36 order (k_ = 4: the head itself)
+        // bit 0 marks "head e IS my cell": its pop happens before my relaxation (the self lane offers +inf)
+        fsrc[e] = in_ ? (k_ == 4 ? e * 4 + 1 : (7 + 8 * e + m_) * 4) : 63 * 4;
         asm volatile("" : "+v"(fsrc[e]));
       }
     }
-    asm volatile("" : "+v"(popm));
     SW_T(t2)
     // ---- relax the 8 neighbours of each head in registers ----
     const uint32_t cur_meta = rn.meta;
@@ -431,7 +436,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     // reference: its head is consumed without effect and without being counted
     const bool self_stale = SEM == 0 && sub == 8 && ((cur_meta & PF_M_CLOSED) || rn.g != pg);
     const unsigned long long stm = __ballot(have && self_stale);
-    const bool my_stale = (stm >> (9 * grp + 8 < 64 ? 9 * grp + 8 : 63)) & 1ull;
+    const bool my_stale = (stm >> grp) & 1ull;
     const double base_g = SEM == 0 ? pg : cur_g;           // astar.py:85 popped g / MPA.py:135 g_score[current]
     const bool rvalid = (rn.tagmm >> PF_TAG_SHIFT) == tag;
     const bool avoided = (rn.meta >> PF_AVOID_SHIFT) == avm;
@@ -440,22 +445,19 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     if (SEM == 0) ok = ok && !closed && !(avoided && nidx != start && nidx != target);
     else ok = ok && !avoided;
     const double tent = base_g + cost;
-    unsigned stale7 = 0;
-#pragma unroll
-    for (int h = 0; h < NH; ++h)
-      if (SEM == 0) stale7 |= (unsigned)((stm >> (9 * h + 8)) & 1ull) << h;
+    const unsigned stale7 = SEM == 0 ? (unsigned)stm & 0x7Fu : 0u;   // the self lanes are lanes 0..6
     // ---- replay the earlier heads' effects on my cell (see above), in head order ----
-    double gmin = rvalid ? rn.g : PF_INF;                       // g_score of my cell as head `grp` will find it
-    bool inop = SEM == 0 ? rvalid : (rvalid && (rn.meta & PF_M_INOPEN));
-    bool clsd = false, imp = false;
-    int pred = 63 * 4;                                          // the last earlier lane that writes my cell's record
+    const double g0 = rvalid ? rn.g : PF_INF;
+    double gmin = g0;                                           // g_score of my cell as head `grp` will find it
+    bool clsd = false;
+    int pred = 63 * 4;                                          // the last earlier lane that writes my cell's record (bit 0: by popping it)
     {
       const double tent_ok = ok ? tent : PF_INF;               // what my relaxation offers my cell (decided statically)
       double tf[NH - 1];
 #pragma unroll
       for (int e = 0; e < NH - 1; ++e) {
         tf[e] = PF_INF;
-        if ((nearg >> (7 * e)) & 0x7Full) {
+        if (((nearg >> (7 * e)) & 0x7Full) && !((stale7 >> e) & 1u)) {   // (a superseded head does nothing)
           const unsigned long long b_ = dbits(tent_ok);
           const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(fsrc[e], (int)(unsigned)b_);
           const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(fsrc[e], (int)(unsigned)(b_ >> 32));
@@ -464,17 +466,19 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
       }
 #pragma unroll
       for (int e = 0; e < NH - 1; ++e) {
-        if ((nearg >> (7 * e)) & 0x7Full) {
-          const bool popev = ((popm >> e) & 1u) && !((stale7 >> e) & 1u);   // head e pops my cell (a superseded head does nothing)
+        if (((nearg >> (7 * e)) & 0x7Full) && !((stale7 >> e) & 1u)) {
+          const bool popev = fsrc[e] & 1;                                    // head e pops my cell
           const bool rel = tf[e] < gmin && !(SEM == 0 && clsd);             // head e's lane improves my cell
           gmin = rel ? tf[e] : gmin;
-          if (SEM == 0) clsd = clsd || popev; else inop = popev ? false : inop;
-          inop = rel ? true : inop;
-          imp = imp || rel;
+          if (SEM == 0) clsd = clsd || popev;
           pred = (rel || popev) ? fsrc[e] : pred;
         }
       }
     }
+    const bool imp = gmin < g0;                                 // some earlier head of this trip improved my cell
+    // in the open list: after the last event on my cell -- an improvement puts it there, a pop takes it out (MPA.py:
+    // 122/147); the closed-set variants test "has an entry" (astar.py:92)
+    const bool inop = SEM == 0 ? (rvalid || imp) : (pred == 63 * 4 ? (rvalid && (rn.meta & PF_M_INOPEN)) : !(pred & 1));
     const bool okd = ok && !(SEM == 0 && clsd);                 // astar.py:83 closed set, incl. this trip's earlier pops
     const bool better = okd && tent < gmin;                     // astar.py:87 / MPA.py:137
     const bool in_open = inop;
@@ -494,13 +498,11 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     // REAL head; since a head can only take effect when every earlier real head did, testing nearness against all
     // earlier real heads (not just the committed ones) changes nothing.  Everything below the first failing real head
     // is consumed; the target, or the step cap, cuts that prefix short.
-    const unsigned tgtm = (unsigned)__ballot(lane < NH && rch == trc);      // bit h: head h is the target
+    const unsigned tgtm = (unsigned)__ballot(lane_t < NH && rch == trc);      // bit h: head h is the target
     // an earlier head improved head h's OWN cell: its relaxations would start from another g (MPA.py:135) or its entry
     // is superseded (astar.py:96-100) -- the one effect that is not replayed; the trip stops there
     const unsigned long long impm = __ballot(sub == 8 && imp);
-    unsigned c1 = 0;
-#pragma unroll
-    for (int h = 1; h < NH; ++h) c1 |= (unsigned)((impm >> (9 * h + 8)) & 1ull) << h;
+    const unsigned c1 = (unsigned)impm & 0x7Eu;
     const unsigned exist7 = (1u << nh) - 1u;
     int first = __builtin_ctz((((viol | c1) & ~stale7) | ~exist7) | 0x80u);   // first failing real head (or nh)
     unsigned real = ((1u << first) - 1u) & ~stale7;             // the real pops below it
@@ -522,7 +524,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     const bool eff = (E >> grp) & 1u;
     // a record written twice in this trip keeps the LAST write: a lane that writes tells the previous writer of its
     // cell (forward permute; lanes nobody addresses read 0) to keep quiet -- no two lanes store to one address
-    const bool keep = __builtin_amdgcn_ds_permute((better && eff) ? pred : 63 * 4, 1) == 0;
+    const bool keep = __builtin_amdgcn_ds_permute((better && eff) ? (pred & ~3) : 63 * 4, 1) == 0;
     if (eff && sub == 8 && keep)                                // astar.py:74 closed.add / leave the open list
       rec[cur].meta = SEM == 0 ? (cur_meta | PF_M_CLOSED) : (cur_meta & ~PF_M_INOPEN);
     const bool push = push0 && eff;
