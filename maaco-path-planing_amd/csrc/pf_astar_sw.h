@@ -93,6 +93,27 @@ PF_DEV void sort_lanes(double& f, double& g, int& c, int lane, int n2) {
 // 64 lanes holding a bitonic sequence -> ascending
 PF_DEV void merge_lanes(double& f, double& g, int& c, int lane) { merge_block<64>(f, g, c, lane); }
 
+// inclusive prefix sum / running maximum over the lanes (row scan by row_shr, then row_bcast:15 / :31)
+PF_DEV int wave_incl_sum(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+  return v;
+}
+PF_DEV int wave_incl_max(int v) {                                // v >= 0
+  int t;
+  t = __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true); v = t > v ? t : v;
+  t = __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true); v = t > v ? t : v;
+  t = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true); v = t > v ? t : v;
+  t = __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true); v = t > v ? t : v;
+  t = __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false); v = t > v ? t : v;
+  t = __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false); v = t > v ? t : v;
+  return v;
+}
+
 #define PF_SW_SPILL 16384
 struct SwPool {
   int* cnt;      // LDS [NBK + 1] entries per bucket; bucket NBK is the FRONT bucket: entries above the window's limit
@@ -319,18 +340,23 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
         const int cb = P.cnt[(b0 + lane) & (NBK - 1)]; // lane k: size of the k-th bucket from b0 (wraps onto empty ones)
         const int c0 = bcast_i(cb, 0);
         if (c0 <= 64) {
-          int total = 0, k = 0;
-          for (; k < 64; ++k) {
-            const int ck = bcast_i(cb, k);
-            if (total + ck > 64) break;
-            if (ck > 0) {
-              const int bi = (b0 + k) & (NBK - 1);
-              const int j = lane - total;
-              if (j >= 0 && j < ck) { W.wf = P.bf[bi * CAP + j]; W.wg = P.bg[bi * CAP + j]; W.wc = P.bc[bi * CAP + j]; }
-              if (lane == 0) P.cnt[bi] = 0;
-              total += ck;
-            }
+          // take buckets b0 .. b0+k-1, as many as fit the window: lane j loads the j-th entry of their concatenation
+          // (prefix sums of the sizes; each bucket marks where it starts, a running maximum spreads the mark)
+          const int incl = wave_incl_sum(cb);
+          const int k = __builtin_popcountll(__ballot(incl <= 64));    // (sizes are >= 0: the lanes that fit are a prefix)
+          const int total = bcast_i(incl, k - 1);
+          int* mark = (int*)O.sx;
+          mark[lane] = 0;
+          PF_LDS_ORDER();
+          if (lane < k && cb > 0) mark[incl - cb] = lane;
+          PF_LDS_ORDER();
+          const int kk = wave_incl_max(mark[lane]);                      // my entry's bucket, counted from b0
+          const int j = lane - bperm_i(kk, incl - cb);                    // ... and its index in that bucket
+          if (lane < total) {
+            const int bi = (b0 + kk) & (NBK - 1);
+            W.wf = P.bf[bi * CAP + j]; W.wg = P.bg[bi * CAP + j]; W.wc = P.bc[bi * CAP + j];
           }
+          if (lane < k) P.cnt[(b0 + lane) & (NBK - 1)] = 0;
           int live = total;
           if (SEM == 0) live = drop_superseded(rec, C, W.wf, W.wg, W.wc);
           int n2 = 1; while (n2 < total) n2 <<= 1;
