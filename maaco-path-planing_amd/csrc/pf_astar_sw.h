@@ -421,7 +421,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     unsigned long long hfb[NH];                                 // f of heads 1.. (uniform) for the push test below
     hfb[0] = 0;
 #pragma unroll
-    for (int h = 1; h < NH; ++h) hfb[h] = dbits(bcast_d(W.wf, W.wp + h < 64 ? W.wp + h : 63));
+    for (int h = 1; h < NH; ++h) hfb[h] = dbits(bcast_d(W.wf, W.wp + (h < nh ? h : nh - 1)));   // (past the last head: its f again, so the list stays sorted)
     // lanes 0..48 look at the head pair (e, h) = (lane / 7, lane % 7): too close to be independent?
     const int pe = (lane_t * 37) >> 8, ph = lane_t - 7 * pe;
     const int rce = bperm_i(W.wp + pe < 64 ? W.wp + pe : 63, W.wc), rch = bperm_i(W.wp + ph < 64 ? W.wp + ph : 63, W.wc);
@@ -512,12 +512,18 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     const double fnew = tent + hn;                             // astar.py:90 / MPA.py:140
     const int nrc = (nr << 16) | nc;
     // ---- which heads take effect ----
-    unsigned viol = 0;                                          // bit h: an earlier group pushes a key at or below head h's f
+    // bit h: an earlier group pushes a key at or below head h's f.  The heads' f are sorted, so a push violates the heads
+    // from some h on: the first one is 1 + max(#heads with f below the key, own group), and the mask starts at the
+    // smallest of those over the pushing lanes.
+    unsigned viol;
     {
       const unsigned long long fb = dbits(fnew);                // non-negative doubles order like their bit patterns
+      int c_ = 0;
 #pragma unroll
-      for (int h = 1; h < NH; ++h)
-        if (__ballot(push0 && grp < h && fb <= hfb[h])) viol |= 1u << h;
+      for (int h = 1; h < NH; ++h) c_ += hfb[h] < fb ? 1 : 0;
+      const int hv = (c_ > grp ? c_ : grp) + 1;
+      const unsigned hmin = wave_min_u32(push0 ? (unsigned)hv : (unsigned)NH);
+      viol = (0x7Fu << hmin) & 0x7Fu;
     }
     // Branch-free form of the sequential rule.  A superseded head (closed-set variants) is transparent: consumed, no
     // effect, not a pop.  A real head fails if an earlier group pushed at or below its f or it is near an earlier
@@ -550,7 +556,9 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     const bool eff = (E >> grp) & 1u;
     // a record written twice in this trip keeps the LAST write: a lane that writes tells the previous writer of its
     // cell (forward permute; lanes nobody addresses read 0) to keep quiet -- no two lanes store to one address
-    const bool keep = __builtin_amdgcn_ds_permute((better && eff) ? (pred & ~3) : 63 * 4, 1) == 0;
+    bool keep = true;
+    if (__ballot(better && eff && pred != 63 * 4))              // (rare: two improvements of one cell in one trip)
+      keep = __builtin_amdgcn_ds_permute((better && eff) ? (pred & ~3) : 63 * 4, 1) == 0;
     if (eff && sub == 8 && keep)                                // astar.py:74 closed.add / leave the open list
       rec[cur].meta = SEM == 0 ? (cur_meta | PF_M_CLOSED) : (cur_meta & ~PF_M_INOPEN);
     const bool push = push0 && eff;
