@@ -383,11 +383,11 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     }
     SW_T(t1)
     // ---- pop: up to seven heads of the window at once, nine lanes each ----
-    // The window is sorted, so the next pops are known.  Lane group h relaxes head h in registers; head h takes
-    // effect (and counts as a pop) iff every earlier head did, no earlier head pushed a key at or below head h's f,
-    // head h lies more than 2 cells (Chebyshev) from every earlier head -- so its loads saw none of their writes --
-    // and no earlier head was the target: exactly the pops, in order, that the sequential loop would make.  A head
-    // that does not qualify simply stays in the window.
+    // The window is sorted, so the next pops are known.  Lane group h relaxes head h in registers; the groups replay
+    // each other's effects on the cells they share (below), and head h takes effect (and counts as a pop) iff every
+    // earlier head did, no earlier head pushed a key at or below head h's f, no earlier head improved head h's own
+    // cell, and no earlier head was the target: exactly the pops, in order, that the sequential loop would make.  A
+    // head that does not qualify simply stays in the window.
     constexpr int NH = 7;
     static_assert(NH == 7, "the lane <-> (group, sub) and lane <-> (head pair) maps below are written for 7 x 9 lanes");
     const int nh = W.wn - W.wp < NH ? W.wn - W.wp : NH;
