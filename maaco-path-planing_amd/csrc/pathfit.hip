@@ -48,6 +48,10 @@ PF_DEV Open make_open(char* smem, int /*S*/, char* tier2) {
   O.lg = O.lf + 64 * PF_S;
   O.lc = (int*)(O.lg + 64 * PF_S);
   O.sx = smem + (size_t)64 * PF_S * 20;
+#if PF_LOOP == 2
+  static_assert(PF_GEO_OFF >= (PF_FLOOD_TAB + PF_FLOOD_K) * 4 && PF_GEO_OFF + sizeof(GeoTab) <= (size_t)64 * PF_S * 20, "LDS layout");
+  geo_to_lds(smem, lane_id());                  // the replay's source-lane table (pf_astar_sw.h), once per wave
+#endif
   char* t2 = tier2 + (size_t)blockIdx.x * PF_POOL_STRIDE;
   O.of = (double*)t2;
   O.og = O.of + 64 * PF_T2;

@@ -114,6 +114,34 @@ PF_DEV int wave_incl_max(int v) {                                // v >= 0
   return v;
 }
 
+// Source-lane table of the replay (see pop_loop_sw): [earlier head e][offset code of (my head - head e), 25 = far]
+// [my sub] -> bpermute address of the lane of head e that handles my cell.
+#define PF_GEO_OFF 12288                       /* byte offset in the wave's LDS, past pocket_flood's scratch */
+struct GeoTab { unsigned char v[6 * 26 * 16]; };
+constexpr GeoTab make_geo() {
+  GeoTab t{};
+  const int mdr[8] = {0, 0, 1, -1, 1, 1, -1, -1}, mdc[8] = {1, -1, 0, 0, 1, -1, 1, -1};   // helper.py:30-36
+  for (int e = 0; e < 6; ++e)
+    for (int code = 0; code < 26; ++code)
+      for (int sub = 0; sub < 16; ++sub) {
+        int v = 63 * 4;
+        if (code < 25 && sub <= 8) {
+          const int r = code / 5 - 2 + (sub < 8 ? mdr[sub] : 0), c = code % 5 - 2 + (sub < 8 ? mdc[sub] : 0);
+          if (r == 0 && c == 0) v = e * 4 + 1;                   // head e itself: its self lane, "pop" flag
+          else if (r >= -1 && r <= 1 && c >= -1 && c <= 1)
+            for (int m = 0; m < 8; ++m) if (mdr[m] == r && mdc[m] == c) v = (7 + 8 * e + m) * 4;
+        }
+        t.v[(e * 26 + code) * 16 + sub] = (unsigned char)v;
+      }
+  return t;
+}
+static __device__ const GeoTab PF_GEO = make_geo();
+PF_DEV void geo_to_lds(char* smem, int lane) {
+  const unsigned* src = (const unsigned*)PF_GEO.v;
+  unsigned* dst = (unsigned*)(smem + PF_GEO_OFF);
+  for (int i = lane; i < (int)(sizeof(GeoTab) / 4); i += 64) dst[i] = src[i];
+}
+
 #define PF_SW_SPILL 16384
 struct SwPool {
   int* cnt;      // LDS [NBK + 1] entries per bucket; bucket NBK is the FRONT bucket: entries above the window's limit
@@ -415,6 +443,9 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     unsigned M = 0;
     double cur_g = 0.0;
     if (have) { rn = rec[nidx]; M = G.mm[cur]; if (SEM == 1) cur_g = rec[cur].g; }
+#if defined(PF_STAMPS) && defined(PF_WAIT_EARLY)
+    { SW_T(ti_) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SW_T(tj_) sw_cnt[0] += tj_ - ti_; }   // diagnostic: the bare load latency
+#endif
     // -- everything below is in the shadow of the loads --
     const int hsrc = W.wp + grp < 64 ? W.wp + grp : 63;            // my group's head lives in this window lane
     const double pg = bperm_d(hsrc, W.wg);
@@ -432,24 +463,20 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     // Heads within 2 cells of each other touch common records.  Instead of stopping the trip there, every lane
     // replays, in head order, what the earlier heads of this trip do to ITS cell: for an earlier head e the lane that
     // handles the same cell is fixed by geometry (cell - head e in [-1,1]^2 picks e's move lane, or e's self lane = the
-    // pop of that cell).  Source lanes are worked out here, in the shadow of the loads; rows of the pair matrix
-    // without a near pair are skipped (wave-uniform).
-    const int dr_ = (rce >> 16) - (rch >> 16), dc_ = (rce & 0xFFFF) - (rch & 0xFFFF);
-    const unsigned long long nearg = __ballot(lane_t < NH * NH && pe < ph && ph < nh && (unsigned)(dr_ + 2) <= 4u && (unsigned)(dc_ + 2) <= 4u);   // bit 7e+h
-    const int vr = sub < 8 ? nr : pr, vc = sub < 8 ? nc : pc;     // the cell this lane handles
-    int fsrc[NH - 1];                                            // bpermute address of the lane of head e on my cell (lane 63: none)
+    // pop of that cell).  The pair lanes (e, h) = (lane / 7, lane % 7) classify head h - head e once (25 offsets +
+    // "far"); each lane then reads its source lane from a table in LDS, [e][offset][sub] -> bpermute address (bit 0:
+    // head e IS my cell; 63*4: none).  All in the shadow of the loads.
+    const int Dr_ = (rch >> 16) - (rce >> 16), Dc_ = (rch & 0xFFFF) - (rce & 0xFFFF);
+    const bool nearp = lane_t < NH * NH && pe < ph && ph < nh && (unsigned)(Dr_ + 2) <= 4u && (unsigned)(Dc_ + 2) <= 4u;
+    const int pcode = nearp ? (Dr_ + 2) * 5 + (Dc_ + 2) : 25;
+    const unsigned long long nearg = __ballot(nearp);           // bit 7e+h
+    const unsigned char* geo = (const unsigned char*)O.lf + PF_GEO_OFF;
+    int fsrc[NH - 1];
 #pragma unroll
     for (int e = 0; e < NH - 1; ++e) {
-      fsrc[e] = 63 * 4;
-      if ((nearg >> (7 * e)) & 0x7Full) {
-        const int a_ = vr - (hcell[e] >> 16) + 1, b_ = vc - (hcell[e] & 0xFFFF) + 1;
-        const bool in_ = grp > e && (unsigned)a_ < 3u && (unsigned)b_ < 3u;
-        const int k_ = a_ * 3 + b_;                              // 0..8 when in_: (dr+1)*3 + (dc+1)
-        const int m_ = (int)((0x425001637ull >> (4 * (k_ & 15))) & 15ull);   // -> move index in helper.py:30-36 order (k_ = 4: the head itself)
-        // bit 0 marks "head e IS my cell": its pop happens before my relaxation (the self lane offers +inf)
-        fsrc[e] = in_ ? (k_ == 4 ? e * 4 + 1 : (7 + 8 * e + m_) * 4) : 63 * 4;
-        asm volatile("" : "+v"(fsrc[e]));
-      }
+      const int pc_ = bperm_i(7 * e + grp, pcode);              // (groups <= e read a pair lane with pe >= ph: "far")
+      fsrc[e] = geo[e * (26 * 16) + pc_ * 16 + sub];
+      asm volatile("" : "+v"(fsrc[e]));
     }
     SW_T(t2)
     // ---- relax the 8 neighbours of each head in registers ----
