@@ -320,6 +320,49 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
 #endif
   for (;;) {
     SW_T(t0)
+    if (W.wn - W.wp > 0 && W.wn - W.wp < 7 && W.n_pool > 0 && W.n_spill == 0) {
+      // ---- early refill: fewer than seven heads left.  With the front bucket and the spill list empty, every pool
+      // entry lies in a regular bucket at or above the limit, so the next whole buckets, sorted, simply continue the
+      // window (its remaining keys are below the limit): the trips keep seven heads instead of running the window dry.
+      const int rem = W.wn - W.wp;
+      const int c_ = P.cnt[(W.bcur + lane) & (NBK - 1)];
+      const unsigned long long nz = __ballot(c_ > 0);
+      if (nz && P.cnt[NBK] == 0) {
+        const int b0 = W.bcur + __builtin_ctzll(nz);
+        const int cb = P.cnt[(b0 + lane) & (NBK - 1)];
+        const int incl = wave_incl_sum(cb);
+        const int k = __builtin_popcountll(__ballot(incl <= 64 - rem));
+        if (k > 0) {
+          const int total = bcast_i(incl, k - 1);
+          int* mark = (int*)O.sx;
+          mark[lane] = 0;
+          PF_LDS_ORDER();
+          if (lane < k && cb > 0) mark[incl - cb] = lane;
+          PF_LDS_ORDER();
+          const int kk = wave_incl_max(mark[lane]);
+          const int j = lane - bperm_i(kk, incl - cb);
+          double nf = PF_INF, ng = 0.0; int nc = 0;
+          if (lane < total) {
+            const int bi = (b0 + kk) & (NBK - 1);
+            nf = P.bf[bi * CAP + j]; ng = P.bg[bi * CAP + j]; nc = P.bc[bi * CAP + j];
+          }
+          if (lane < k) P.cnt[(b0 + lane) & (NBK - 1)] = 0;
+          int live = total;
+          if (SEM == 0) live = drop_superseded(rec, C, nf, ng, nc);
+          int n2 = 1; while (n2 < total) n2 <<= 1;
+          sort_lanes(nf, ng, nc, lane, n2);
+          // lanes 0..rem-1 <- the old window, then the new entries
+          const int so = W.wp + lane < 64 ? W.wp + lane : 63, sn = lane >= rem ? lane - rem : 0;
+          const double of_ = bperm_d(so, W.wf), og_ = bperm_d(so, W.wg); const int oc_ = bperm_i(so, W.wc);
+          const double mf_ = bperm_d(sn, nf), mg_ = bperm_d(sn, ng); const int mc_ = bperm_i(sn, nc);
+          W.wf = lane < rem ? of_ : mf_; W.wg = lane < rem ? og_ : mg_; W.wc = lane < rem ? oc_ : mc_;
+          W.wp = 0; W.wn = rem + live; W.n_pool -= total;
+          W.bcur = b0 + k;
+          W.lf = (double)W.bcur * (1.0 / PF_SW_Q); W.lg = -PF_INF; W.lc = 0;
+          PF_LDS_ORDER();
+        }
+      }
+    }
     if (W.wp == W.wn) {
       // ---- refill: the front bucket if it holds anything, else the next non-empty buckets (<= 64 entries); sorted ----
       if (W.n_pool == 0) { status = 1; break; }
