@@ -14,8 +14,10 @@ fitness all_gather + elite broadcast per iteration (pathfit/dist.py).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`
 for the dominant kernel (k_mpa_sweep / k_maaco_walk8 / k_decode_batch; HIP-event
-timed inside the library on its own stream) and `cpu_baseline` (the CPU oracle
-port, bounded sample, 1 core).
+timed inside the library on its own stream; `copy_GBs_measured` = a plain 1 GiB
+device-to-device copy in the same run) and `cpu_baseline` (the CPU oracle port,
+bounded sample, 1 core; for mpa512 also `all_cores`: the same sample over up to
+16 child processes).
 """
 import argparse
 import json
@@ -56,7 +58,13 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + PF_BENCH_SHARE_GPU=1 rehearses N ranks on one GPU (exchange logic only)")
+    ap.add_argument("--cpu-worker", default="", help=argparse.SUPPRESS)   # internal: "lo:hi" slice for the all-cores CPU leg
     a = ap.parse_args()
+    if a.cpu_worker:                                                       # a child of cpu_baseline(): no GPU, no torch
+        lo, hi = (int(x) for x in a.cpu_worker.split(":"))
+        from pathfit import env as env_
+        print(json.dumps(_mpa_cpu_slice(env_.bench_grid(512), a.seed, lo, hi, a.cpu_seconds)), flush=True)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -236,6 +244,22 @@ def main():
         except Exception:
             pass
 
+    if roof is not None and rank == 0:
+        # the nominal 8 TB/s next to what a plain device-to-device copy reaches on this GPU, same run
+        try:
+            nb = 1 << 30
+            src, dst = eng.buf(nb, np.uint8), eng.buf(nb, np.uint8)
+            src.zero(); dst.zero()
+            eng.d2d(dst.ptr, src.ptr, nb); eng._ck(eng.L.pf_sync(eng.h))
+            t1 = time.perf_counter()
+            for _ in range(10):
+                eng.d2d(dst.ptr, src.ptr, nb)
+            eng._ck(eng.L.pf_sync(eng.h))
+            roof["copy_GBs_measured"] = round(10 * 2 * nb / (time.perf_counter() - t1) / 1e9, 1)   # read + write
+            src.free(); dst.free()
+        except Exception:
+            pass
+
     cpu = None
     if rank == 0 and not a.no_cpu:
         cpu = cpu_baseline(a.workload, grid, a.seed, a.cpu_seconds)
@@ -250,9 +274,51 @@ def main():
         dist.destroy_process_group()
 
 
+def _mpa_cpu_slice(grid, seed, lo, hi, budget_s):
+    """Predators [lo, hi) of MPA iteration 1 on the CPU oracle, at most budget_s seconds -> (count, seconds)."""
+    import pf_oracle as po
+    import pf_loops
+    orc = po.Oracle(grid)
+    ref = pf_loops.MpaOracle(orc, 0, grid.size - 1, 4096, 15, FADs_rate=0.2, P_const=0.5, levy_beta=2.0, w_turn=0.1, w_safe=0.8,
+                             min_safe=1.8, diag_pen=100.0, seed=seed)
+    ref._sort()
+    elite = ref.pop[0]
+    CF = (1.0 - 1 / 15) ** (2.0 / 15)
+    t0 = time.perf_counter()
+    n = lo
+    while time.perf_counter() - t0 < budget_s and n < hi:
+        cand = ref.phase_candidate(1, n, elite, CF)
+        ind = cand if cand[1][4] < ref.pop[n][1][4] else ref.pop[n]
+        ref.fads(1, n, ind, CF)
+        n += 1
+    return {"count": n - lo, "seconds": time.perf_counter() - t0}
+
+
+def _mpa_cpu_all_cores(seed, budget_s):
+    """The same sample spread over every host core this process may use: one child process per core (fresh
+    interpreters, no GPU), each taking a contiguous slice of the 4096 predators."""
+    import subprocess
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 16))                  # a one-GPU box's CPU share
+    per = -(-4096 // cores)
+    procs = []
+    for k in range(cores):
+        lo, hi = k * per, min(4096, (k + 1) * per)
+        if lo >= hi:
+            break
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", f"{lo}:{hi}", "--seed", str(seed),
+                                       "--cpu-seconds", str(budget_s)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
+    tot, secs = 0, 0.0
+    for pr in procs:
+        out, _ = pr.communicate(timeout=budget_s * 4 + 120)
+        r = json.loads(out.strip().splitlines()[-1])
+        tot += r["count"]; secs = max(secs, r["seconds"])
+    return {"value": round(tot / secs, 3), "cores": len(procs), "sample": f"{tot} predators of iteration 1 in {len(procs)} processes"}
+
+
 def cpu_baseline(workload, grid, seed, budget_s):
     """Time the CPU oracle (the C port of the reference's algorithm; checker code, kind 'port') on a bounded
-    sample of the SAME workload, single thread."""
+    sample of the SAME workload, single thread (mpa512: also on all host cores)."""
     import pf_oracle as po
     import pf_loops
     orc = po.Oracle(grid)
@@ -301,8 +367,14 @@ def cpu_baseline(workload, grid, seed, budget_s):
             n += 1
         sample = f"first {n} chromosomes (W=5 decode + score), same grid and seed"
     dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 3), "unit": "evals/s", "cores": 1, "kind": "port", "sample": sample,
-            "seconds": round(dt, 2)}
+    out = {"value": round(n / dt, 3), "unit": "evals/s", "cores": 1, "kind": "port", "sample": sample,
+           "seconds": round(dt, 2)}
+    if workload == "mpa512":
+        try:
+            out["all_cores"] = _mpa_cpu_all_cores(seed, min(budget_s, 10.0))
+        except Exception as e:                      # the single-core figure stands on its own
+            out["all_cores"] = {"error": repr(e)[:200]}
+    return out
 
 
 if __name__ == "__main__":
