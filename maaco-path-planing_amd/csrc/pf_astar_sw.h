@@ -485,7 +485,11 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     Rec rn; rn.g = 0.0; rn.tagmm = 0; rn.meta = 0;
     unsigned M = 0;
     double cur_g = 0.0;
+#ifdef PF_CURG_LOAD
     if (have) { rn = rec[nidx]; M = G.mm[cur]; if (SEM == 1) cur_g = rec[cur].g; }
+#else
+    if (have) { rn = rec[nidx]; M = G.mm[cur]; }               // (MPA variant: g_score[current] comes from the self lane's record)
+#endif
 #if defined(PF_STAMPS) && defined(PF_WAIT_EARLY)
     { SW_T(ti_) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SW_T(tj_) sw_cnt[0] += tj_ - ti_; }   // diagnostic: the bare load latency
 #endif
@@ -533,6 +537,9 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     const bool self_stale = SEM == 0 && sub == 8 && ((cur_meta & PF_M_CLOSED) || rn.g != pg);
     const unsigned long long stm = __ballot(have && self_stale);
     const bool my_stale = (stm >> grp) & 1ull;
+#ifndef PF_CURG_LOAD
+    if (SEM == 1) cur_g = bperm_d(grp, rn.g);               // my head's self lane is lane `grp`
+#endif
     const double base_g = SEM == 0 ? pg : cur_g;           // astar.py:85 popped g / MPA.py:135 g_score[current]
     const bool rvalid = (rn.tagmm >> PF_TAG_SHIFT) == tag;
     const bool avoided = (rn.meta >> PF_AVOID_SHIFT) == avm;
