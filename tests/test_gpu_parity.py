@@ -159,6 +159,40 @@ def test_astar_sealed_rooms_vs_oracle():
     e.close()
 
 
+def test_astar_clustered_heads_vs_oracle():
+    """The pop loop takes up to seven window heads per trip and replays, per cell, what the earlier heads of the trip
+    do to the records they share.  Small, nearly open maps keep consecutive pops adjacent (every trip has overlapping
+    3x3 neighbourhoods), thin walls and avoid sets make cells get improved twice within a trip, and start == target /
+    adjacent / unreachable pairs cover the short trips.  Every search is compared with the oracle: path, pops, pushes;
+    all three connector variants, both corner policies."""
+    from pathfit.engine import Engine
+    import pf_oracle as po
+    rnd = np.random.default_rng(11)
+    maps = []
+    g = np.zeros((40, 40), np.uint8); maps.append(g)
+    g = (rnd.random((48, 48)) < 0.06).astype(np.uint8); maps.append(g)
+    g = np.zeros((33, 57), np.uint8); g[5:28, 20] = 1; g[5, 20:40] = 1; g[16, 0:14] = 1; g[16, 15:20] = 1; maps.append(g)
+    for g in maps:
+        e, o = Engine(g), po.Oracle(g)
+        free = np.flatnonzero(g.reshape(-1) != 1)
+        n = 120
+        starts = rnd.choice(free, n); targets = rnd.choice(free, n)
+        targets[:6] = starts[:6]                                           # start == target
+        targets[6:12] = np.clip(starts[6:12] + 1, 0, g.size - 1)           # neighbours (or an obstacle / the next row)
+        avoid = [rnd.choice(free, int(rnd.integers(1, 80))) if i % 3 else None for i in range(n)]
+        for variant in (0, 1, 2):
+            for restrict in (1, 0):
+                o.restrict = restrict
+                paths, st, cnt = e.astar_host(variant, starts, targets, avoid, path_cap=2048, restrict_corner=restrict,
+                                              want_counters=True)
+                for i in range(n):
+                    want, ost = o.astar(int(starts[i]), int(targets[i]), avoid[i], variant)
+                    assert st[i] != 3 and np.array_equal(paths[i], want), (g.shape, variant, restrict, i)
+                    if len(want) > 1:
+                        assert cnt[i, 0] == ost[0] and cnt[i, 1] == ost[1], (g.shape, variant, restrict, i, cnt[i], ost)
+        e.close()
+
+
 def test_astar_open_map_plateaus_vs_oracle():
     """An empty 1024 x 1024 map: thousands of open entries within 1/64 of f (near-ties along straight runs) overflow
     single buckets of the open-list pool, so the spill list and its re-offer at refill time are exercised; nothing
