@@ -4,6 +4,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "maaco-path-planing_amd"), os.path.join(ROOT, "tests")]
 import numpy as np
 import golden_io as gio
+from pathfit import _lib
+if os.environ.get("PF_LIB"):
+    _lib._SO = os.path.abspath(os.environ["PF_LIB"])
 from pathfit.engine import Engine
 g = gio.upsample(gio.grid("g256")[0], 2)
 e = Engine(g)
