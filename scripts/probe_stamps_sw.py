@@ -11,17 +11,20 @@ g = gio.upsample(gio.grid("g256")[0], 2)
 e = Engine(g)
 e.L.pf_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 names = ["refill", "heads+address+load issue", "wait for the loads", "relax+viol+chain", "meta/record stores+pool atomic", "window inserts", "pool stores+tail"]
-for n in (1,):
+for n in ((int(sys.argv[1]),) if len(sys.argv) > 1 else (1,)):
     rnd = np.random.default_rng(1)
     free = np.flatnonzero(g.reshape(-1) != 1)
     starts = rnd.choice(free, n).astype(np.int32); targets = rnd.choice(free, n).astype(np.int32)
     starts[0], targets[0] = 0, g.size - 1
+    if os.environ.get("PF_SAME"):      # n copies of the corner-to-corner search (shader clocks per trip under load)
+        starts[:] = 0; targets[:] = g.size - 1
     for v in (1, 0):
         out = np.zeros(16, np.uint64)
         e.L.pf_debug_stamps(e.h, out.ctypes.data, 1)
         paths, st, cnt = e.astar_host(v, starts, targets, None, path_cap=8192, want_counters=True)
         e.L.pf_debug_stamps(e.h, out.ctypes.data, 1)
         trips = int(out[7]); pops = int(cnt[:, 0].sum())
+        print(f"us per trip (kernel time / trips of one search) {1e3 * e.last_kernel_ms() / (trips / n):.3f}")
         print(f"n={n} v{v}: {e.last_kernel_ms():.1f} ms pops {pops} trips {trips} pops/trip {pops / trips:.2f} clocks/trip {out[:7].sum() / trips:.0f}: " +
               "; ".join(f"{names[i]} {out[i] / trips:.0f}" for i in range(7)))
         c = out[8:].astype(float)
