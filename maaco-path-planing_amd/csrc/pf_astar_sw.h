@@ -516,6 +516,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     const int Dr_ = (rch >> 16) - (rce >> 16), Dc_ = (rch & 0xFFFF) - (rce & 0xFFFF);
     const bool nearp = lane_t < NH * NH && pe < ph && ph < nh && (unsigned)(Dr_ + 2) <= 4u && (unsigned)(Dc_ + 2) <= 4u;
     const int pcode = nearp ? (Dr_ + 2) * 5 + (Dc_ + 2) : 25;
+    const unsigned long long nearg = __ballot(nearp);           // bit 7e+h
     const unsigned char* geo = (const unsigned char*)O.lf + PF_GEO_OFF;
     int fsrc[NH - 1];
 #pragma unroll
@@ -554,16 +555,20 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     bool clsd = false;
     int pred = 63 * 4;                                          // the last earlier lane that writes my cell's record (bit 0: by popping it)
     {
-      // Every row runs: a lane with no counterpart in head e reads lane 63 (+inf, no event), and the lanes of a
-      // superseded head offer +inf by themselves; only its pop has to be switched off by hand.
+      // The replay arithmetic runs for every row: a lane with no counterpart in head e reads lane 63 (+inf, no
+      // event) -- or skips the read when head e has no near successor at all -- and the lanes of a superseded head
+      // offer +inf by themselves; only its pop has to be switched off by hand.
       const double tent_ok = ok ? tent : PF_INF;               // what my relaxation offers my cell (decided statically)
       const unsigned long long b_ = dbits(tent_ok);
       double tf[NH - 1];
 #pragma unroll
       for (int e = 0; e < NH - 1; ++e) {
-        const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(fsrc[e], (int)(unsigned)b_);
-        const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(fsrc[e], (int)(unsigned)(b_ >> 32));
-        tf[e] = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+        tf[e] = PF_INF;
+        if ((nearg >> (7 * e)) & 0x7Full) {                       // (wave-uniform: with the chip busy the LDS crossbar is worth sparing)
+          const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(fsrc[e], (int)(unsigned)b_);
+          const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(fsrc[e], (int)(unsigned)(b_ >> 32));
+          tf[e] = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+        }
       }
 #pragma unroll
       for (int e = 0; e < NH - 1; ++e) {

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(os.path.dirname(_HERE), "lib", "libpathfit.so")
+_SO = os.environ.get("PF_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libpathfit.so")   # PF_LIB: A/B builds
 _LIB = None
 
 
