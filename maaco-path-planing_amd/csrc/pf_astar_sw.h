@@ -522,7 +522,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
 #pragma unroll
     for (int e = 0; e < NH - 1; ++e) {
       const int pc_ = bperm_i(7 * e + grp, pcode);              // (groups <= e read a pair lane with pe >= ph: "far")
-      fsrc[e] = geo[e * (26 * 16) + pc_ * 16 + sub];
+      fsrc[e] = geo[e * (26 * 16) + pc_ * 16 + sub];            // (skipping rows without a near pair measured slower here)
       asm volatile("" : "+v"(fsrc[e]));
     }
     SW_T(t2)
