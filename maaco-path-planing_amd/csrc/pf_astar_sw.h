@@ -23,6 +23,9 @@
 namespace pf {
 
 #define PF_SW_Q 64.0
+#ifndef PF_EARLY_REFILL
+#define PF_EARLY_REFILL 1   /* 0: refill only when the window is empty (A/B builds: 123-127 k against 131.5 k evals/s) */
+#endif
 #ifndef PF_SW_NBK
 #define PF_SW_NBK 256     /* circular buckets, a power of two (a stress build with 64 sends far keys through the spill list) */
 #endif
@@ -320,7 +323,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
 #endif
   for (;;) {
     SW_T(t0)
-    if (W.wn - W.wp > 0 && W.wn - W.wp < 7 && W.n_pool > 0 && W.n_spill == 0) {
+    if (PF_EARLY_REFILL && W.wn - W.wp > 0 && W.wn - W.wp < 7 && W.n_pool > 0 && W.n_spill == 0) {
       // ---- early refill: fewer than seven heads left.  With the front bucket and the spill list empty, every pool
       // entry lies in a regular bucket at or above the limit, so the next whole buckets, sorted, simply continue the
       // window (its remaining keys are below the limit): the trips keep seven heads instead of running the window dry.
