@@ -72,6 +72,8 @@ def main():
     dist = None
     torch = None
     try:
+        if os.environ.get("PF_BENCH_NOTORCH"):         # diagnostic (N=1 only): leave torch out of the process
+            raise ImportError
         import torch as _t
         torch = _t
     except Exception:
@@ -208,6 +210,10 @@ def main():
                            "(BASELINE.json configs[3] per-GPU share)", "agents_per_gpu": per_gpu,
                "grid_sha256": env.grid_hash(grid)[:16]}
 
+    sync_all()             # torch's lazy device initialisation happens here, before the warm-up
+    if a.workload.startswith("maaco"):
+        step()             # set-up, not warm-up: with torch in the process the SECOND MAACO iteration pays a one-off ~40 ms
+                           # (first iteration allocates the walk / visit-bit buffers; not seen without torch, PF_BENCH_NOTORCH=1)
     for _ in range(W):
         step()
     kern_ms, kern_bytes, launches = 0.0, 0.0, 0
@@ -215,7 +221,10 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     for _ in range(K):
-        step()
+        if os.environ.get("PF_BENCH_TRACE"):           # diagnostic: host wall time of every step, to stderr
+            ts = time.perf_counter(); step(); print(f"step {1e3 * (time.perf_counter() - ts):.2f} ms", file=sys.stderr, flush=True)
+        else:
+            step()
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
