@@ -677,22 +677,25 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
           for (unsigned c2 = cand; c2; c2 &= c2 - 1) sum = sum + gbcast8_d(attr, __builtin_ctz(c2));
           if (sum < 1e-9) pick = nth_set_bit(cand, (int)g.randbelow((unsigned long long)ncand));   // :253-254
           else {
-            double ps = 0.0;                                        // :255-258
-            for (unsigned c2 = cand; c2; c2 &= c2 - 1) ps = ps + gbcast8_d(attr, __builtin_ctz(c2)) / sum;
+            // Every quotient of :255-259 belongs to one candidate, and candidate j's values live in lane j: each lane
+            // divides for its own move (three fp64 divisions a step for the whole group instead of ~4 per candidate,
+            // one after the other); only the sums run over the candidates, in candidate order, as the reference's do.
+            const double p0 = attr / sum;                           // :255 probabilities[j]
+            double ps = 0.0;
+            for (unsigned c2 = cand; c2; c2 &= c2 - 1) ps = ps + gbcast8_d(p0, __builtin_ctz(c2));   // :256 sum(probabilities)
             const bool renorm = fabs(ps - 1.0) > 1e-6;
-            const double u = g.random();                            // :259
-            double last = 0.0; bool first = true;
+            const double pj = renorm ? p0 / ps : p0;                // :257-258
+            const double u = g.random();                            // :259 numpy.random.choice: cdf = cumsum(p); cdf /= cdf[-1]
+            double acc = 0.0, mine = 0.0; bool first = true;
             for (unsigned c2 = cand; c2; c2 &= c2 - 1) {
-              double pj = gbcast8_d(attr, __builtin_ctz(c2)) / sum; if (renorm) pj = pj / ps;
-              last = first ? pj : last + pj; first = false;
+              const int j = __builtin_ctz(c2);
+              const double pjj = gbcast8_d(pj, j);
+              acc = first ? pjj : acc + pjj; first = false;
+              mine = k == j ? acc : mine;                           // cdf[position of my move]
             }
-            double acc = 0.0; first = true; int idx = 0, seen = 0;
-            for (unsigned c2 = cand; c2; c2 &= c2 - 1) {
-              double pj = gbcast8_d(attr, __builtin_ctz(c2)) / sum; if (renorm) pj = pj / ps;
-              acc = first ? pj : acc + pj; first = false;
-              seen += 1;
-              if (acc / last <= u) idx = seen;
-            }
+            const double last = acc;
+            const unsigned tm = gballot8(((cand >> k) & 1u) && mine / last <= u);   // searchsorted(cdf, u, side="right")
+            int idx = tm ? __builtin_popcount(cand & ((2u << (31 - __builtin_clz(tm))) - 1u)) : 0;
             if (idx > ncand - 1) idx = ncand - 1;
             pick = nth_set_bit(cand, idx);
           }
