@@ -451,6 +451,8 @@ struct MaacoArgs {
   Grid G;
   const double* tau;      // tau^alpha when alpha != 1 (host-refreshed), else tau
   const double* eta;      // [RC][2]  eta'^beta for (no turn, turn)
+  const double* tep;      // [RC][3]  (eta'^beta no turn, tau, eta'^beta turn): ONE 16-byte load at offset 8*turn gives tau and
+                          // eta'[turn] (k_maaco_walk8; refreshed by k_pack_tep before every walk)
   unsigned* visit;        // [nslots][RC] tabu epoch stamps
   unsigned* slot_epoch;   // [nslots]
   int* work; DevCounters* cnt;
@@ -458,6 +460,12 @@ struct MaacoArgs {
   unsigned long long seed; int ant0, n, path_cap;
   int* cells; int* len; double* plen; int* turns; int* status;
 };
+
+__global__ void k_pack_tep(int RC, const double* tau, const double* eta, double* tep) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < RC) { tep[(size_t)i * 3] = eta[(size_t)i * 2]; tep[(size_t)i * 3 + 1] = tau[i]; tep[(size_t)i * 3 + 2] = eta[(size_t)i * 2 + 1]; }
+}
+typedef double pf_d2u __attribute__((ext_vector_type(2), aligned(8)));
 
 __global__ __launch_bounds__(64) void k_maaco_walk(MaacoArgs p) {
   const int lane = lane_id();
@@ -646,7 +654,12 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
       const int turn = (prev_k >= 0 && k != prev_k) ? 1 : 0;       // MAACO.py:184-195
       unsigned vst = 0; double tv = 0.0, ev = 0.0;
       const unsigned M = G.mm[cur];
-      if (inb) { vst = visit[nidx]; tv = p.tau[nidx]; ev = p.eta[(size_t)nidx * 2 + turn]; }
+      if (inb) {
+        vst = visit[nidx];
+        // the step is bound by the number of divergent vector loads: tau and eta'[turn] in one
+        const pf_d2u te = *(const pf_d2u*)(p.tep + (size_t)nidx * 3 + turn);
+        tv = turn ? te.x : te.y; ev = turn ? te.y : te.x;
+      }
       const bool ok = inb && (M & hbit) && vst != epoch;
       const unsigned mall = gballot8(ok);
       const int vr = tr - cr, vc = tc - cc;
@@ -1433,7 +1446,7 @@ struct pf_handle {
   // MAACO
   bool maaco_ready = false;
   pf_maaco_params mp = {};
-  double *d_tau = nullptr, *d_taua = nullptr, *d_eta = nullptr, *d_dep = nullptr;
+  double *d_tau = nullptr, *d_taua = nullptr, *d_eta = nullptr, *d_dep = nullptr, *d_tep = nullptr;
   bool bits_clean = false;            // the visit-bit matrix is all zero (k_tau_deposit leaves it so)
   unsigned* d_visit = nullptr; unsigned* d_visit_epoch = nullptr; int maaco_slots = 0;
   unsigned long long* d_bits = nullptr; size_t bits_words = 0; int dep_cap = 0;
@@ -1545,7 +1558,7 @@ void pf_destroy(pf_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   void* ptrs[] = {h->d_occ, h->d_mm_r1, h->d_mm_r0, h->d_mm_r1_nd, h->d_mm_r0_nd, h->d_d2near, h->d_rec, h->d_slot_state,
-                  h->d_work, h->d_cnt, h->d_pen, h->d_tier2, h->d_tau, h->d_taua, h->d_eta, h->d_dep, h->d_visit, h->d_visit_epoch,
+                  h->d_work, h->d_cnt, h->d_pen, h->d_tier2, h->d_tau, h->d_taua, h->d_eta, h->d_dep, h->d_tep, h->d_visit, h->d_visit_epoch,
                   h->d_bits, h->d_tmp, h->d_elite_stats, h->d_init_cells, h->d_init_stats, h->d_est, h->d_queue,
                   h->d_comp[0], h->d_comp[1], h->d_comp[2], h->d_comp[3], h->d_ds, h->d_dt};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1966,6 +1979,8 @@ int pf_maaco_walk_batch(pf_handle* h, int32_t iter, uint64_t seed, int32_t ant0,
   MaacoArgs a;
   a.G = make_grid(h, 1, 1);
   a.tau = h->mp.alpha == 1.0 ? h->d_tau : h->d_taua; a.eta = h->d_eta;
+  if (!h->d_tep) CK(hipMalloc(&h->d_tep, sizeof(double) * 3 * (size_t)h->RC));
+  a.tep = h->d_tep;
   a.visit = h->d_visit; a.slot_epoch = h->d_visit_epoch; a.work = h->d_work; a.cnt = h->d_cnt;
   a.start = h->mp.start; a.target = h->mp.target; a.iter = iter; a.num_iterations = h->mp.num_iterations;
   a.q0 = maaco_q0(iter, h->mp.num_iterations, h->mp.q0_initial);
@@ -1977,6 +1992,7 @@ int pf_maaco_walk_batch(pf_handle* h, int32_t iter, uint64_t seed, int32_t ant0,
   const int need = pack8 ? (n + 7) / 8 : n; if (grid > need) grid = need;
   CK(hipMemsetAsync(h->d_work, 0, sizeof(int), h->stream));
   CK(hipMemsetAsync(h->d_cnt, 0, sizeof(DevCounters), h->stream));
+  if (pack8) hipLaunchKernelGGL(k_pack_tep, dim3((h->RC + 255) / 256), dim3(256), 0, h->stream, h->RC, a.tau, a.eta, h->d_tep);
   CK(hipEventRecord(h->ev0, h->stream));
   if (pack8) hipLaunchKernelGGL(k_maaco_walk8, dim3(grid), dim3(64), 0, h->stream, a);
   else hipLaunchKernelGGL(k_maaco_walk, dim3(grid), dim3(64), 0, h->stream, a);
