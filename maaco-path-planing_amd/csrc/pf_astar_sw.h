@@ -522,11 +522,14 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     const unsigned long long nearg = __ballot(nearp);           // bit 7e+h
     const unsigned char* geo = (const unsigned char*)O.lf + PF_GEO_OFF;
     int fsrc[NH - 1];
+    {
+      int pc_[NH - 1];                                          // the six permutes go out together, then the six table reads:
+#pragma unroll                                                  // two LDS round trips in all instead of two per row
+      for (int e = 0; e < NH - 1; ++e) pc_[e] = bperm_i(7 * e + grp, pcode);   // (groups <= e read a pair lane with pe >= ph: "far")
 #pragma unroll
-    for (int e = 0; e < NH - 1; ++e) {
-      const int pc_ = bperm_i(7 * e + grp, pcode);              // (groups <= e read a pair lane with pe >= ph: "far")
-      fsrc[e] = geo[e * (26 * 16) + pc_ * 16 + sub];            // (skipping rows without a near pair measured slower here)
-      asm volatile("" : "+v"(fsrc[e]));
+      for (int e = 0; e < NH - 1; ++e) fsrc[e] = geo[e * (26 * 16) + pc_[e] * 16 + sub];   // (skipping rows without a near pair measured slower)
+#pragma unroll
+      for (int e = 0; e < NH - 1; ++e) asm volatile("" : "+v"(fsrc[e]));
     }
     SW_T(t2)
     // ---- relax the 8 neighbours of each head in registers ----
