@@ -170,6 +170,21 @@ void* pf_maaco_tau_dev(pf_handle* h); /* device pointer, for collectives */
 int pf_maaco_best_scan(int32_t n, const double* plen, const int32_t* turns, int32_t idx0, double* best_len,
                        double* best_turns, int32_t* best_idx);
 
+/* ---- GA host operators (native, no device work) ------------------------ */
+/* GASolver._selection, ga_solver.py:136-142: one generation of tournaments on the stream (seed, DOM_GA_SELECT, gen, 0):
+ * random.sample(population, min(tournament_size, n)) then the first minimum of fitness.  parent_idx[n] = indices into
+ * the (sorted) population. */
+int pf_ga_select(uint64_t seed, int32_t gen, int32_t n, int32_t tournament_size, const double* fitness, int32_t* parent_idx);
+/* GASolver._create_chromosome, ga_solver.py:55-56 (+48-53), for attempts attempt0 .. attempt0+n-1 of the population
+ * initialisation (:95-133): attempt k draws W free cells from the stream (seed, DOM_INIT, 0, k).  cells[n][W]. */
+int pf_ga_random_chromosomes(uint64_t seed, int32_t attempt0, int32_t n, int32_t W, const uint8_t* occ, int32_t R, int32_t C,
+                             int32_t* cells);
+/* GASolver._crossover + _mutate + _generate_random_waypoint for all children of a generation, ga_solver.py:144-160,
+ * 186-194, 48-53: pair j (parents 2j, 2j+1 mod n of parent_cells[n][W], cells r*C+c) draws from (seed, DOM_GA, gen, j).
+ * occ = host occupancy, 1 = obstacle.  child_cells[n][W]. */
+int pf_ga_breed(uint64_t seed, int32_t gen, int32_t n, int32_t W, double crossover_rate, double mutation_rate,
+                const uint8_t* occ, int32_t R, int32_t C, const int32_t* parent_cells, int32_t* child_cells);
+
 /* ---- K7 + K2b + K1: MPA --------------------------------------------- */
 int pf_mpa_setup(pf_handle* h, const pf_mpa_params* p, const pf_score_params* sp);
 /* One phase sweep MPA.py:339-377 over n local predators.  d_gidx[a] = index

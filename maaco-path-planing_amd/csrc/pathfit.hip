@@ -2078,6 +2078,100 @@ int pf_maaco_best_scan(int32_t n, const double* plen, const int32_t* turns, int3
 }
 
 // ---------------------------------------------------------------------------
+// GA host side: the genetic operators (ga_solver.py:48-53, 136-160, 186-194) in native code.  Draw-count dependent and
+// tiny, so they stay on the host as in the reference -- but not in Python: the same keyed streams
+// (pathfit/rng.py) and the same CPython 3.10 derivations (random.sample / randint / _randbelow) restated in C.
+// ---------------------------------------------------------------------------
+namespace {
+struct HostRng {                               // pathfit/rng.py AgentRandom
+  uint64_t key, ctr;
+  static uint64_t mix(uint64_t z) { z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31; return z; }
+  HostRng(uint64_t seed, uint64_t dom, uint64_t it, uint64_t agent) : ctr(0) {
+    uint64_t k = mix(seed + 0x9E3779B97F4A7C15ull * (dom + 1));
+    k = mix(k + 0xD1B54A32D192ED03ull * (it + 1));
+    key = mix(k + 0x8CB92BA72F3D8DD7ull * (agent + 1));
+  }
+  uint64_t next64() { ctr += 1; return mix(key + ctr * 0x9E3779B97F4A7C15ull); }
+  double random() { return (double)(next64() >> 11) * (1.0 / 9007199254740992.0); }
+  uint64_t randbelow(uint64_t n) {             // random.py _randbelow_with_getrandbits
+    int k = 0; for (uint64_t t = n; t; t >>= 1) ++k;
+    uint64_t r = next64() >> (64 - k);
+    while (r >= n) r = next64() >> (64 - k);
+    return r;
+  }
+  int64_t randint(int64_t a, int64_t b) { return a + (int64_t)randbelow((uint64_t)(b - a + 1)); }
+};
+}  // namespace
+
+extern "C" {
+int pf_ga_select(uint64_t seed, int32_t gen, int32_t n, int32_t tournament_size, const double* fitness, int32_t* parent_idx) {
+  if (n <= 0 || tournament_size <= 0 || !fitness || !parent_idx) return -1;
+  HostRng r(seed, 7 /* DOM_GA_SELECT */, (uint64_t)gen, 0);
+  const int k = tournament_size < n ? tournament_size : n;          // ga_solver.py:139 min(tournament_size, len(population))
+  int64_t setsize = 21;                                              // random.sample: pool copy for small n, rejection set otherwise
+  if (k > 5) { int64_t p4 = 1; while (p4 < (int64_t)k * 3) p4 *= 4; setsize += p4; }
+  std::vector<int32_t> pool, sel((size_t)k);
+  for (int s = 0; s < n; ++s) {
+    if (n <= setsize) {
+      pool.resize((size_t)n);
+      for (int i = 0; i < n; ++i) pool[i] = i;
+      for (int i = 0; i < k; ++i) { const uint64_t j = r.randbelow((uint64_t)(n - i)); sel[i] = pool[j]; pool[j] = pool[n - i - 1]; }
+    } else {
+      for (int i = 0; i < k; ++i) {
+        int32_t j;
+        for (;;) { j = (int32_t)r.randbelow((uint64_t)n); bool seen = false; for (int q = 0; q < i; ++q) seen |= sel[q] == j; if (!seen) break; }
+        sel[i] = j;
+      }
+    }
+    int32_t best = sel[0];                                           // min(tournament, key=fitness): the first minimum
+    for (int i = 1; i < k; ++i) if (fitness[sel[i]] < fitness[best]) best = sel[i];
+    parent_idx[s] = best;
+  }
+  return 0;
+}
+
+int pf_ga_random_chromosomes(uint64_t seed, int32_t attempt0, int32_t n, int32_t W, const uint8_t* occ, int32_t R, int32_t Cc,
+                             int32_t* cells) {
+  if (n <= 0 || W <= 0 || !occ || R <= 0 || Cc <= 0 || !cells) return -1;
+  for (int a = 0; a < n; ++a) {                                      // ga_solver.py:55-56 per attempt, stream (seed, DOM_INIT, 0, attempt)
+    HostRng r(seed, 6 /* DOM_INIT */, 0, (uint64_t)(attempt0 + a));
+    for (int i = 0; i < W; ++i)
+      for (;;) {                                                     // :48-53
+        const int rr = (int)r.randint(0, R - 1), cc = (int)r.randint(0, Cc - 1);
+        if (occ[(size_t)rr * Cc + cc] != 1) { cells[(size_t)a * W + i] = rr * Cc + cc; break; }
+      }
+  }
+  return 0;
+}
+
+int pf_ga_breed(uint64_t seed, int32_t gen, int32_t n, int32_t W, double crossover_rate, double mutation_rate, const uint8_t* occ,
+                int32_t R, int32_t Cc, const int32_t* parent_cells, int32_t* child_cells) {
+  if (n <= 0 || W <= 0 || !occ || R <= 0 || Cc <= 0 || !parent_cells || !child_cells) return -1;
+  std::vector<int32_t> c1((size_t)W), c2((size_t)W);
+  int made = 0;
+  for (int pair = 0, idx = 0; made < n; ++pair, idx += 2) {          // ga_solver.py:186-194
+    const int32_t* p1 = parent_cells + (size_t)(idx % n) * W;
+    const int32_t* p2 = parent_cells + (size_t)((idx + 1) % n) * W;
+    HostRng r(seed, 4 /* DOM_GA */, (uint64_t)gen, (uint64_t)pair);
+    int point = 0;
+    if (r.random() < crossover_rate) point = W > 1 ? (int)r.randint(1, W - 1) : 0;   // :145-148
+    for (int i = 0; i < W; ++i) { const bool tail = point > 0 && i >= point; c1[i] = tail ? p2[i] : p1[i]; c2[i] = tail ? p1[i] : p2[i]; }
+    for (int which = 0; which < 2; ++which) {                        // :154-160, child 1 then child 2 on the same stream
+      std::vector<int32_t>& c = which ? c2 : c1;
+      for (int i = 0; i < W; ++i)
+        if (r.random() < mutation_rate)
+          for (;;) {                                                 // :48-53 rejection-sample a free cell
+            const int rr = (int)r.randint(0, R - 1), cc = (int)r.randint(0, Cc - 1);
+            if (occ[(size_t)rr * Cc + cc] != 1) { c[i] = rr * Cc + cc; break; }
+          }
+      if (made < n) { for (int i = 0; i < W; ++i) child_cells[(size_t)made * W + i] = c[i]; ++made; }
+    }
+  }
+  return 0;
+}
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
 // MPA host side
 // ---------------------------------------------------------------------------
 // Exact shortest-path lengths from the start and to the target on the static grid (Dijkstra on the host over the

@@ -70,6 +70,9 @@ SYMBOLS = {
     "pf_maaco_set_pheromone": (C.c_int, [_vp, _vp]),
     "pf_maaco_tau_dev": (_vp, [_vp]),
     "pf_maaco_best_scan": (C.c_int, [_i32, _vp, _vp, _i32, C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_i32)]),
+    "pf_ga_select": (C.c_int, [_u64, _i32, _i32, _i32, _vp, _vp]),
+    "pf_ga_random_chromosomes": (C.c_int, [_u64, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "pf_ga_breed": (C.c_int, [_u64, _i32, _i32, _i32, _dbl, _dbl, _vp, _i32, _i32, _vp, _vp]),
     "pf_mpa_setup": (C.c_int, [_vp, C.POINTER(MpaParams), C.POINTER(ScoreParams)]),
     "pf_mpa_phase_batch": (C.c_int, [_vp, _i32, _dbl, _i32, _u64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32,
                                      _vp, _vp, _vp, _vp, _vp]),

@@ -13,6 +13,39 @@ from . import rng as pfrng
 from .engine import Engine, score_params
 from .env import START_NODE_VAL, TARGET_NODE_VAL, find_marker
 from .paths import CellPath, cells_of
+from . import _lib
+
+
+def ga_select_native(seed, gen, fitness, tournament_size):
+    """GASolver._selection (ga_solver.py:136-142) for one generation in native code: indices of the chosen parents."""
+    fit = np.ascontiguousarray(fitness, np.float64)
+    out = np.empty(len(fit), np.int32)
+    if _lib.lib().pf_ga_select(int(seed), int(gen), len(fit), int(tournament_size), fit.ctypes.data, out.ctypes.data) != 0:
+        raise ValueError("pf_ga_select: bad arguments")
+    return out
+
+
+def ga_random_chromosomes_native(seed, attempt0, n, W, occ):
+    """GASolver._create_chromosome for attempts attempt0..attempt0+n-1 (ga_solver.py:55-56) -> int32 cells [n][W]."""
+    occ = np.ascontiguousarray(occ, np.uint8)
+    out = np.empty((n, W), np.int32)
+    if _lib.lib().pf_ga_random_chromosomes(int(seed), int(attempt0), int(n), int(W), occ.ctypes.data, occ.shape[0], occ.shape[1],
+                                           out.ctypes.data) != 0:
+        raise ValueError("pf_ga_random_chromosomes: bad arguments")
+    return out
+
+
+def ga_breed_native(seed, gen, crossover_rate, mutation_rate, occ, parent_cells):
+    """Crossover + mutation of a whole generation (ga_solver.py:144-160, 186-194, 48-53) in native code:
+    parent_cells int32 [n][W] in parent order -> child cells int32 [n][W]."""
+    pc = np.ascontiguousarray(parent_cells, np.int32)
+    occ = np.ascontiguousarray(occ, np.uint8)
+    n, W = pc.shape
+    out = np.empty((n, W), np.int32)
+    if _lib.lib().pf_ga_breed(int(seed), int(gen), n, W, float(crossover_rate), float(mutation_rate), occ.ctypes.data,
+                              occ.shape[0], occ.shape[1], pc.ctypes.data, out.ctypes.data) != 0:
+        raise ValueError("pf_ga_breed: bad arguments")
+    return out
 
 INF = float("inf")
 
@@ -177,6 +210,7 @@ class GASolver(_WaypointSolver):
         self.best_solution_overall = {"fitness": INF, "path": []}
         self.verbose = verbose
         self._free = self.grid != 1
+        self.native_operators = True      # selection / crossover / mutation through pf_ga_select / pf_ga_breed
 
     # ---- host-side genetic operators (ga_solver.py:48-56,136-160), per-agent streams ----
     def _generate_random_waypoint(self, r):
@@ -200,6 +234,13 @@ class GASolver(_WaypointSolver):
         return [{"chromosome": c, "path": p, "fitness": float(s[4]), "length": float(s[0]), "turns": int(s[1]),
                  "safety_penalty": float(s[2]), "diag_penalty": float(s[3])} for c, p, s in zip(chroms, cps, stats)]
 
+    def _chrom_cells(self, ind):
+        """int32 cells of an individual's chromosome (cached on the individual)."""
+        cc = ind.get("_cells")
+        if cc is None:
+            cc = ind["_cells"] = np.array([self._cell(w) for w in ind["chromosome"]], np.int32)
+        return cc
+
     def _initialize_population(self):
         """ga_solver.py:95-133; attempt k draws its chromosome from stream (seed, DOM_INIT, 0, k)."""
         self.population = []
@@ -207,11 +248,17 @@ class GASolver(_WaypointSolver):
         k = 0
         while len(self.population) < self.population_size and k < max_total_attempts:
             batch = min(max_total_attempts - k, max(self.population_size - len(self.population), 32) * 2)
-            chroms = [self._create_chromosome(pfrng.AgentRandom(self.seed, pfrng.DOM_INIT, 0, k + i)) for i in range(batch)]
-            wp = np.array([[self._cell(w) for w in c] for c in chroms], np.int32).reshape(batch, self.num_waypoints)
+            if self.native_operators and self.num_waypoints > 0:
+                wp = ga_random_chromosomes_native(self.seed, k, batch, self.num_waypoints, self.grid == 1)
+                C_ = self.cols
+                chroms = [[(c // C_, c % C_) for c in row] for row in wp.tolist()]
+            else:
+                chroms = [self._create_chromosome(pfrng.AgentRandom(self.seed, pfrng.DOM_INIT, 0, k + i)) for i in range(batch)]
+                wp = np.array([[self._cell(w) for w in c] for c in chroms], np.int32).reshape(batch, self.num_waypoints)
             cps, stats, feas = self._evaluate(wp_cells=wp)
-            for ind, ok in zip(self._individuals(chroms, cps, stats), feas):
+            for j, (ind, ok) in enumerate(zip(self._individuals(chroms, cps, stats), feas)):
                 if ok and len(self.population) < self.population_size:
+                    ind["_cells"] = wp[j]
                     self.population.append(ind)
             k += batch
         if not self.population and self.num_waypoints > 0:
@@ -268,26 +315,38 @@ class GASolver(_WaypointSolver):
         self.best_solution_overall = self.population[0].copy()
         self.convergence_curve.append(self.best_solution_overall["fitness"])
         N = self.population_size
+        Wn = self.num_waypoints
         for gen in range(self.num_generations):
-            parents = self._selection(gen)
-            # children of pair j come from stream (seed, DOM_GA, gen, j) (ga_solver.py:186-194)
-            kids, owners = [], []
-            idx = pair = 0
-            while len(kids) < N:
-                p1, p2 = parents[idx % len(parents)], parents[(idx + 1) % len(parents)]
-                idx += 2
-                r = pfrng.AgentRandom(self.seed, pfrng.DOM_GA, gen, pair)
-                pair += 1
-                c1, c2 = self._crossover(p1["chromosome"], p2["chromosome"], r)
-                for c in (self._mutate(c1, r), self._mutate(c2, r)):
-                    if len(kids) < N:
-                        kids.append(c)
-                        owners.append((p1, p2))
+            kid_cells = None
+            if self.native_operators and len(self.population) == N and all(len(x["chromosome"]) == Wn for x in self.population):
+                # the genetic operators in native code (same streams, same CPython derivations: tests/test_ga_native.py)
+                pidx = ga_select_native(self.seed, gen, [x["fitness"] for x in self.population], self.tournament_size)
+                parents = [self.population[i] for i in pidx]
+                kid_cells = ga_breed_native(self.seed, gen, self.crossover_rate, self.mutation_rate, self.grid == 1,
+                                            np.stack([self._chrom_cells(x) for x in parents]))
+                C_ = self.cols
+                kids = [[(int(c) // C_, int(c) % C_) for c in row] for row in kid_cells.tolist()]
+                owners = [(parents[(i & ~1) % N], parents[((i & ~1) + 1) % N]) for i in range(N)]
+            else:
+                parents = self._selection(gen)
+                # children of pair j come from stream (seed, DOM_GA, gen, j) (ga_solver.py:186-194)
+                kids, owners = [], []
+                idx = pair = 0
+                while len(kids) < N:
+                    p1, p2 = parents[idx % len(parents)], parents[(idx + 1) % len(parents)]
+                    idx += 2
+                    r = pfrng.AgentRandom(self.seed, pfrng.DOM_GA, gen, pair)
+                    pair += 1
+                    c1, c2 = self._crossover(p1["chromosome"], p2["chromosome"], r)
+                    for c in (self._mutate(c1, r), self._mutate(c2, r)):
+                        if len(kids) < N:
+                            kids.append(c)
+                            owners.append((p1, p2))
             # ---- the hot path: decode + stitch + score every child on the GPU ----
             with_wp = [i for i, c in enumerate(kids) if c]
             cps, stats, feas = [None] * N, np.zeros((N, 5)), np.zeros(N, bool)
             if with_wp:
-                wp = np.array([[self._cell(w) for w in kids[i]] for i in with_wp], np.int32)
+                wp = kid_cells if kid_cells is not None else np.array([[self._cell(w) for w in kids[i]] for i in with_wp], np.int32)
                 a, b, c_ = self._evaluate(wp_cells=wp)
                 for j, i in enumerate(with_wp):
                     cps[i], stats[i], feas[i] = a[j], b[j], c_[j]
@@ -303,6 +362,8 @@ class GASolver(_WaypointSolver):
                         continue
                 elif feas[i]:
                     new_pop.append(self._individuals([kids[i]], [cps[i]], [stats[i]])[0])
+                    if kid_cells is not None:
+                        new_pop[-1]["_cells"] = kid_cells[i]
                     continue
                 p1, p2 = owners[i]                                   # ga_solver.py:204-205
                 new_pop.append(p1 if len(new_pop) % 2 == 0 else p2)
