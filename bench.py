@@ -270,7 +270,7 @@ def main():
             pass
 
     cpu = None
-    if rank == 0 and not a.no_cpu:
+    if rank == 0 and world == 1 and not a.no_cpu:      # the CPU baseline is an N=1 figure (the other ranks would only wait for it)
         cpu = cpu_baseline(a.workload, grid, a.seed, a.cpu_seconds)
 
     if rank == 0:
