@@ -228,12 +228,91 @@ PF_DEV bool respill(const SwPool& P, SwWin& W, int lane) {
     double ef = 0.0, eg = 0.0; int ec = 0;
     if (lane < m) { ef = P.sf[base + lane]; eg = P.sg[base + lane]; ec = P.sc[base + lane]; }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       // read this chunk before re-spilled entries overwrite it
+#if PF_PLATEAU
+    // An entry that is neither below the limit nor offered room by its bucket stays spilled: on a plateau that is nearly
+    // all of them, so they are put back 64 at a time; only the others go through sw_add one by one.
+    PF_LDS_ORDER();
+    const int ba = (int)(ef * PF_SW_Q);
+    const bool inr = ba - W.bcur < PF_SW_NBK;
+    const int bb = ba < W.bcur ? PF_SW_NBK : (ba & (PF_SW_NBK - 1));
+    const bool stays = lane < m && !key_lt(ef, eg, ec, W.lf, W.lg, W.lc) && (!inr || P.cnt[bb] >= PF_SW_CAP);
+    const unsigned long long sm = __ballot(stays);
+    if (stays) {
+      const int at = W.n_spill + __builtin_popcountll(sm & ((1ull << lane) - 1ull));   // (<= base + lane: in place)
+      P.sf[at] = ef; P.sg[at] = eg; P.sc[at] = ec;
+    }
+    W.n_spill += __builtin_popcountll(sm); W.n_pool += __builtin_popcountll(sm);
+    for (unsigned long long rest = __ballot(lane < m && !stays); rest; rest &= rest - 1) {
+      const int k = __builtin_ctzll(rest);
+      if (!sw_add(P, W, bcast_d(ef, k), bcast_d(eg, k), bcast_i(ec, k), lane)) return false;
+    }
+#else
     for (int k = 0; k < m; ++k)
       if (!sw_add(P, W, bcast_d(ef, k), bcast_d(eg, k), bcast_i(ec, k), lane)) return false;
+#endif
   }
   return true;
 }
 // A bucket larger than the window: leave its 64 smallest entries sorted in the lanes, compact the rest in place.
+// The same for a bucket of many windows' worth (a plateau of equal f on an open map holds thousands of entries): the
+// sort-and-merge pass above costs a full sort per 64 entries of the bucket, every refill.  Here a pivot is drawn from a
+// sorted sample of the bucket, one cheap pass counts the keys below it (retried with a lower pivot while more than 64), a
+// second pass moves those keys to LDS and compacts the others in place; the <= 64 selected keys ARE the bucket's smallest.
+// Returns how many were taken (>= 1), sorted in the lanes; 0 = no usable pivot (the caller falls back).
+#ifndef PF_PLATEAU
+#define PF_PLATEAU 0   /* 1: cheaper refills on plateaus of equal f (open maps): pivot selection for buckets of many windows' worth and
+                        bulk re-spilling.  Exact either way; off by default because the extra code costs the bench sweep 3-4 %
+                        (register allocation / code layout of the hot loop), on: empty 1024^2 closed-set batch 284 -> 169 ms */
+#endif
+#define PF_USE_SELECT PF_PLATEAU
+#ifndef PF_SELECT_MIN
+#define PF_SELECT_MIN 256   /* bucket size from which the pivot selection replaces the sort-and-merge pass */
+#endif
+#define PF_SEL_LDS 2048     /* byte offset of the staging area (64 x 20 B) in the wave's LDS, between the bucket counts and the replay table */
+PF_DEV int take_smallest_select(const SwPool& P, char* lds, int bi, int c0, double& wf, double& wg, int& wc, int lane) {
+  constexpr int CAP = PF_SW_CAP;
+  double* sf = (double*)(lds + PF_SEL_LDS); double* sg = sf + 64; int* sc = (int*)(sg + 64);
+  double pf_ = P.bf[bi * CAP + lane], pg_ = P.bg[bi * CAP + lane]; int pc_ = P.bc[bi * CAP + lane];   // sample: the first 64 entries
+  sort_lanes(pf_, pg_, pc_, lane, 64);
+  int r = (64 * 64) / c0; r = r < 1 ? 1 : (r > 63 ? 63 : r);           // about 64 keys of the bucket lie below the sample's r-th
+  double vf = 0.0, vg = 0.0; int vc = 0, cnt = 0;
+  for (;;) {
+    vf = bcast_d(pf_, r); vg = bcast_d(pg_, r); vc = bcast_i(pc_, r);
+    cnt = 0;
+    for (int rd = 0; rd < c0; rd += 64) {
+      const bool in = rd + lane < c0;
+      double ef = PF_INF, eg = 0.0; int ec = 0;
+      if (in) { ef = P.bf[bi * CAP + rd + lane]; eg = P.bg[bi * CAP + rd + lane]; ec = P.bc[bi * CAP + rd + lane]; }
+      cnt += __builtin_popcountll(__ballot(in && key_lt(ef, eg, ec, vf, vg, vc)));
+    }
+    if (cnt <= 64) break;                                               // (cnt >= r >= 1: the sample keys below the pivot)
+    if (r == 1) return 0;
+    r >>= 1;
+  }
+  int wr = 0, sel = 0;
+  for (int rd = 0; rd < c0; rd += 64) {
+    const bool in = rd + lane < c0;
+    double ef = PF_INF, eg = 0.0; int ec = 0;
+    if (in) { ef = P.bf[bi * CAP + rd + lane]; eg = P.bg[bi * CAP + rd + lane]; ec = P.bc[bi * CAP + rd + lane]; }
+    const bool below = in && key_lt(ef, eg, ec, vf, vg, vc);
+    const unsigned long long bm = __ballot(below), km = __ballot(in && !below);
+    const unsigned long long lo = (1ull << lane) - 1ull;
+    if (below) { const int at = sel + __builtin_popcountll(bm & lo); sf[at] = ef; sg[at] = eg; sc[at] = ec; }
+    if (in && !below) { const int at = wr + __builtin_popcountll(km & lo); P.bf[bi * CAP + at] = ef; P.bg[bi * CAP + at] = eg; P.bc[bi * CAP + at] = ec; }
+    sel += __builtin_popcountll(bm); wr += __builtin_popcountll(km);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");             // write-back before the next chunk is read
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+  PF_LDS_ORDER();
+  wf = PF_INF; wg = 0.0; wc = 0;
+  if (lane < sel) { wf = sf[lane]; wg = sg[lane]; wc = sc[lane]; }
+  PF_LDS_ORDER();
+  int n2 = 1; while (n2 < sel) n2 <<= 1;
+  sort_lanes(wf, wg, wc, lane, n2);
+  if (lane == 0) P.cnt[bi] = wr;
+  return sel;
+}
+
 PF_DEV void take_smallest64(const SwPool& P, int bi, int c0, double& wf, double& wg, int& wc, int lane) {
   constexpr int CAP = PF_SW_CAP;
   wf = P.bf[bi * CAP + lane]; wg = P.bg[bi * CAP + lane]; wc = P.bc[bi * CAP + lane];
@@ -388,9 +467,10 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
 #ifdef PF_STAMPS
           sw_cnt[2] += 1; sw_cnt[3] += cF;
 #endif
-          take_smallest64(P, NBK, cF, W.wf, W.wg, W.wc, lane);
-          W.wp = 0; W.wn = 64; W.n_pool -= 64;
-          W.lf = bcast_d(W.wf, 63); W.lg = bcast_d(W.wg, 63); W.lc = bcast_i(W.wc, 63);        // the rest of the front bucket is above this key
+          int nt = PF_USE_SELECT && cF >= PF_SELECT_MIN ? take_smallest_select(P, (char*)O.lf, NBK, cF, W.wf, W.wg, W.wc, lane) : 0;
+          if (nt == 0) { take_smallest64(P, NBK, cF, W.wf, W.wg, W.wc, lane); nt = 64; }
+          W.wp = 0; W.wn = nt; W.n_pool -= nt;
+          W.lf = bcast_d(W.wf, nt - 1); W.lg = bcast_d(W.wg, nt - 1); W.lc = bcast_i(W.wc, nt - 1);   // the rest of the front bucket is above this key
         }
       } else {
         int b0 = -1;
@@ -445,10 +525,11 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
 #ifdef PF_STAMPS
           sw_cnt[4] += 1; sw_cnt[5] += c0;
 #endif
-          take_smallest64(P, b0 & (NBK - 1), c0, W.wf, W.wg, W.wc, lane);
-          W.wp = 0; W.wn = 64; W.n_pool -= 64;
+          int nt = PF_USE_SELECT && c0 >= PF_SELECT_MIN ? take_smallest_select(P, (char*)O.lf, b0 & (NBK - 1), c0, W.wf, W.wg, W.wc, lane) : 0;
+          if (nt == 0) { take_smallest64(P, b0 & (NBK - 1), c0, W.wf, W.wg, W.wc, lane); nt = 64; }
+          W.wp = 0; W.wn = nt; W.n_pool -= nt;
           W.bcur = b0;
-          W.lf = bcast_d(W.wf, 63); W.lg = bcast_d(W.wg, 63); W.lc = bcast_i(W.wc, 63);        // the rest of the bucket is above the window's last key
+          W.lf = bcast_d(W.wf, nt - 1); W.lg = bcast_d(W.wg, nt - 1); W.lc = bcast_i(W.wc, nt - 1);   // the rest of the bucket is above the window's last key
         }
       }
       PF_LDS_ORDER();
