@@ -231,9 +231,10 @@ int pf_mpa_memory(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_sl
                   const int32_t* d_cand_len, const double* d_cand_stats, int32_t* d_pop_cells, int32_t* d_pop_len,
                   double* d_pop_stats);
 
-/* Tuning knobs.  "use16_min": batches of at least this many agents run four agents per wavefront (one per
- * 16-lane DPP row, pf_astar16.h); smaller batches run one agent per wavefront.  Results are identical.
- * Default: off (INT_MAX) -- the lockstep form measured slower on heterogeneous searches. */
+/* Tuning knobs (results never change): "maaco_pack8_min" ants per batch from which eight ants share a wavefront
+ * (default 2048); "mpa_prune" 0/1 exact bound pruning of MPA rebuilds (default 1).  Test hook: "astar_step_cap" > 0
+ * lowers the connectors' step cap below the reference's 3RC / 2RC (astar.py:58, MPA.py:118) so that the cap path
+ * (PF_ST_STEP_CAP) can be exercised; 0 restores the reference's value. */
 int pf_set_option(pf_handle* h, const char* name, int64_t value);
 
 /* ---- device self-tests (used by tests/ to pin device arithmetic) ----- */

@@ -12,7 +12,6 @@
 
 #include "../../include/pathfit.h"
 #include "pf_astar.h"
-#include "pf_astar16.h"
 #include "pf_device.h"
 #include "pf_score.h"
 
@@ -45,20 +44,13 @@ struct Common {
 PF_DEV Open make_open(char* smem, int /*S*/, char* tier2) {
   Open O;
   O.lf = (double*)smem;
-  O.lg = O.lf + 64 * PF_S;
-  O.lc = (int*)(O.lg + 64 * PF_S);
-  O.sx = smem + (size_t)64 * PF_S * 20;
-#if PF_LOOP == 2
-  static_assert(PF_GEO_OFF >= (PF_FLOOD_TAB + PF_FLOOD_K) * 4 && PF_GEO_OFF + sizeof(GeoTab) <= (size_t)64 * PF_S * 20, "LDS layout");
-  geo_to_lds(smem, lane_id());                  // the replay's source-lane table (pf_astar_sw.h), once per wave
-#endif
-  char* t2 = tier2 + (size_t)blockIdx.x * PF_POOL_STRIDE;
-  O.of = (double*)t2;
-  O.og = O.of + 64 * PF_T2;
-  O.oc = (int*)(O.og + 64 * PF_T2);
+  O.sx = smem + PF_SX_OFF;
+  static_assert(PF_GEO_OFF >= (PF_FLOOD_TAB + PF_FLOOD_K) * 4 && PF_GEO_OFF + sizeof(GeoTab) <= PF_SX_OFF, "LDS layout");
+  geo_to_lds(smem, lane_id());                    // the replay's source-lane table (pf_astar_sw.h), once per wave
+  O.of = (double*)(tier2 + (size_t)blockIdx.x * PF_POOL_STRIDE);
   return O;
 }
-static size_t open_bytes(int S) { return (size_t)64 * S * 20 + PF_SPEC_LDS; }
+static size_t open_bytes(int /*S*/) { return (size_t)PF_LDS_BYTES; }
 
 PF_DEV Slot slot_load(const Common& c, int RC) {
   Slot s;
@@ -71,10 +63,13 @@ PF_DEV Slot slot_load(const Common& c, int RC) {
 PF_DEV void slot_store(const Common& c, const Slot& s, int lane) {
   if (lane == 0) { c.slot_state[2 * blockIdx.x] = s.tag; c.slot_state[2 * blockIdx.x + 1] = s.avoid_ep; }
 }
-// new agent evaluation: fresh avoid epoch; wipe the slot before an epoch can wrap
+// new agent evaluation: fresh avoid epoch; wipe the slot before an epoch can wrap.  One evaluation runs at most
+// PF_MAX_SEARCHES_PER_EVAL searches (each takes a fresh 24-bit tag): pf_decode_batch rejects W beyond it, the other
+// callers run one or two.
+#define PF_MAX_SEARCHES_PER_EVAL 0x8000
 PF_DEV void slot_begin_eval(Slot& s, int RC, int lane) {
   s.avoid_ep += 1;
-  if (s.avoid_ep >= 0x3FF0u || s.tag >= 0xFFFFF0u) slot_wipe(s, RC, lane);
+  if (s.avoid_ep >= 0x3FF0u || s.tag >= 0xFFFFFFu - 2u * PF_MAX_SEARCHES_PER_EVAL) slot_wipe(s, RC, lane);
 }
 PF_DEV int next_work(int* work, int lane) {
   int a = 0;
@@ -190,12 +185,15 @@ __global__ __launch_bounds__(64) void k_astar_batch(AstarArgs p) {
     slot_begin_eval(s, RC, lane);
     if (p.avoid_off) {
       const long long b = p.avoid_off[a], e = p.avoid_off[a + 1];
-      mark_avoid(s, p.avoid_cells + b, (int)(e - b), lane);
+      mark_avoid_checked(s, p.avoid_cells + b, (int)(e - b), RC, lane);
     }
     AStat st = {0, 0, 0, 0, 0, 0};
     int n = 0;
-    const int rc = astar<VARIANT>(p.c.G, s, O, p.start[a], p.target[a], p.cells + (size_t)a * p.path_cap,
-                                  p.path_cap, n, st, lane);
+    // cell indices come straight from the caller: an index outside the grid is "not a valid node" (astar.py:37-39 /
+    // MPA.py:109-111 -> []), never an address
+    const int sa = p.start[a], ta = p.target[a];
+    const int rc = ((unsigned)sa >= (unsigned)RC || (unsigned)ta >= (unsigned)RC) ? 1 :
+                   astar<VARIANT>(p.c.G, s, O, sa, ta, p.cells + (size_t)a * p.path_cap, p.path_cap, n, st, lane);
     if (lane == 0) {
       p.len[a] = rc == 0 ? n : 0;
       p.status[a] = rc;
@@ -209,78 +207,6 @@ __global__ __launch_bounds__(64) void k_astar_batch(AstarArgs p) {
   }
   slot_store(p.c, s, lane);
   flush_counters(p.c.cnt, tot, cells, ovf, lane);
-}
-
-// ---- four agents per wavefront (pf_astar16.h) ------------------------------------------------------
-// a wave takes four neighbouring queue entries; row r (16 lanes) runs entry base + r in slot 4*wave + r
-PF_DEV int next_agent16(const Common& c, int n) {
-  int base = 0;
-  if (lane_id() == 0) base = atomicAdd(c.work, 4);
-  base = first_i(base);
-  if (base >= n) return -2;                                  // queue drained for the whole wave
-  const int w = base + rgrp();
-  if (w >= n) return -1;                                     // this row idles
-  return c.queue ? c.queue[w] : w;
-}
-PF_DEV Slot slot_load16(const Common& c, int RC) {
-  Slot s;
-  const int slot = blockIdx.x * 4 + rgrp();
-  s.rec = c.rec + (size_t)slot * RC;
-  s.mm = c.G.mm;
-  s.tag = c.slot_state[2 * slot];
-  s.avoid_ep = c.slot_state[2 * slot + 1];
-  return s;
-}
-PF_DEV void slot_store16(const Common& c, const Slot& s) {
-  const int slot = blockIdx.x * 4 + rgrp();
-  if (rlane() == 0) { c.slot_state[2 * slot] = s.tag; c.slot_state[2 * slot + 1] = s.avoid_ep; }
-}
-PF_DEV void slot_begin_eval16(Slot& s, int RC) {
-  s.avoid_ep += 1;
-  if (s.avoid_ep >= 0x3FF0u || s.tag >= 0xFFFFF0u) slot_wipe16(s, RC);
-}
-PF_DEV void flush_counters16(DevCounters* c, const AStat& st, unsigned long long cells, unsigned long long ovf) {
-  if (rlane() == 0) {
-    atomicAdd(&c->pops, st.pops); atomicAdd(&c->pushes, st.pushes); atomicAdd(&c->nbr, st.nbr);
-    atomicAdd(&c->deckey, st.deckey); atomicAdd(&c->path_cells, cells); atomicAdd(&c->overflow, ovf);
-  }
-}
-
-template <int VARIANT>
-__global__ __launch_bounds__(64) void k_astar_batch16(AstarArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int RC = p.c.G.R * p.c.G.C;
-  const int slot = blockIdx.x * 4 + rgrp();
-  Open16 O = make_open16(smem, p.c.tier2 + (size_t)slot * PF_POOL_STRIDE);
-  Slot s = slot_load16(p.c, RC);
-  AStat tot = {0, 0, 0, 0, 0, 0};
-  unsigned long long cells = 0, ovf = 0;
-  for (;;) {
-    const int a = next_agent16(p.c, p.n);
-    if (a == -2) break;
-    if (a >= 0) {
-      slot_begin_eval16(s, RC);
-      if (p.avoid_off) {
-        const long long b = p.avoid_off[a], e = p.avoid_off[a + 1];
-        mark_avoid16(s, p.avoid_cells + b, (int)(e - b));
-      }
-      AStat st = {0, 0, 0, 0, 0, 0};
-      int n = 0;
-      const int rc = astar16<VARIANT>(p.c.G, s, O, p.start[a], p.target[a], p.cells + (size_t)a * p.path_cap, p.path_cap, n, st);
-      if (rlane() == 0) {
-        p.len[a] = rc == 0 ? n : 0;
-        p.status[a] = rc;
-        if (p.counters) {
-          p.counters[4 * a] = (long long)st.pops; p.counters[4 * a + 1] = (long long)st.pushes;
-          p.counters[4 * a + 2] = st.max_open; p.counters[4 * a + 3] = (long long)st.nbr;
-        }
-      }
-      tot.pops += st.pops; tot.pushes += st.pushes; tot.nbr += st.nbr; tot.deckey += st.deckey; tot.spills += st.spills;
-      cells += rc == 0 ? n : 0; ovf += rc == 3;
-    }
-  }
-  slot_store16(p.c, s);
-  flush_counters16(p.c.cnt, tot, cells, ovf);
 }
 
 // ===========================================================================
@@ -354,55 +280,6 @@ __global__ __launch_bounds__(64) void k_decode_batch(DecodeArgs p) {
   }
   slot_store(p.c, s, lane);
   flush_counters(p.c.cnt, tot, cells, ovf, lane);
-}
-
-__global__ __launch_bounds__(64) void k_decode_batch16(DecodeArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const Grid& G = p.c.G;
-  const int RC = G.R * G.C;
-  const int L = rlane();
-  const int slot = blockIdx.x * 4 + rgrp();
-  Open16 O = make_open16(smem, p.c.tier2 + (size_t)slot * PF_POOL_STRIDE);
-  Slot s = slot_load16(p.c, RC);
-  AStat tot = {0, 0, 0, 0, 0, 0};
-  unsigned long long cells = 0, ovf = 0;
-  for (;;) {
-    const int a = next_agent16(p.c, p.n);
-    if (a == -2) break;
-    if (a >= 0) {
-      slot_begin_eval16(s, RC);
-      int* out = p.cells + (size_t)a * p.path_cap;
-      int n = 1, cur = p.start, rc = 0;
-      if (L == 0) { out[0] = p.start; s.rec[p.start].meta = s.avoid_ep << PF_AVOID_SHIFT; }
-      for (int k = 0; k <= p.W && rc == 0; ++k) {
-        int goal = p.target;
-        if (k < p.W) {
-          if (p.wp_cells) goal = p.wp_cells[(size_t)a * p.W + k];
-          else {
-            const double x = p.wp_pos[((size_t)a * p.W + k) * 2], y = p.wp_pos[((size_t)a * p.W + k) * 2 + 1];
-            long r = (long)__builtin_rint(x), c = (long)__builtin_rint(y);
-            r = r < 0 ? 0 : (r > G.R - 1 ? G.R - 1 : r);
-            c = c < 0 ? 0 : (c > G.C - 1 ? G.C - 1 : c);
-            goal = (int)(r * G.C + c);
-          }
-        }
-        int m = 0;
-        rc = astar16<0>(G, s, O, cur, goal, out + n - 1, p.path_cap - (n - 1), m, tot);
-        if (rc != 0) break;
-        mark_avoid16(s, out + n, m - 1);
-        n += m - 1;
-        cur = goal;
-      }
-      if (rc != 0) n = 0;
-      double sc[5];
-      if (p.do_score) score_path16(G, p.sp, out, n, sc);
-      if (L == 0) { p.len[a] = n; p.status[a] = rc; }
-      if (p.do_score && L < 5) p.stats[(size_t)a * 5 + L] = sc[L];
-      cells += n; ovf += rc == 3;
-    }
-  }
-  slot_store16(p.c, s);
-  flush_counters16(p.c.cnt, tot, cells, ovf);
 }
 
 // ===========================================================================
@@ -1461,6 +1338,7 @@ struct pf_handle {
   float* d_est = nullptr; int* d_queue = nullptr; int est_cap = 0;
 };
 
+static long long g_step_cap = 0;   // > 0: lowers the connectors' step cap (pf_set_option "astar_step_cap": tests of the cap path)
 static std::string g_create_err;
 static int fail(pf_handle* h, const char* what, hipError_t e) {
   std::string m = std::string(what) + ": " + hipGetErrorString(e);
@@ -1506,6 +1384,7 @@ static Grid make_grid(pf_handle* h, int allow_diag, int restrict_corner) {
   G.comp = ensure_comp(h, (allow_diag ? 2 : 0) | (restrict_corner ? 1 : 0), G.mm);
   G.d2near = h->d_d2near; G.R = h->R; G.C = h->C;
   G.magicC = ((1ull << 40) / (uint64_t)h->C) + 1;
+  G.step_cap = g_step_cap;
   return G;
 }
 
@@ -1582,16 +1461,11 @@ float pf_last_kernel_ms(pf_handle* h) { return h->last_ms; }
 // ---- scratch / launch helpers ----------------------------------------------
 // resident agent slots per CU and LDS bin capacity; PF_SLOTS_PER_CU / PF_LDS_S override for experiments
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; }
-static const int kSlotsPerCU = 8;                       // resident one-agent waves per CU at most (the 4-agents-per-wave experiment runs 2 waves/CU on them)
+static const int kSlotsPerCU = 8;                       // resident one-agent waves per CU at most
 static const int kWavesPerCU = env_int("PF_WAVES_PER_CU", 8);   // resident one-agent waves per CU (LDS permitting)
-static const int kUse16 = env_int("PF_USE16", 1);      // PF_USE16=0 forces the one-agent-per-wave kernels
-// measured r01: the lockstep-gang form is SLOWER than one agent per wave on heterogeneous searches (211 vs 450
-// Mpops/s on 7168 random G512 pairs: rows idle until the gang's longest search ends, and 512 LDS entries per
-// agent spill heavily) -> off by default; kept, parity-tested, as the base of the per-row state machine
-static int g_use16_min = env_int("PF_USE16_MIN", 0x7fffffff);
 static int g_mpa_prune = 1;   // exact bound pruning of MPA rebuilds (pf_set_option "mpa_prune")
 static int g_maaco_pack8_min = env_int("PF_MAACO_PACK8_MIN", 2048);   // ants per batch from which 8 ants share a wavefront
-static const int kLdsS = PF_S;
+static const int kLdsS = 16;
 static int ensure_slots(pf_handle* h, int allow_diag = 1, int restrict_corner = 1) {
   CK(hipSetDevice(h->device));
   if (!h->d_rec) {
@@ -1662,50 +1536,9 @@ static int make_queue(pf_handle* h, int n, Plan plan) {
   return 0;
 }
 
-// four-agents-per-wave launch; agents whose open list outgrows the row's capacity come back with status 3
-// and are re-run by the 64-lane kernel `kern64` (retry mode: only status==3 agents).
-template <typename KArgs, typename Kern16, typename Kern64>
-static int launch16_with_fallback(pf_handle* h, Kern16 kern16, Kern64 kern64, KArgs& args, int n) {
-  if (n <= 0) return 0;
-  args.c.S = PF_S16; args.c.retry = 0;
-  const size_t lds = 4 * PF_LDS16;
-  CK(hipFuncSetAttribute((const void*)kern16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int waves = h->nslots / 4; const int need = (n + 3) / 4; if (waves > need) waves = need;
-  CK(hipMemsetAsync(h->d_work, 0, sizeof(int), h->stream));
-  CK(hipMemsetAsync(h->d_cnt, 0, sizeof(DevCounters), h->stream));
-  CK(hipEventRecord(h->ev0, h->stream));
-  hipLaunchKernelGGL(kern16, dim3(waves), dim3(64), lds, h->stream, args);
-  CK(hipGetLastError());
-  CK(hipEventRecord(h->ev1, h->stream));
-  DevCounters dc;
-  if (end_batch(h, &dc)) return -1;
-  float ms = 0.f; CK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-  if (dc.overflow) {
-    pf_counters first = h->last;
-    args.c.S = PF_S; args.c.retry = 1;
-    const size_t lds64 = open_bytes(PF_S);
-    CK(hipFuncSetAttribute((const void*)kern64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64));
-    int grid = (h->nslots / kSlotsPerCU) * 7; if (grid > n) grid = n;
-    CK(hipMemsetAsync(h->d_work, 0, sizeof(int), h->stream));
-    CK(hipMemsetAsync(h->d_cnt, 0, sizeof(DevCounters), h->stream));
-    CK(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(kern64, dim3(grid), dim3(64), lds64, h->stream, args);
-    CK(hipGetLastError());
-    CK(hipEventRecord(h->ev1, h->stream));
-    if (end_batch(h, &dc)) return -1;
-    float ms2 = 0.f; CK(hipEventElapsedTime(&ms2, h->ev0, h->ev1));
-    ms += ms2;
-    h->last.pops += first.pops; h->last.pushes += first.pushes; h->last.nbr_examined += first.nbr_examined;
-    h->last.path_cells += first.path_cells; h->last.decrease_keys += first.decrease_keys;
-  }
-  h->last_ms = ms;
-  return 0;
-}
-
 template <typename KArgs, typename Kern>
 static int launch_with_retry(pf_handle* h, Kern kern, KArgs& args, int n) {
   if (n <= 0) return 0;
-  // LDS bin capacity S = 16 (20 KiB per agent); bins spill to the HBM tier, so there is no retry pass.
   const int S = kLdsS;
   args.c.S = S; args.c.retry = 0;
   const size_t lds = open_bytes(S);
@@ -1763,14 +1596,9 @@ int pf_astar_batch(pf_handle* h, int32_t variant, int32_t allow_diag, int32_t re
     if (make_queue(h, n, [&](float* est) { hipLaunchKernelGGL(k_plan_astar, dim3((n + 255) / 256), dim3(256), 0, h->stream, a.c.G, n, d_start, d_target, est); })) return -1;
     a.c.queue = h->d_queue;
   }
-  const bool use16 = kUse16 && n >= g_use16_min;                     // small batches are latency bound: one agent per wave
-  if (variant == PF_ASTAR_REF) return use16 ? launch16_with_fallback(h, k_astar_batch16<0>, k_astar_batch<0>, a, n) : launch_with_retry(h, k_astar_batch<0>, a, n);
-  if (variant == PF_ASTAR_MPA) return use16 ? launch16_with_fallback(h, k_astar_batch16<1>, k_astar_batch<1>, a, n) : launch_with_retry(h, k_astar_batch<1>, a, n);
-#if PF_LOOP == 2
+  if (variant == PF_ASTAR_REF) return launch_with_retry(h, k_astar_batch<0>, a, n);
+  if (variant == PF_ASTAR_MPA) return launch_with_retry(h, k_astar_batch<1>, a, n);
   if (variant == PF_ASTAR_DIJKSTRA) return launch_with_retry(h, k_astar_batch<2>, a, n);
-#else
-  if (variant == PF_ASTAR_DIJKSTRA) return failmsg(h, "pf_astar_batch: the Dijkstra variant needs the default (PF_LOOP=2) build");
-#endif
   return failmsg(h, "pf_astar_batch: unknown variant");
 }
 
@@ -1799,7 +1627,7 @@ int pf_decode_batch(pf_handle* h, int32_t allow_diag, int32_t restrict_corner, i
                     int32_t path_cap, int32_t* d_cells, int32_t* d_len, int32_t* d_status,
                     const pf_score_params* sp, double* d_stats) {
   if (!h) return -2;
-  if (n < 0 || W < 0 || path_cap < 1 || (!d_wp_cells && !d_wp_pos && W > 0) || !d_cells || !d_len || !d_status ||
+  if (n < 0 || W < 0 || W >= PF_MAX_SEARCHES_PER_EVAL || path_cap < 1 || (!d_wp_cells && !d_wp_pos && W > 0) || !d_cells || !d_len || !d_status ||
       start < 0 || start >= h->RC || target < 0 || target >= h->RC || (sp && !d_stats))
     return failmsg(h, "pf_decode_batch: bad arguments");
   if (ensure_slots(h, allow_diag, restrict_corner)) return -1;
@@ -1813,7 +1641,6 @@ int pf_decode_batch(pf_handle* h, int32_t allow_diag, int32_t restrict_corner, i
     if (make_queue(h, n, [&](float* est) { hipLaunchKernelGGL(k_plan_decode, dim3((n + 255) / 256), dim3(256), 0, h->stream, a.c.G, n, W, d_wp_cells, d_wp_pos, start, target, est); })) return -1;
     a.c.queue = h->d_queue;
   }
-  if (kUse16 && n >= g_use16_min) return launch16_with_fallback(h, k_decode_batch16, k_decode_batch, a, n);
   return launch_with_retry(h, k_decode_batch, a, n);
 }
 
@@ -1868,7 +1695,7 @@ extern "C" int pf_debug_stamps(pf_handle* h, uint64_t* out, int reset) {
 #endif
 int pf_set_option(pf_handle* h, const char* name, int64_t value) {
   if (!name) return failmsg(h, "pf_set_option: bad arguments");
-  if (!strcmp(name, "use16_min")) { g_use16_min = (int)value; return 0; }
+  if (!strcmp(name, "astar_step_cap")) { g_step_cap = value > 0 ? (long long)value : 0; return 0; }
   if (!strcmp(name, "maaco_pack8_min")) { g_maaco_pack8_min = (int)value; return 0; }
   if (!strcmp(name, "mpa_prune")) { g_mpa_prune = value != 0; return 0; }
   return failmsg(h, std::string("pf_set_option: unknown option ") + name);

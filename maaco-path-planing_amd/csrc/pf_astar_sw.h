@@ -1,8 +1,7 @@
-// pf_astar_sw.h -- sorted-window pop loop of the one-wavefront A* (included by pf_astar.h; PF_LOOP == 2).
+// pf_astar_sw.h -- sorted-window pop loop of the one-wavefront A* (included by pf_astar.h).
 //
-// The lane-owned-bin loops pay, for every pop, a 64-lane argmin (two DPP reductions), a rescan of the bin the
-// entry left (LDS round trip + another reduction) and a cached-minimum update per push: ~430 instructions a
-// pop, all on one wave's issue port.  Here the open list is a monotone bucket queue with a sorted window:
+// The open list is a monotone bucket queue with a sorted window (the round-1 designs it replaced -- lane-owned LDS
+// bins with an argmin + rescan per pop, and four speculative pops over those bins -- are in the history):
 //
 //   pool    entries live unsorted in HBM buckets keyed by floor(f * Q) (Q = 64, 256 circular buckets: a push is at
 //           most 2*sqrt(2) above the pop that made it, 182 buckets); an append is one LDS atomic for the slot
@@ -21,6 +20,12 @@
 #pragma once
 
 namespace pf {
+
+// Lanes of the wave talk through LDS here.  The hardware executes one wave's LDS instructions in order, so no
+// wait is needed, but the compiler must not move a lane's load above another lane's (to it unrelated) store:
+// a compiler-only barrier at each hand-over point.
+#define PF_LDS_ORDER() asm volatile("" ::: "memory")
+PF_DEV unsigned long long dbits(double x) { return (unsigned long long)__double_as_longlong(x); }
 
 #define PF_SW_Q 64.0
 #ifndef PF_EARLY_REFILL

@@ -21,16 +21,13 @@ namespace pf {
 struct __attribute__((aligned(16))) Rec {
   double g;
   uint32_t tagmm;  // [7:0] static move mask of the cell (helper order, this handle's diagonal policy), [31:8] solve epoch
-  uint32_t meta;   // [2:0] parent move, [3] closed, [4] in-open, [17:5] open-list position (bin<<7|slot), [31:18] avoid epoch
+  uint32_t meta;   // [2:0] parent move, [3] closed, [4] in-open, [31:18] avoid epoch
 };
 #define PF_M_PARENT 7u
 #define PF_M_CLOSED 8u
 #define PF_M_INOPEN 16u
-#define PF_POS_SHIFT 5
-#define PF_POS_MASK 0x1FFFu
 #define PF_AVOID_SHIFT 18
 #define PF_AVOID_KEEP 0xFFFC0000u
-#define PF_T2 64 /* tier-2 (HBM) overflow slots per bin */
 #define PF_POOL_STRIDE ((257 * 1024 + 16384) * 20) /* bytes of open-list HBM scratch per resident agent slot (bucket pool / tier 2) */
 #define PF_TAG_SHIFT 8
 
@@ -49,6 +46,7 @@ struct Grid {
   const int* comp;        // connected-component label of every free cell under `mm` (obstacles: -1); may be null
   int R, C;
   uint64_t magicC;        // floor(2^40 / C) + 1 : cell / C == (cell * magicC) >> 40 for cell < 2^24
+  long long step_cap;     // > 0: lowers the connectors' step cap (tests of the cap path; 0 = the reference's 3RC / 2RC)
 };
 PF_DEV int row_of(const Grid& G, int cell) { return (int)(((uint64_t)(uint32_t)cell * G.magicC) >> 40); }
 
@@ -100,26 +98,6 @@ PF_DEV unsigned wave_min_u32(unsigned v) {
   v = dpp_umin<0x143, 0xC>(v);
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
-// min over lanes 0..15 only (row 0); other rows are ignored
-PF_DEV unsigned row0_min_u32(unsigned v) {
-  v = dpp_umin<0x121, 0xF>(v);
-  v = dpp_umin<0x122, 0xF>(v);
-  v = dpp_umin<0x124, 0xF>(v);
-  v = dpp_umin<0x128, 0xF>(v);
-  return (unsigned)__builtin_amdgcn_readlane((int)v, 0);
-}
-// Lanes holding the minimum of a non-negative double key (bit pattern order == value order).
-// ROW0: only lanes 0..15 take part (their keys; others must pass +inf).
-template <bool ROW0>
-PF_DEV unsigned long long argmin_mask_d(double key, unsigned& mh, unsigned& ml) {
-  const unsigned hi = (unsigned)__double2hiint(key), lo = (unsigned)__double2loint(key);
-  mh = ROW0 ? row0_min_u32(hi) : wave_min_u32(hi);
-  const unsigned lo2 = hi == mh ? lo : 0xFFFFFFFFu;
-  ml = ROW0 ? row0_min_u32(lo2) : wave_min_u32(lo2);
-  return __ballot(hi == mh && lo == ml);
-}
-#define PF_INF_HI 0x7FF00000u
-
 PF_DEV int wave_sum_i(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);  // row_shr:1
   v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);  // row_shr:2

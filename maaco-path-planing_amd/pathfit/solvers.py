@@ -429,6 +429,13 @@ class PSOSolver(_WaypointSolver):
                 if feas[i] and len(pos) < N:
                     pos.append(P[i]); vel.append(V[i]); cps.append(a[i]); stats.append(b[i])
             k += batch
+        if not pos and W > 0:                                            # :126-143 fallback: the direct A* path as one particle
+            direct = self._reconstruct_path_from_position([])
+            if direct and direct[0] == self.start_node and direct[-1] == self.target_node:
+                cells = cells_of(direct, self.cols)
+                st = self.engine.score_host([cells], self._sp)[0]
+                pos.append(np.zeros((W, 2))); vel.append(np.zeros((W, 2)))
+                cps.append(CellPath(cells, self.cols)); stats.append(st)
         if not pos:
             return False
         r = pfrng.AgentRandom(self.seed, pfrng.DOM_INIT, 1, 0)

@@ -1,4 +1,4 @@
-"""Run the A* / decode GPU parity tests against an alternative build of the library (A/B builds: -DPF_LOOP=0|1,
+"""Run the A* / decode GPU parity tests against an alternative build of the library (A/B builds:
 stress builds): PF_LIB=path/to/lib.so python scripts/run_parity_with_lib.py"""
 import os, sys
 sys.path[:0] = ["maaco-path-planing_amd", "tests", "oracle"]

@@ -353,19 +353,6 @@ def test_mpa_rebuild_golden():
                     assert np.array_equal(stats[j], z["stats"][i]), (gname, beta, i)
 
 
-@pytest.mark.parametrize("which", ["astar", "astar512", "decode", "decode512"])
-def test_four_agents_per_wave_path_matches(which):
-    """The 16-lane-row kernels (pf_astar16.h) must give the same bits as the goldens / oracle: force them on
-    for every batch size and re-run the connector and decode parity checks."""
-    e, _, _, _, _ = eng("fig7")
-    e.set_option("use16_min", 1)
-    try:
-        {"astar": test_astar_golden_both_variants, "astar512": test_astar_random_512_vs_oracle,
-         "decode": test_decode_and_score_golden, "decode512": test_decode_random_512_vs_oracle}[which]()
-    finally:
-        e.set_option("use16_min", 0x7fffffff)
-
-
 def test_maaco_eight_ants_per_wave_path_matches():
     """k_maaco_walk8 (8 ants per wavefront, in-loop refetch) == goldens: force it on for tiny batches too."""
     e, _, _, _, _ = eng("fig7")
