@@ -234,7 +234,9 @@ int pf_mpa_memory(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_sl
 /* Tuning knobs (results never change): "maaco_pack8_min" ants per batch from which eight ants share a wavefront
  * (default 2048); "mpa_prune" 0/1 exact bound pruning of MPA rebuilds (default 1).  Test hook: "astar_step_cap" > 0
  * lowers the connectors' step cap below the reference's 3RC / 2RC (astar.py:58, MPA.py:118) so that the cap path
- * (PF_ST_STEP_CAP) can be exercised; 0 restores the reference's value. */
+ * (PF_ST_STEP_CAP) can be exercised; 0 restores the reference's value.  "mpa_doubt_log_e15" / "mpa_doubt_round_e15":
+ * margins (in 1e-15; < 0 = default) inside which an MPA proposal is handed to the host's libm (tests widen them to
+ * force that route). */
 int pf_set_option(pf_handle* h, const char* name, int64_t value);
 
 /* ---- device self-tests (used by tests/ to pin device arithmetic) ----- */
@@ -248,6 +250,15 @@ int pf_selftest_sqrt(pf_handle* h, int32_t n, const int64_t* d_in, double* d_out
  * list, [34..37) draw counters after the randint / normal / choice runs. */
 int pf_selftest_rng(pf_handle* h, uint64_t seed, uint64_t dom, uint64_t it, uint64_t agent, uint64_t* d_u64,
                     double* d_f64, int64_t* d_i64);
+
+/* Target-cell proposals of MPA._get_levy_target_node / _get_brownian_target_node (MPA.py:250-282) for n keyed streams
+ * (seed, DOM_MPA, 0, i) from cells d_cur[i] (and elite cells d_elite[i], < 0 = None): the device arithmetic, with the
+ * proposals whose accept test / rounding lies within the libm-disagreement margin recomputed by the host's glibc
+ * exactly as the MPA sweeps do.  *n_doubt = how many took that route. */
+int pf_selftest_mpa_targets(pf_handle* h, uint64_t seed, int32_t n, int32_t is_levy, double beta, double sigma,
+                            double scale, const int32_t* d_cur, const int32_t* d_elite, int32_t* d_out, int64_t* n_doubt);
+/* proposals the host had to confirm since pf_create (expected: 0) */
+long long pf_mpa_doubts_resolved(pf_handle* h);
 
 #ifdef __cplusplus
 }

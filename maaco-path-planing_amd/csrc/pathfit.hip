@@ -1,6 +1,7 @@
 // pathfit.hip -- kernels K0..K7 and the C-ABI of libpathfit.so (gfx950 / MI355X).
 // See include/pathfit.h for the boundary and DESIGN.md for the data layout.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -714,21 +715,45 @@ struct MpaDev {
 PF_DEV long py_round(double x) { return (long)__builtin_rint(x); }
 PF_DEV int clampi(long v, int lo, int hi) { return (int)(v < lo ? lo : (v > hi ? hi : v)); }
 
+// ---- target-cell proposals (MPA.py:250-282) -------------------------------------------------------------------
+// The proposals are the one place on the path where libm transcendentals (log in normalvariate's accept test, pow /
+// sin / cos in the Levy step) feed a DISCRETE decision (an accept, a round()).  The device's ocml functions are not
+// glibc's, so a result is trusted only when it is far from every decision boundary: the functions below also report
+// `doubt` when an accept test or a rounding lies within a margin that dwarfs any 1-2 ulp disagreement (2^-33
+// relative for the accept test, 1e-7 absolute on the fraction for round()).  Doubtful proposals (expected never: ~1e-9
+// per call) are recomputed by the host with glibc itself (mpa_resolve_doubts) before the searches start.  Brownian
+// arithmetic other than the accept test is IEEE +,*,/,sqrt: bit-identical on both sides.
+struct Doubt { double eps_log, eps_round; bool hit; };
+PF_DEV double normalvariate_chk(Rng& g, double mu, double sigma, Doubt& d) {   // random.py normalvariate
+  double z;
+  for (;;) {
+    const double u1 = g.random();
+    const double u2 = 1.0 - g.random();
+    z = 1.7155277699214135 * (u1 - 0.5) / u2;
+    const double zz = z * z / 4.0, l = -log(u2);
+    if (fabs(zz - l) <= d.eps_log * (1.0 + fabs(l))) d.hit = true;
+    if (zz <= l) break;
+  }
+  return mu + z * sigma;
+}
+PF_DEV bool near_half(double x, double eps) { return fabs(fabs(x - __builtin_rint(x)) - 0.5) <= eps; }
 // MPA._get_levy_target_node, MPA.py:250-264
-PF_DEV int levy_target(Rng& g, const Grid& G, int cur, double scale, double beta, double sigma) {
-  const double u = g.normalvariate(0.0, sigma);
-  double v = g.normalvariate(0.0, 1.0);
+PF_DEV int levy_target(Rng& g, const Grid& G, int cur, double scale, double beta, double sigma, Doubt& d) {
+  const double u = normalvariate_chk(g, 0.0, sigma, d);
+  double v = normalvariate_chk(g, 0.0, 1.0, d);
   if (fabs(v) < 1e-9) v = 1e-9;
   double step = 0.05 * u / pow(fabs(v), 1.0 / beta) * scale;
   const double mx = (double)(G.R > G.C ? G.R : G.C) * 0.5;
   step = fmin(fmax(step, -mx), mx);
   const double ang = g.uniform(0.0, 2.0 * 3.141592653589793);
-  const long dr = py_round(step * sin(ang)), dc = py_round(step * cos(ang));
+  const double xr = step * sin(ang), xc = step * cos(ang);
+  if (near_half(xr, d.eps_round) || near_half(xc, d.eps_round)) d.hit = true;
+  const long dr = py_round(xr), dc = py_round(xc);
   const int r = row_of(G, cur), c = cur - r * G.C;
   return clampi(r + dr, 0, G.R - 1) * G.C + clampi(c + dc, 0, G.C - 1);
 }
 // MPA._get_brownian_target_node, MPA.py:266-282 (elite < 0 == None)
-PF_DEV int brownian_target(Rng& g, const Grid& G, int cur, int elite, double scale) {
+PF_DEV int brownian_target(Rng& g, const Grid& G, int cur, int elite, double scale, Doubt& d) {
   const int cr = row_of(G, cur), cc = cur - cr * G.C;
   long tr_, tc_;
   if (g.random() < 0.7 && elite >= 0) {
@@ -736,14 +761,14 @@ PF_DEV int brownian_target(Rng& g, const Grid& G, int cur, int elite, double sca
     const int dr = er - cr, dc = ec - cc;
     const double dist = __builtin_sqrt((double)((long)dr * dr + (long)dc * dc));
     if (dist > 1e-6) {
-      const double fac = fabs(g.normalvariate(0.0, 1.0));
+      const double fac = fabs(normalvariate_chk(g, 0.0, 1.0, d));
       long kk = py_round(scale * fac * 5.0); if (kk < 1) kk = 1;
       const double ms = dist < (double)kk ? dist : (double)kk;
       tr_ = cr + py_round((double)dr / dist * ms);
       tc_ = cc + py_round((double)dc / dist * ms);
     } else return elite;
   } else {
-    long m = py_round((double)(G.R > G.C ? G.R : G.C) * 0.1 * scale * fabs(g.normalvariate(0.0, 1.0)));
+    long m = py_round((double)(G.R > G.C ? G.R : G.C) * 0.1 * scale * fabs(normalvariate_chk(g, 0.0, 1.0, d)));
     if (m < 1) m = 1;
     const long dr = g.randint(-m, m);
     const long dc = g.randint(-m, m);
@@ -767,7 +792,57 @@ struct MpaPhaseArgs {
   int* out_cells; int* out_len; double* out_stats; int* status;
   // explicit mode (pf_mpa_rebuild_batch): no idx/gate draws
   const int* ex_idx; const int* ex_levy; const double* ex_scale; const int* ex_agent;
+  // proposals (k_mpa_propose, before the searches): prop[a] = {idx or -1 when the predator does not move, target cell}
+  int2* prop; int* doubt_list; int* doubt_n; double eps_log, eps_round;
 };
+
+// which path a predator modifies and which one it samples the elite node from (MPA.py:339-377), explicit mode included
+struct MpaPlan { bool is_levy; double scale, gate_p; const int* mod; int modL; const double* mod_stats; const int* ref; int refL;
+                 const int* prey; int preyL; const double* prey_stats; int gi, slot; };
+PF_DEV MpaPlan mpa_plan(const MpaPhaseArgs& p, int a) {
+  MpaPlan q;
+  q.gi = p.ex_idx ? p.ex_agent[a] : p.gidx[a];                   // index in the fitness-sorted population
+  q.slot = p.ex_idx ? a : p.slot[a];
+  q.prey = p.pop_cells + (size_t)q.slot * p.path_cap; q.preyL = p.pop_len[q.slot]; q.prey_stats = p.pop_stats + (size_t)q.slot * 5;
+  if (p.ex_idx) { q.is_levy = p.ex_levy[a] != 0; q.scale = p.ex_scale[a]; q.mod = q.prey; q.modL = q.preyL; q.mod_stats = q.prey_stats; q.ref = p.elite_cells; q.refL = p.elite_len; }
+  else if (p.phase == 1) { q.is_levy = false; q.scale = p.m.P; q.mod = q.prey; q.modL = q.preyL; q.mod_stats = q.prey_stats; q.ref = p.elite_cells; q.refL = p.elite_len; }
+  else if (p.phase == 2) {
+    q.is_levy = q.gi < p.m.N / 2;                                 // :351
+    q.scale = q.is_levy ? p.m.P : p.m.P * p.CF;                   // :354
+    q.mod = q.is_levy ? q.prey : p.elite_cells; q.modL = q.is_levy ? q.preyL : p.elite_len;
+    q.mod_stats = q.is_levy ? q.prey_stats : p.elite_stats;
+    q.ref = q.is_levy ? p.elite_cells : q.prey; q.refL = q.is_levy ? p.elite_len : q.preyL;
+  } else { q.is_levy = true; q.scale = p.m.P * p.CF; q.mod = p.elite_cells; q.modL = p.elite_len; q.mod_stats = p.elite_stats; q.ref = q.prey; q.refL = q.preyL; }
+  q.gate_p = p.phase == 1 ? p.m.P : q.scale;                      // :344 / :359 / :372
+  return q;
+}
+// Proposal pass, one thread per predator: the gating draws (:343-344 etc.), the target cell, the work estimate of the
+// longest-first queue, and the list of predators whose proposal the host has to confirm (see Doubt).
+__global__ void k_mpa_propose(MpaPhaseArgs p, float* est) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= p.n) return;
+  const MpaPlan q = mpa_plan(p, a);
+  int idx = -1, inter = -1;
+  Doubt d; d.eps_log = p.eps_log; d.eps_round = p.eps_round; d.hit = false;
+  Rng g; g.init(p.seed, DOM_MPA, (unsigned long long)p.iter, (unsigned long long)q.gi);
+  if (p.ex_idx ? (q.modL > 0 && p.ex_idx[a] < q.modL - 1) : (q.modL > 1)) {    // explicit: the :286 early return
+    const int i0 = p.ex_idx ? p.ex_idx[a] : (int)g.randint(0, q.modL - 2);      // :343 / :358 / :371
+    if (p.ex_idx || g.random() < q.gate_p) {
+      idx = i0;
+      const int cur = q.mod[idx];
+      if (q.is_levy) inter = levy_target(g, p.c.G, cur, q.scale, p.m.levy_beta, p.m.sigma, d);
+      else {
+        int en = -1;
+        if (q.refL > 0) en = q.ref[(int)g.randbelow((unsigned long long)q.refL)];   // random.choice :248
+        inter = brownian_target(g, p.c.G, cur, en, q.scale, d);
+      }
+    }
+  }
+  p.prop[a] = make_int2(idx, inter);
+  if (est) est[a] = idx >= 0 ? (float)(q.modL - idx) : 0.f;
+  if (d.hit && idx >= 0) { const int at = atomicAdd(p.doubt_n, 1); p.doubt_list[at] = a; }
+}
+
 
 // One predator of one phase sweep, MPA.py:339-377 + _reconstruct_path_segment :284-318.
 __device__ __forceinline__ void mpa_phase_item(const MpaPhaseArgs& p, int a, Slot& s, const Open& O, AStat& tot,
@@ -775,42 +850,22 @@ __device__ __forceinline__ void mpa_phase_item(const MpaPhaseArgs& p, int a, Slo
   const Grid& G = p.c.G;
   const int RC = G.R * G.C;
   {
-    const int gi = p.ex_idx ? p.ex_agent[a] : p.gidx[a];         // index in the fitness-sorted population
-    const int slot = p.ex_idx ? a : p.slot[a];
-    const int* prey = p.pop_cells + (size_t)slot * p.path_cap;
-    const int preyL = p.pop_len[slot];
-    const double* prey_stats = p.pop_stats + (size_t)slot * 5;
+    const MpaPlan q = mpa_plan(p, a);
+    const int* prey = q.prey; const double* prey_stats = q.prey_stats;
+    const int* mod = q.mod; const int modL = q.modL; const double* mod_stats = q.mod_stats;
     int* out = p.out_cells + (size_t)a * p.path_cap;
-    // which path is modified / which one is the elite-node reference
-    bool is_levy; double scale; const int* mod; int modL; const double* mod_stats; const int* ref; int refL;
-    if (p.ex_idx) { is_levy = p.ex_levy[a] != 0; scale = p.ex_scale[a]; mod = prey; modL = preyL; mod_stats = prey_stats; ref = p.elite_cells; refL = p.elite_len; }
-    else if (p.phase == 1) { is_levy = false; scale = p.m.P; mod = prey; modL = preyL; mod_stats = prey_stats; ref = p.elite_cells; refL = p.elite_len; }
-    else if (p.phase == 2) {
-      is_levy = gi < p.m.N / 2;                                   // :351
-      scale = is_levy ? p.m.P : p.m.P * p.CF;                     // :354
-      mod = is_levy ? prey : p.elite_cells; modL = is_levy ? preyL : p.elite_len;
-      mod_stats = is_levy ? prey_stats : p.elite_stats;
-      ref = is_levy ? p.elite_cells : prey; refL = is_levy ? p.elite_len : preyL;
-    } else { is_levy = true; scale = p.m.P * p.CF; mod = p.elite_cells; modL = p.elite_len; mod_stats = p.elite_stats; ref = prey; refL = preyL; }
-    const double gate_p = p.phase == 1 ? p.m.P : scale;           // :344 / :359 / :372
     int rc = 4, n = modL;                                         // default: the unmodified path + its stats
     bool rebuilt = false;
-    Rng g; g.init(p.seed, DOM_MPA, (unsigned long long)p.iter, (unsigned long long)gi);
-    if (p.ex_idx ? (modL > 0 && p.ex_idx[a] < modL - 1) : (modL > 1)) {   // explicit: the :286 early return
-      const int idx = p.ex_idx ? p.ex_idx[a] : (int)g.randint(0, modL - 2);   // :343 / :358 / :371
-      if (p.ex_idx || g.random() < gate_p) {
+    {
+      const int2 pr = p.prop[a];                                  // k_mpa_propose: {idx or -1, target cell}
+      const int idx = first_i(pr.x);
+      if (idx >= 0) {
         // ---- _reconstruct_path_segment(mod, ref, idx, is_levy, scale) ----
         // (idx <= modL-2 so the :286 early return cannot trigger)
         slot_begin_eval(s, RC, lane);
         const int cur = mod[idx];
         mark_avoid(s, mod, idx, lane);                            // set(prefix[:-1]) :290
-        int inter;
-        if (is_levy) inter = levy_target(g, G, cur, scale, p.m.levy_beta, p.m.sigma);
-        else {
-          int en = -1;
-          if (refL > 0) en = ref[(int)g.randbelow((unsigned long long)refL)];   // random.choice :248
-          inter = brownian_target(g, G, cur, en, scale);
-        }
+        const int inter = first_i(pr.y);
 #ifdef PF_TRACE
         if (lane == 0 && a < 8192) { g_trace3[4 * a] = 1 + idx; g_trace3[4 * a + 1] = inter; g_trace3[4 * a + 2] = cur; }
 #endif
@@ -1036,38 +1091,22 @@ __device__ __forceinline__ void mpa_sweep_item(const MpaSweepArgs& q, int item, 
   // FADs state
   int slot = 0; bool have = false, have_stats = false;
   if (isph) {
-    const int gi = p.gidx[a];                                    // index in the fitness-sorted population
-    slot = p.slot[a];
-    const int* prey = p.pop_cells + (size_t)slot * p.path_cap;
-    const int preyL = p.pop_len[slot];
-    const double* prey_stats = p.pop_stats + (size_t)slot * 5;
+    const MpaPlan q = mpa_plan(p, a);
+    slot = q.slot;
+    const int* prey = q.prey;
+    const double* prey_stats = q.prey_stats;
     out = p.out_cells + (size_t)a * p.path_cap;
-    bool is_levy; double scale; const int* ref; int refL;
-    if (p.phase == 1) { is_levy = false; scale = p.m.P; mod = prey; modL = preyL; mod_stats = prey_stats; ref = p.elite_cells; refL = p.elite_len; }
-    else if (p.phase == 2) {
-      is_levy = gi < p.m.N / 2;                                   // :351
-      scale = is_levy ? p.m.P : p.m.P * p.CF;                     // :354
-      mod = is_levy ? prey : p.elite_cells; modL = is_levy ? preyL : p.elite_len;
-      mod_stats = is_levy ? prey_stats : p.elite_stats;
-      ref = is_levy ? p.elite_cells : prey; refL = is_levy ? p.elite_len : preyL;
-    } else { is_levy = true; scale = p.m.P * p.CF; mod = p.elite_cells; modL = p.elite_len; mod_stats = p.elite_stats; ref = prey; refL = preyL; }
-    const double gate_p = p.phase == 1 ? p.m.P : scale;           // :344 / :359 / :372
+    mod = q.mod; modL = q.modL; mod_stats = q.mod_stats;
     n = modL;                                                     // default: the unmodified path + its stats
-    Rng g; g.init(p.seed, DOM_MPA, (unsigned long long)p.iter, (unsigned long long)gi);
-    if (modL > 1) {
-      const int idx = (int)g.randint(0, modL - 2);                // :343 / :358 / :371
-      if (g.random() < gate_p) {
+    {
+      const int2 pr = p.prop[a];                                  // k_mpa_propose: {idx or -1, target cell}
+      const int idx = first_i(pr.x);
+      if (idx >= 0) {
         // ---- _reconstruct_path_segment(mod, ref, idx, is_levy, scale) ----
         slot_begin_eval(s, RC, lane);
         const int cur = mod[idx];
         mark_avoid(s, mod, idx, lane);                            // set(prefix[:-1]) :290
-        int inter;
-        if (is_levy) inter = levy_target(g, G, cur, scale, p.m.levy_beta, p.m.sigma);
-        else {
-          int en = -1;
-          if (refL > 0) en = ref[(int)g.randbelow((unsigned long long)refL)];   // random.choice :248
-          inter = brownian_target(g, G, cur, en, scale);
-        }
+        const int inter = first_i(pr.y);
         bool pruned = false;                                      // exact pruning: see mpa_phase_item
         if (p.m.dt) {
           double pre = 0.0;
@@ -1220,26 +1259,7 @@ __global__ __launch_bounds__(64) void k_mpa_apply(int n, int path_cap, const int
   if (threadIdx.x == 0) pop_len[slot] = L;
 }
 
-// work estimates for the two MPA sweeps: replay only the gating draws of each predator's stream
-__global__ void k_plan_mpa_phase(MpaPhaseArgs p, float* est) {
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= p.n) return;
-  float e = 0.f;
-  if (p.ex_idx) { const int L = p.pop_len[a]; e = p.ex_idx[a] < L - 1 ? (float)(L - p.ex_idx[a]) : 0.f; }
-  else {
-    const int gi = p.gidx[a], slot = p.slot[a];
-    int modL; double gate_p;
-    if (p.phase == 1) { modL = p.pop_len[slot]; gate_p = p.m.P; }
-    else if (p.phase == 2) { const bool lv = gi < p.m.N / 2; modL = lv ? p.pop_len[slot] : p.elite_len; gate_p = lv ? p.m.P : p.m.P * p.CF; }
-    else { modL = p.elite_len; gate_p = p.m.P * p.CF; }
-    if (modL > 1) {
-      Rng g; g.init(p.seed, DOM_MPA, (unsigned long long)p.iter, (unsigned long long)gi);
-      const int idx = (int)g.randint(0, modL - 2);
-      if (g.random() < gate_p) e = (float)(modL - idx);
-    }
-  }
-  est[a] = e;
-}
+// work estimates of the FADs detours (the phase items' come from k_mpa_propose): replay only the gating draws
 __global__ void k_plan_mpa_fads(MpaFadsArgs p, float* est) {
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= p.n) return;
@@ -1296,6 +1316,17 @@ __global__ void k_selftest_rng(unsigned long long seed, unsigned long long dom, 
   i64[36] = (long long)g.ctr;
 }
 
+// proposals of n keyed streams (seed, DOM_MPA, 0, i) from given cells: the device arithmetic + its doubt flags
+__global__ void k_selftest_targets(Grid G, unsigned long long seed, int n, int is_levy, double beta, double sigma, double scale,
+                                   const int* cur, const int* elite, double eps_log, double eps_round, int* out, unsigned char* flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Rng g; g.init(seed, DOM_MPA, 0, (unsigned long long)i);
+  Doubt d; d.eps_log = eps_log; d.eps_round = eps_round; d.hit = false;
+  out[i] = is_levy ? levy_target(g, G, cur[i], scale, beta, sigma, d) : brownian_target(g, G, cur[i], elite[i], scale, d);
+  flag[i] = d.hit ? 1 : 0;
+}
+
 // ===========================================================================
 // host side
 // ===========================================================================
@@ -1335,7 +1366,10 @@ struct pf_handle {
   double* d_elite_stats = nullptr;
   int* d_init_cells = nullptr; int init_len = 0; int init_cap = 0; double* d_init_stats = nullptr;
   double* d_ds = nullptr; double* d_dt = nullptr;   // static shortest distances from the start / to the target (pruning bounds)
-  float* d_est = nullptr; int* d_queue = nullptr; int est_cap = 0;
+  float* d_est = nullptr; float* d_est2 = nullptr; int* d_iota = nullptr; int* d_queue = nullptr; int est_cap = 0;
+  void* d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
+  int2* d_prop = nullptr; int* d_doubt = nullptr; int prop_cap = 0;   // MPA proposals {idx, target cell}; doubt list [0] = count, [1..] = predators
+  long long doubts_resolved = 0;
 };
 
 static long long g_step_cap = 0;   // > 0: lowers the connectors' step cap (pf_set_option "astar_step_cap": tests of the cap path)
@@ -1438,7 +1472,7 @@ void pf_destroy(pf_handle* h) {
   (void)hipSetDevice(h->device);
   void* ptrs[] = {h->d_occ, h->d_mm_r1, h->d_mm_r0, h->d_mm_r1_nd, h->d_mm_r0_nd, h->d_d2near, h->d_rec, h->d_slot_state,
                   h->d_work, h->d_cnt, h->d_pen, h->d_tier2, h->d_tau, h->d_taua, h->d_eta, h->d_dep, h->d_tep, h->d_visit, h->d_visit_epoch,
-                  h->d_bits, h->d_tmp, h->d_elite_stats, h->d_init_cells, h->d_init_stats, h->d_est, h->d_queue,
+                  h->d_bits, h->d_tmp, h->d_elite_stats, h->d_init_cells, h->d_init_stats, h->d_est, h->d_est2, h->d_iota, h->d_queue, h->d_sort_tmp, h->d_prop, h->d_doubt,
                   h->d_comp[0], h->d_comp[1], h->d_comp[2], h->d_comp[3], h->d_ds, h->d_dt};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1464,6 +1498,8 @@ static int env_int(const char* name, int dflt) { const char* v = getenv(name); r
 static const int kSlotsPerCU = 8;                       // resident one-agent waves per CU at most
 static const int kWavesPerCU = env_int("PF_WAVES_PER_CU", 8);   // resident one-agent waves per CU (LDS permitting)
 static int g_mpa_prune = 1;   // exact bound pruning of MPA rebuilds (pf_set_option "mpa_prune")
+static double g_doubt_log = 1.0 / 8589934592.0;   // 2^-33 relative margin on normalvariate's accept test (pf_set_option "mpa_doubt_log_e15" overrides, in 1e-15)
+static double g_doubt_round = 1e-7;                // absolute margin on the fraction fed to round()   ("mpa_doubt_round_e15")
 static int g_maaco_pack8_min = env_int("PF_MAACO_PACK8_MIN", 2048);   // ants per batch from which 8 ants share a wavefront
 static const int kLdsS = 16;
 static int ensure_slots(pf_handle* h, int allow_diag = 1, int restrict_corner = 1) {
@@ -1513,26 +1549,28 @@ static int end_batch(pf_handle* h, DevCounters* dc) {
   return 0;
 }
 
-// Sort the batch longest-expected-first from per-agent estimates produced by `plan` (a functor that
-// launches a plan kernel writing h->d_est[0..n)).
+// Sort the batch longest-expected-first from per-agent estimates produced by `plan` (a functor that launches plan
+// kernels writing h->d_est[0..n)): a stable device radix sort (hipCUB) of (estimate, index) pairs, descending.  Nothing
+// crosses PCIe and nothing waits: the sweep is queued behind it on the same stream.
+__global__ void k_iota(int* v, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) v[i] = i; }
 template <typename Plan>
 static int make_queue(pf_handle* h, int n, Plan plan) {
   if (n > h->est_cap) {
-    if (h->d_est) CK(hipFree(h->d_est));
-    if (h->d_queue) CK(hipFree(h->d_queue));
-    CK(hipMalloc(&h->d_est, sizeof(float) * (size_t)n)); CK(hipMalloc(&h->d_queue, sizeof(int) * (size_t)n));
+    for (void* q : {(void*)h->d_est, (void*)h->d_est2, (void*)h->d_iota, (void*)h->d_queue}) if (q) CK(hipFree(q));
+    CK(hipMalloc(&h->d_est, sizeof(float) * (size_t)n)); CK(hipMalloc(&h->d_est2, sizeof(float) * (size_t)n));
+    CK(hipMalloc(&h->d_iota, sizeof(int) * (size_t)n)); CK(hipMalloc(&h->d_queue, sizeof(int) * (size_t)n));
+    hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_iota, n);
     h->est_cap = n;
   }
   plan(h->d_est);
   CK(hipGetLastError());
-  std::vector<float> est(n);
-  CK(hipMemcpyAsync(est.data(), h->d_est, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
-  CK(hipStreamSynchronize(h->stream));
-  std::vector<int> q(n);
-  for (int i = 0; i < n; ++i) q[i] = i;
-  std::stable_sort(q.begin(), q.end(), [&](int a, int b) { return est[a] > est[b]; });
-  CK(hipMemcpyAsync(h->d_queue, q.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, h->stream));
-  CK(hipStreamSynchronize(h->stream));
+  size_t need = 0;
+  CK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, need, h->d_est, h->d_est2, h->d_iota, h->d_queue, n, 0, 32, h->stream));
+  if (need > h->sort_tmp_bytes) {
+    if (h->d_sort_tmp) CK(hipFree(h->d_sort_tmp));
+    CK(hipMalloc(&h->d_sort_tmp, need)); h->sort_tmp_bytes = need;
+  }
+  CK(hipcub::DeviceRadixSort::SortPairsDescending(h->d_sort_tmp, need, h->d_est, h->d_est2, h->d_iota, h->d_queue, n, 0, 32, h->stream));
   return 0;
 }
 
@@ -1698,6 +1736,8 @@ int pf_set_option(pf_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "astar_step_cap")) { g_step_cap = value > 0 ? (long long)value : 0; return 0; }
   if (!strcmp(name, "maaco_pack8_min")) { g_maaco_pack8_min = (int)value; return 0; }
   if (!strcmp(name, "mpa_prune")) { g_mpa_prune = value != 0; return 0; }
+  if (!strcmp(name, "mpa_doubt_log_e15")) { g_doubt_log = value < 0 ? 1.0 / 8589934592.0 : (double)value * 1e-15; return 0; }
+  if (!strcmp(name, "mpa_doubt_round_e15")) { g_doubt_round = value < 0 ? 1e-7 : (double)value * 1e-15; return 0; }
   return failmsg(h, std::string("pf_set_option: unknown option ") + name);
 }
 int pf_selftest_sqrt(pf_handle* h, int32_t n, const int64_t* d_in, double* d_out) {
@@ -1927,6 +1967,17 @@ struct HostRng {                               // pathfit/rng.py AgentRandom
     return r;
   }
   int64_t randint(int64_t a, int64_t b) { return a + (int64_t)randbelow((uint64_t)(b - a + 1)); }
+  double uniform(double a, double b) { return a + (b - a) * random(); }
+  double normalvariate(double mu, double sigma) {   // random.py normalvariate, glibc log as math.log
+    double z;
+    for (;;) {
+      const double u1 = random(), u2 = 1.0 - random();
+      z = 1.7155277699214135 * (u1 - 0.5) / u2;
+      const double zz = z * z / 4.0;
+      if (zz <= -log(u2)) break;
+    }
+    return mu + z * sigma;
+  }
 };
 }  // namespace
 
@@ -2073,6 +2124,106 @@ static MpaDev mpa_dev(const pf_handle* h) {
   return m;
 }
 
+// ---- proposals: k_mpa_propose, then the host confirms the (expected: zero) doubtful ones with glibc ----
+static int mpa_launch_propose(pf_handle* h, MpaPhaseArgs& a, float* est) {
+  const int n = a.n;
+  if (n > h->prop_cap) {
+    if (h->d_prop) CK(hipFree(h->d_prop));
+    if (h->d_doubt) CK(hipFree(h->d_doubt));
+    CK(hipMalloc(&h->d_prop, sizeof(int2) * (size_t)n)); CK(hipMalloc(&h->d_doubt, sizeof(int) * ((size_t)n + 1)));
+    h->prop_cap = n;
+  }
+  a.prop = h->d_prop; a.doubt_n = h->d_doubt; a.doubt_list = h->d_doubt + 1; a.eps_log = g_doubt_log; a.eps_round = g_doubt_round;
+  CK(hipMemsetAsync(h->d_doubt, 0, sizeof(int), h->stream));
+  if (n > 0) hipLaunchKernelGGL(k_mpa_propose, dim3((n + 255) / 256), dim3(256), 0, h->stream, a, est);
+  CK(hipGetLastError());
+  return 0;
+}
+static int d2h_bytes(pf_handle* h, const void* d, void* out, size_t nb) { CK(hipMemcpyAsync(out, d, nb, hipMemcpyDeviceToHost, h->stream)); CK(hipStreamSynchronize(h->stream)); return 0; }
+#define d2h_one(h, d, out) d2h_bytes(h, (const void*)(d), (void*)(out), sizeof(*(out)))
+static long host_round(double x) { return (long)nearbyint(x); }     // Python round(): half to even
+static int host_clamp(long v, int lo, int hi) { return (int)(v < lo ? lo : (v > hi ? hi : v)); }
+// MPA.py:250-282 on the host (glibc log / pow / sin / cos: what CPython's math module calls)
+static int host_levy(HostRng& g, int R, int C, int cur, double scale, double beta, double sigma) {
+  const double u = g.normalvariate(0.0, sigma);
+  double v = g.normalvariate(0.0, 1.0);
+  if (fabs(v) < 1e-9) v = 1e-9;
+  double step = 0.05 * u / pow(fabs(v), 1.0 / beta) * scale;
+  const double mx = (double)(R > C ? R : C) * 0.5;
+  step = fmin(fmax(step, -mx), mx);
+  const double ang = g.uniform(0.0, 2.0 * 3.141592653589793);
+  const long dr = host_round(step * sin(ang)), dc = host_round(step * cos(ang));
+  return host_clamp(cur / C + dr, 0, R - 1) * C + host_clamp(cur % C + dc, 0, C - 1);
+}
+static int host_brownian(HostRng& g, int R, int C, int cur, int elite, double scale) {
+  const int cr = cur / C, cc = cur % C;
+  long tr_, tc_;
+  if (g.random() < 0.7 && elite >= 0) {
+    const int dr = elite / C - cr, dc = elite % C - cc;
+    const double dist = sqrt((double)((long)dr * dr + (long)dc * dc));
+    if (dist > 1e-6) {
+      const double fac = fabs(g.normalvariate(0.0, 1.0));
+      long kk = host_round(scale * fac * 5.0); if (kk < 1) kk = 1;
+      const double ms = dist < (double)kk ? dist : (double)kk;
+      tr_ = cr + host_round((double)dr / dist * ms);
+      tc_ = cc + host_round((double)dc / dist * ms);
+    } else return elite;
+  } else {
+    long m = host_round((double)(R > C ? R : C) * 0.1 * scale * fabs(g.normalvariate(0.0, 1.0)));
+    if (m < 1) m = 1;
+    const long dr = g.randint(-m, m);
+    const long dc = g.randint(-m, m);
+    tr_ = cr + dr; tc_ = cc + dc;
+  }
+  return host_clamp(tr_, 0, R - 1) * C + host_clamp(tc_, 0, C - 1);
+}
+// Recompute the proposals the device flagged (a decision within the margin of a libm disagreement) with the host's
+// libm and patch them in.  One small D2H (the count) per sweep; the rest only when the count is not zero.
+static int mpa_resolve_doubts(pf_handle* h, const MpaPhaseArgs& a) {
+  int nd = 0;
+  if (d2h_one(h, a.doubt_n, &nd)) return -1;
+  if (nd <= 0) return 0;
+  std::vector<int> list((size_t)nd);
+  CK(hipMemcpyAsync(list.data(), a.doubt_list, sizeof(int) * (size_t)nd, hipMemcpyDeviceToHost, h->stream));
+  CK(hipStreamSynchronize(h->stream));
+  const int R = h->R, C = h->C;
+  for (int a_ : list) {
+    int gi = 0, slot = a_, preyL = 0;
+    if (a.ex_idx) { if (d2h_one(h, a.ex_agent + a_, &gi)) return -1; }
+    else { if (d2h_one(h, a.gidx + a_, &gi) || d2h_one(h, a.slot + a_, &slot)) return -1; }
+    if (d2h_one(h, a.pop_len + slot, &preyL)) return -1;
+    const int* prey = a.pop_cells + (size_t)slot * a.path_cap;
+    bool is_levy; double scale; const int* mod; int modL; const int* ref; int refL;
+    if (a.ex_idx) {
+      int lv = 0; double sc = 0.0;
+      if (d2h_one(h, a.ex_levy + a_, &lv) || d2h_one(h, a.ex_scale + a_, &sc)) return -1;
+      is_levy = lv != 0; scale = sc; mod = prey; modL = preyL; ref = a.elite_cells; refL = a.elite_len;
+    } else if (a.phase == 1) { is_levy = false; scale = a.m.P; mod = prey; modL = preyL; ref = a.elite_cells; refL = a.elite_len; }
+    else if (a.phase == 2) {
+      is_levy = gi < a.m.N / 2; scale = is_levy ? a.m.P : a.m.P * a.CF;
+      mod = is_levy ? prey : a.elite_cells; modL = is_levy ? preyL : a.elite_len;
+      ref = is_levy ? a.elite_cells : prey; refL = is_levy ? a.elite_len : preyL;
+    } else { is_levy = true; scale = a.m.P * a.CF; mod = a.elite_cells; modL = a.elite_len; ref = prey; refL = preyL; }
+    HostRng g(a.seed, DOM_MPA, (uint64_t)a.iter, (uint64_t)gi);
+    int idx;
+    if (a.ex_idx) { if (d2h_one(h, a.ex_idx + a_, &idx)) return -1; }
+    else { idx = (int)g.randint(0, modL - 2); (void)g.random(); }   // the gate passed (no libm in it): same draws
+    int cur = 0, inter;
+    if (d2h_one(h, mod + idx, &cur)) return -1;
+    if (is_levy) inter = host_levy(g, R, C, cur, scale, a.m.levy_beta, a.m.sigma);
+    else {
+      int en = -1;
+      if (refL > 0) { const int k = (int)g.randbelow((uint64_t)refL); if (d2h_one(h, ref + k, &en)) return -1; }
+      inter = host_brownian(g, R, C, cur, en, scale);
+    }
+    const int2 v = make_int2(idx, inter);
+    CK(hipMemcpyAsync(a.prop + a_, &v, sizeof(int2), hipMemcpyHostToDevice, h->stream));
+    CK(hipStreamSynchronize(h->stream));
+    h->doubts_resolved += 1;
+  }
+  return 0;
+}
+
 int pf_mpa_phase_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uint64_t seed, int32_t n,
                        int32_t path_cap, const int32_t* d_pop_cells, const int32_t* d_pop_len,
                        const double* d_pop_stats, const int32_t* d_gidx, const int32_t* d_slot, const int32_t* d_elite_cells,
@@ -2092,10 +2243,10 @@ int pf_mpa_phase_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uin
   a.elite_stats = d_elite_stats;
   a.out_cells = d_out_cells; a.out_len = d_out_len; a.out_stats = d_out_stats; a.status = d_status;
   a.ex_idx = nullptr; a.ex_levy = nullptr; a.ex_scale = nullptr; a.ex_agent = nullptr;
-  if (n > 64) {
-    if (make_queue(h, n, [&](float* est) { hipLaunchKernelGGL(k_plan_mpa_phase, dim3((n + 255) / 256), dim3(256), 0, h->stream, a, est); })) return -1;
-    a.c.queue = h->d_queue;
-  }
+  int prc = 0;
+  if (make_queue(h, n > 0 ? n : 1, [&](float* est) { prc = mpa_launch_propose(h, a, est); })) return -1;
+  if (prc || mpa_resolve_doubts(h, a)) return -1;
+  a.c.queue = n > 64 ? h->d_queue : nullptr;
   return launch_with_retry(h, k_mpa_phase, a, n);
 }
 
@@ -2117,6 +2268,7 @@ int pf_mpa_rebuild_batch(pf_handle* h, int32_t iter, uint64_t seed, int32_t n, i
   a.elite_cells = d_elite_cells; a.elite_len = elite_len; a.elite_stats = d_pop_stats;
   a.out_cells = d_out_cells; a.out_len = d_out_len; a.out_stats = d_out_stats; a.status = d_status;
   a.ex_idx = d_idx; a.ex_levy = d_is_levy; a.ex_scale = d_scale; a.ex_agent = d_agent;
+  if (mpa_launch_propose(h, a, nullptr) || mpa_resolve_doubts(h, a)) return -1;
   return launch_with_retry(h, k_mpa_phase, a, n);
 }
 
@@ -2171,10 +2323,12 @@ int pf_mpa_iter_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uint
   a.fd.tmp_cells = nullptr; a.fd.status = d_status;
   a.fd.init_cells = h->d_init_cells; a.fd.init_len = h->init_len; a.fd.init_stats = h->d_init_stats;
   a.fd.cand_cells = d_c2_cells; a.fd.cand_len = d_c2_len; a.fd.cand_stats = d_c2_stats;
+  int prc = 0;
   if (make_queue(h, 2 * n, [&](float* est) {
-        hipLaunchKernelGGL(k_plan_mpa_phase, dim3((n + 255) / 256), dim3(256), 0, h->stream, a.ph, est);
+        prc = mpa_launch_propose(h, a.ph, est);
         hipLaunchKernelGGL(k_plan_mpa_fads, dim3((n + 255) / 256), dim3(256), 0, h->stream, a.fd, est + n);
       })) return -1;
+  if (prc || mpa_resolve_doubts(h, a.ph)) return -1;
   a.ph.c.queue = h->d_queue; a.fd.c.queue = h->d_queue;
   const int S = kLdsS;
   a.ph.c.S = S; a.fd.c.S = S; a.ph.c.retry = 0; a.fd.c.retry = 0;
@@ -2207,6 +2361,38 @@ int pf_mpa_memory(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_sl
                      d_cand_stats, d_pop_cells, d_pop_len, d_pop_stats);
   CK(hipGetLastError());
   CK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+
+long long pf_mpa_doubts_resolved(pf_handle* h) { return h ? h->doubts_resolved : 0; }
+
+int pf_selftest_mpa_targets(pf_handle* h, uint64_t seed, int32_t n, int32_t is_levy, double beta, double sigma, double scale,
+                            const int32_t* d_cur, const int32_t* d_elite, int32_t* d_out, int64_t* n_doubt) {
+  if (!h || n < 0 || !d_cur || !d_elite || !d_out) return failmsg(h, "pf_selftest_mpa_targets: bad arguments");
+  if (n == 0) return 0;
+  CK(hipSetDevice(h->device));
+  unsigned char* d_flag = nullptr;
+  CK(hipMalloc(&d_flag, (size_t)n));
+  const Grid G = make_grid(h, 1, 1);
+  hipLaunchKernelGGL(k_selftest_targets, dim3((n + 255) / 256), dim3(256), 0, h->stream, G, (unsigned long long)seed, n, is_levy, beta, sigma,
+                     scale, d_cur, d_elite, g_doubt_log, g_doubt_round, d_out, d_flag);
+  CK(hipGetLastError());
+  std::vector<unsigned char> flag((size_t)n);
+  CK(hipMemcpyAsync(flag.data(), d_flag, (size_t)n, hipMemcpyDeviceToHost, h->stream));
+  CK(hipStreamSynchronize(h->stream));
+  long long nd = 0;
+  for (int i = 0; i < n; ++i) if (flag[i]) {                      // the same hand-over as mpa_resolve_doubts
+    int cur = 0, el = 0;
+    if (d2h_one(h, d_cur + i, &cur) || d2h_one(h, d_elite + i, &el)) { (void)hipFree(d_flag); return -1; }
+    HostRng g(seed, DOM_MPA, 0, (uint64_t)i);
+    const int t = is_levy ? host_levy(g, h->R, h->C, cur, scale, beta, sigma) : host_brownian(g, h->R, h->C, cur, el, scale);
+    CK(hipMemcpyAsync(d_out + i, &t, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    CK(hipStreamSynchronize(h->stream));
+    nd += 1;
+  }
+  (void)hipFree(d_flag);
+  if (n_doubt) *n_doubt = nd;
   return 0;
 }
 

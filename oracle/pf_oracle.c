@@ -202,6 +202,12 @@ static int64_t reconstruct(orc_ws* w, int start, int target, int32_t* out, int64
   return n;
 }
 
+/* Test hook: > 0 lowers the step cap of both connectors below the reference's 3RC / 2RC, so that the cap path can be
+ * exercised (the reference's own caps cannot be reached on any grid tried: DESIGN.md 2).  Mirrors the product's
+ * pf_set_option("astar_step_cap"). */
+static int64_t g_step_cap_override = 0;
+ORC_API void orc_set_step_cap(int64_t cap) { g_step_cap_override = cap > 0 ? cap : 0; }
+
 /* variant 0: AStarSolver.solve, astar.py:33-101.  avoid = nodes_to_avoid as a
  * per-cell byte mask (or NULL).  Returns path length in cells, 0 for [],
  * -1 if `cap` is too small. */
@@ -218,6 +224,7 @@ static int64_t astar_v0(orc_ws* w, const uint8_t* occ, int R, int C, int allow_d
   orc_ent e0 = {hzero ? 0.0 : orc_dist(sr, sc, tr, tc), 0.0, start};               /* :45 / dijkstra.py:45 */
   heap_push(&w->h, e0); st[1]++;
   int64_t max_steps = (int64_t)R * C * 3, steps = 0;                               /* :58 */
+  if (g_step_cap_override > 0 && g_step_cap_override < max_steps) max_steps = g_step_cap_override;
   int32_t nb[8];
   while (w->h.n > 0 && steps < max_steps) {                                        /* :60 */
     steps++;
@@ -275,6 +282,7 @@ static int64_t astar_v1(orc_ws* w, const uint8_t* occ, int R, int C, int allow_d
   orc_ent e0 = {0 + orc_dist(sr, sc, tr, tc), 0.0, start};                               /* :113 */
   heap_push(&w->h, e0); st[1]++;
   int64_t max_steps = (int64_t)R * C * 2, steps = 0;                                     /* :118 */
+  if (g_step_cap_override > 0 && g_step_cap_override < max_steps) max_steps = g_step_cap_override;
   while (w->h.n > 0 && steps < max_steps) {
     steps++;
     orc_ent cur = heap_pop(&w->h);                                                       /* :122 */
@@ -674,6 +682,16 @@ ORC_API int orc_mpa_brownian_target(orc_rng* g, int R, int C, int cur, int elite
     tr_ = cr + dr; tc_ = cc + dc;
   }
   return clampi(tr_, 0, R - 1) * C + clampi(tc_, 0, C - 1);
+}
+
+/* n proposals from the keyed streams (seed, DOM_MPA = 2, 0, i): the checker of pf_selftest_mpa_targets */
+ORC_API void orc_mpa_targets_batch(uint64_t seed, int64_t n, int is_levy, int R, int C, const int32_t* cur, const int32_t* elite,
+                                   double scale, double levy_beta, double sigma, int32_t* out) {
+  for (int64_t i = 0; i < n; ++i) {
+    orc_rng g; orc_rng_init(&g, seed, 2, 0, (uint64_t)i);
+    out[i] = is_levy ? orc_mpa_levy_target(&g, R, C, cur[i], scale, levy_beta, sigma)
+                     : orc_mpa_brownian_target(&g, R, C, cur[i], elite[i], scale);
+  }
 }
 
 /* MPA._reconstruct_path_segment MPA.py:284-318.  The caller has positioned

@@ -68,8 +68,23 @@ def lib():
         L.orc_mpa_rebuild.restype = i64
         L.orc_mpa_rebuild.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, i64, vp, i64, i64, i32, dbl, dbl, dbl,
                                       C.POINTER(Rng), vp, vp, i64, vp, vp]
+        L.orc_mpa_targets_batch.argtypes = [u64, i64, i32, i32, i32, vp, vp, dbl, dbl, dbl, vp]
+        L.orc_set_step_cap.argtypes = [i64]
         _LIB = L
     return _LIB
+
+
+def set_step_cap(cap):
+    """Test hook: lower both connectors' step cap (0 = the reference's 3RC / 2RC)."""
+    lib().orc_set_step_cap(int(cap))
+
+
+def mpa_targets_batch(seed, is_levy, R, Cc, cur, elite, scale, levy_beta, sigma):
+    cur = np.ascontiguousarray(cur, np.int32); elite = np.ascontiguousarray(elite, np.int32)
+    out = np.zeros(cur.size, np.int32)
+    lib().orc_mpa_targets_batch(int(seed), cur.size, int(is_levy), int(R), int(Cc), _p(cur), _p(elite), float(scale),
+                                float(levy_beta), float(sigma), _p(out))
+    return out
 
 
 def _p(a):

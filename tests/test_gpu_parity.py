@@ -361,3 +361,100 @@ def test_maaco_eight_ants_per_wave_path_matches():
         test_maaco_golden_walks_and_pheromone()
     finally:
         e.set_option("maaco_pack8_min", 2048)
+
+
+def _levy_sigma(beta):
+    num = math.gamma(1 + beta) * math.sin(math.pi * beta / 2)
+    den = math.gamma((1 + beta) / 2) * beta * (2 ** ((beta - 1) / 2))
+    return (num / den) ** (1 / beta)
+
+
+def _targets(e, seed, is_levy, beta, scale, cur, elite):
+    import ctypes as C
+    d_cur, d_el, d_out = e.put(cur, np.int32), e.put(elite, np.int32), e.buf(cur.size, np.int32)
+    nd = C.c_int64(0)
+    e._ck(e.L.pf_selftest_mpa_targets(e.h, seed, cur.size, int(is_levy), beta, _levy_sigma(beta), scale, d_cur.ptr, d_el.ptr,
+                                      d_out.ptr, C.byref(nd)))
+    return d_out.download(), int(nd.value)
+
+
+def test_mpa_target_cells_two_million_draws_vs_oracle():
+    """MPA.py:250-282 on the device (ocml log / pow / sin / cos, decisions near a boundary handed to the host's glibc)
+    == the oracle's libm arithmetic on 2.5 M keyed draws: Levy with beta 1.5 and scales that make the step actually
+    move (the main.py beta = 2 setting almost never does), Brownian with both branches."""
+    import pf_oracle as po
+    e, o, s, t, g = eng("up2:g256")
+    rnd = np.random.default_rng(11)
+    n = 500_000
+    cur = rnd.integers(0, g.size, n).astype(np.int32)
+    elite = rnd.integers(0, g.size, n).astype(np.int32)
+    elite[::7] = -1                                       # elite_node_on_path is None
+    elite[1::11] = cur[1::11]                             # dist <= 1e-6 -> return the elite node
+    doubts = 0
+    for is_levy, beta, scale in ((1, 1.5, 40.0), (1, 1.5, 800.0), (1, 2.0, 300.0), (0, 1.5, 0.5), (0, 1.5, 6.0)):
+        seed = 1000 + int(scale)
+        got, nd = _targets(e, seed, is_levy, beta, scale, cur, elite)
+        want = po.mpa_targets_batch(seed, is_levy, e.R, e.C, cur, elite, scale, beta, _levy_sigma(beta))
+        assert np.array_equal(got, want), (is_levy, beta, scale, int((got != want).sum()))
+        if is_levy:
+            assert (got != cur).mean() > 0.5              # the Levy branch really moves at these scales
+        doubts += nd
+    assert doubts < 100                                   # the host route is the exception (expected ~0)
+
+
+def test_mpa_doubtful_proposals_take_the_host_route():
+    """Widen the margins so that EVERY proposal counts as doubtful: all of them are then recomputed by the host's libm
+    (mpa_resolve_doubts) and the golden rebuilds / the target sweep must still come out bit for bit."""
+    import pf_oracle as po
+    e, o, s, t, g = eng("fig7")
+    before = e.L.pf_mpa_doubts_resolved(e.h)
+    for ee in {id(v[0]): v[0] for v in _eng.values()}.values():
+        ee.set_option("mpa_doubt_round_e15", 600_000_000_000_000)      # 0.6 > any |frac - 0.5|
+        ee.set_option("mpa_doubt_log_e15", 10 ** 18)
+    try:
+        test_mpa_rebuild_golden()
+        rnd = np.random.default_rng(3)
+        cur = rnd.integers(0, g.size, 2000).astype(np.int32); elite = rnd.integers(0, g.size, 2000).astype(np.int32)
+        for is_levy, scale in ((1, 30.0), (0, 2.0)):
+            got, nd = _targets(e, 5, is_levy, 1.5, scale, cur, elite)
+            assert nd == 2000
+            assert np.array_equal(got, po.mpa_targets_batch(5, is_levy, e.R, e.C, cur, elite, scale, 1.5, _levy_sigma(1.5)))
+    finally:
+        for ee in {id(v[0]): v[0] for v in _eng.values()}.values():
+            ee.set_option("mpa_doubt_round_e15", -1)
+            ee.set_option("mpa_doubt_log_e15", -1)
+    assert e.L.pf_mpa_doubts_resolved(e.h) > before or any(v[0].L.pf_mpa_doubts_resolved(v[0].h) > 0 for v in _eng.values())
+
+
+def test_step_cap_path_vs_oracle():
+    """astar.py:58 / MPA.py:118: `while open_set and steps < max_steps`.  The reference's caps (3RC / 2RC loop
+    iterations) cannot be reached on a grid (every cell is popped once, re-pops are a few per cent), so
+    the cap path is exercised with the cap lowered on both sides by the same test hook: same status, same pop count,
+    no path -- including caps that fall in the middle of a seven-head trip."""
+    import pf_oracle as po
+    e, o, s, t, g = eng("up2:g256")
+    rnd = np.random.default_rng(9)
+    free = np.flatnonzero(g.reshape(-1) != 1)
+    n = 24
+    starts = rnd.choice(free, n); targets = rnd.choice(free, n)
+    starts[0], targets[0] = s, t
+    try:
+        for cap in (1, 2, 5, 7, 8, 13, 1000, 1003, 20011):
+            e.set_option("astar_step_cap", cap); po.set_step_cap(cap)
+            for variant in (0, 1, 2):
+                paths, st, cnt = e.astar_host(variant, starts, targets, None, path_cap=8192, want_counters=True)
+                for i in range(n):
+                    want, ost = o.astar(int(starts[i]), int(targets[i]), None, variant)
+                    assert np.array_equal(paths[i], want), (cap, variant, i)
+                    if st[i] == 1 and ost[5] == 2:
+                        # the engine proves "no path" without searching (component / pocket proofs): the uncapped
+                        # reference must agree that there is none
+                        po.set_step_cap(0)
+                        assert len(o.astar(int(starts[i]), int(targets[i]), None, variant)[0]) == 0
+                        po.set_step_cap(cap)
+                        continue
+                    assert st[i] == ost[5], (cap, variant, i, st[i], ost[5])
+                    if ost[5] == 2:
+                        assert cnt[i, 0] == cap and len(want) == 0
+    finally:
+        e.set_option("astar_step_cap", 0); po.set_step_cap(0)
