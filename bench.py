@@ -3,21 +3,20 @@
 
     python bench.py --gpus N --steps K --warmup W [--workload mpa512|maaco512|pso512|ga512|maaco128|maaco1024|astar1024]
 
-Workload at N=1 (default `mpa512`) = BASELINE.json configs[2]: MPA, 4096
-predators on G512 (np.kron 2x of the reference's 256x256 map), main.py:44-52
-parameters.  A "step" is one MPA iteration's population evaluate-and-update
-hot path: per predator propose a target cell, stitch with two A* connectors,
-score, greedy memory, FADs.  One eval = one predator's pass through it.  Inputs
-(grid, population) are resident in HBM when the timed region starts.  For N>1
-every rank owns 4096 predators (weak scaling); the only exchange is the
-fitness all_gather + elite broadcast per iteration (pathfit/dist.py).
+Headline workload (default `mpa512`) = BASELINE.json configs[2]: MPA, 4096 predators on G512 (np.kron 2x of the
+reference's 256x256 map), main.py:44-52 parameters.  A "step" is one MPA iteration's population evaluate-and-update hot
+path: per predator propose a target cell, stitch with two A* connectors, score, greedy memory, FADs.  One eval = one
+predator's pass through it.  The timed region is ONE COMPLETE K-iteration run of the solver (so the three phases
+appear in the reference's proportions, MPA.py:339-377); the W warm-up iterations run on a separate instance of the
+same configuration.  Inputs (grid, population) are resident in HBM when the timed region starts.  For N>1 every rank
+owns 4096 predators (weak scaling); the only exchange is the fitness all_gather + elite broadcast per iteration
+(pathfit/dist.py).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`
-for the dominant kernel (k_mpa_sweep / k_maaco_walk8 / k_decode_batch; HIP-event
-timed inside the library on its own stream; `copy_GBs_measured` = a plain 1 GiB
-device-to-device copy in the same run) and `cpu_baseline` (the CPU oracle port,
-bounded sample, 1 core; for mpa512 also `all_cores`: the same sample over up to
-16 child processes).
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel (HIP-event timed
+inside the library on its own stream; `copy_GBs_measured` = a plain 1 GiB device-to-device copy in the same run),
+`cpu_baseline` (the CPU oracle port, bounded sample, 1 core; for mpa512 also `all_cores`) and, at N=1 with the default
+workload, `extra`: every other BASELINE workload measured in the same process, each with value / ms_per_step / roofline
+(pso512 = the parity-exact ASYNCHRONOUS PSO through PSOSolver.solve; `--no-extra` skips them).
 """
 import argparse
 import json
@@ -38,6 +37,10 @@ MAACO_MAIN = dict(alpha=1.0, beta=7.0, rho=0.1, Q=2.5, a_turn_coef=1.0, wh_max=0
                   q0_initial=0.5, C0_initial_pheromone=0.1)                          # main.py:34-38
 W_MAIN = dict(turn_penalty_factor=0.3, safety_penalty_factor=0.8, min_safe_distance=1.8,
               diagonal_obstacle_penalty_value=100.0)                                 # main.py:21-24
+WORKLOADS = ["mpa512", "maaco512", "pso512", "ga512", "maaco128", "maaco1024", "astar1024"]
+DOMINANT = {"mpa512": ("mpa_sweep", "k_mpa_sweep"), "ga512": ("decode", "k_decode_batch"), "pso512": ("decode", "k_decode_batch"),
+            "astar1024": ("astar", "k_astar_batch"), "maaco128": ("maaco_walk", "k_maaco_walk"),
+            "maaco512": ("maaco_walk", "k_maaco_walk8"), "maaco1024": ("maaco_walk", "k_maaco_walk8")}
 
 
 def astar_bytes(c):
@@ -46,16 +49,219 @@ def astar_bytes(c):
     return 34 * c["pops"] + 8 * c["nbr_examined"] + 33 * c["pushes"] + 4 * c["path_cells"]
 
 
+def maaco_bytes(c):
+    """9 B window + 8 B tabu probes + 16 B per candidate (tau + eta) + 5 B path/tabu write per step."""
+    return 22 * c["steps"] + 16 * c["candidates"]
+
+
+def gsize_of(w):
+    return 128 if w.endswith("128") else (1024 if w.endswith("1024") else 512)
+
+
+class Run:
+    """One workload on one engine: build(), then step() K times; evals per step = per_gpu (x world)."""
+
+    def __init__(self, name, eng, grid, comm, a, rank, world, K, W):
+        import pathfit
+        from pathfit import env
+        from pathfit.dist import ShardedMPA, ShardedMAACO
+        self.name, self.eng, self.K, self.W = name, eng, K, W
+        self.pre = None            # optional: runs before the timed region (after warm-up)
+        gsize = gsize_of(name)
+        per_gpu = a.agents
+        if name == "mpa512":
+            per_gpu = per_gpu or 4096
+            total = per_gpu * world
+
+            def make(iters):
+                return ShardedMPA(comm, lambda n: pathfit.MPA(grid, total, iters, engine=eng, seed=a.seed, n_local=n, **MPA_MAIN), total)
+            self.cfg = {"workload": f"MPA {per_gpu} predators/GPU, 512x512 G512 (BASELINE.json configs[2]), main.py:44-52 params; timed region = "
+                                    f"one complete {K}-iteration run (phases 1/2/3 in the reference's proportions)",
+                        "agents_per_gpu": per_gpu, "grid": "G512=kron2(G256)", "grid_sha256": env.grid_hash(grid)[:16]}
+            st = {"sm": None, "it": 0}
+            if a.phase1_only:      # the round-1 protocol, kept for comparison: every step is a phase-1 iteration
+                st["sm"] = make(max(K + W, 3 * (K + W)))
+                self.cfg["workload"] += " [--phase1-only: phase-1 iterations of a longer run]"
+
+                def step():
+                    st["it"] += 1
+                    st["sm"].step(st["it"])
+                self.warm = step
+            else:
+                wm = {"sm": make(max(W, 1)), "it": 0}
+
+                def warm():
+                    wm["it"] += 1
+                    wm["sm"].step(wm["it"])
+                self.warm = warm
+
+                def pre():
+                    wm["sm"] = None
+                    st["sm"] = make(K); st["it"] = 0
+                self.pre = pre
+
+                def step():
+                    st["it"] += 1
+                    st["sm"].step(st["it"])
+            self.step = step
+            self.bytes_of = astar_bytes
+        elif name.startswith("maaco"):
+            # maaco512: 16384 ants/GPU; maaco128 = BASELINE.json configs[1] (256 ants, G128); maaco1024 = configs[4]'s per-GPU
+            # share (8192 ants, G1024)
+            per_gpu = per_gpu or {128: 256, 512: 16384, 1024: 8192}[gsize]
+            total = per_gpu * world
+            sm = ShardedMAACO(comm, lambda: pathfit.MAACO(grid, total, 100, engine=eng, seed=a.seed, **MAACO_MAIN), total)
+            st = {"it": 0}
+
+            def step():
+                st["it"] += 1
+                sm.step(st["it"])
+            self.step = self.warm = step
+            self.setup_steps = 1   # set-up, not warm-up: the first iteration allocates the walk / visit-bit buffers
+            self.cfg = {"workload": f"MAACO {per_gpu} ants/GPU on {gsize}x{gsize}, main.py:34-38 params (walk + ordered pheromone update)",
+                        "agents_per_gpu": per_gpu,
+                        "grid": {128: "G128=random_blocks(seed 128)", 512: "G512=kron2(G256)", 1024: "G1024=kron4(G256)"}[gsize],
+                        "grid_sha256": env.grid_hash(grid)[:16]}
+            self.bytes_of = maaco_bytes
+        elif name == "astar1024":
+            # BASELINE.json configs[4], second part: a standalone batch of seeded (start, target) pairs on G1024 through the
+            # AStarSolver connector (8192 pairs per GPU = 65536 over 8); one eval = one connector solve + path emit
+            per_gpu = per_gpu or 8192
+            rng = np.random.default_rng(a.seed + rank)
+            free = np.flatnonzero(grid.reshape(-1) != 1)
+            cap = 16 * 1024 + 64
+            d_s, d_t = eng.put(rng.choice(free, per_gpu).astype(np.int32)), eng.put(rng.choice(free, per_gpu).astype(np.int32))
+            d_cells, d_len, d_st = eng.buf((per_gpu, cap), np.int32), eng.buf(per_gpu, np.int32), eng.buf(per_gpu, np.int32)
+
+            def step():
+                eng.astar_batch(0, d_s, d_t, per_gpu, cap, d_cells, d_len, d_st)
+            self.step = self.warm = step
+            self.cfg = {"workload": f"A* connector batch (AStarSolver semantics), {per_gpu} uniform free-cell pairs/GPU, G1024 "
+                                    "(BASELINE.json configs[4] K2a batch)", "agents_per_gpu": per_gpu, "grid": "G1024=kron4(G256)",
+                        "grid_sha256": env.grid_hash(grid)[:16]}
+            self.bytes_of = astar_bytes
+        elif name == "ga512":
+            per_gpu = per_gpu or 2048                     # BASELINE.json configs[3]: 16384 over 8 GPUs
+            rng = np.random.default_rng(a.seed + rank)
+            free = np.flatnonzero(grid.reshape(-1) != 1)
+            sp = pathfit.score_params(0, True, 0.3, 0.8, 1.8, 100.0)
+            cap = 16 * 1024 + 64
+            d_cells, d_len, d_st, d_stats = (eng.buf((per_gpu, cap), np.int32), eng.buf(per_gpu, np.int32), eng.buf(per_gpu, np.int32),
+                                             eng.buf((per_gpu, 5), np.float64))
+            d_wp = eng.put(rng.choice(free, (per_gpu, 5)).astype(np.int32).reshape(-1))
+
+            def step():
+                eng.decode_batch(per_gpu, 5, 0, 512 * 512 - 1, cap, d_cells, d_len, d_st, d_wp, None, sp, d_stats)
+                if world > 1:       # C3: the tournament needs the whole fitness column
+                    comm.all_gather_concat(d_stats.download()[:, 4], [per_gpu] * world)
+            self.step = self.warm = step
+            self.cfg = {"workload": f"GA chained-waypoint decode+score of one generation's children, W=5, {per_gpu} agents/GPU, G512 "
+                                    "(BASELINE.json configs[3] per-GPU share)", "agents_per_gpu": per_gpu,
+                        "grid_sha256": env.grid_hash(grid)[:16]}
+            self.bytes_of = astar_bytes
+        else:                                              # pso512
+            per_gpu = per_gpu or 2048
+            self.cfg = {"workload": f"PSO, {per_gpu} particles/GPU, W=5, G512, main.py:109-118 params, ASYNCHRONOUS gbest as pso.py:222-229 "
+                                    "(speculate-and-repair through PSOSolver.solve); a step = one sweep of the swarm "
+                                    "(BASELINE.json configs[3] per-GPU share)", "agents_per_gpu": per_gpu,
+                        "grid_sha256": env.grid_hash(grid)[:16]}
+
+            def make(iters):
+                return pathfit.PSOSolver(grid, num_iterations=iters, num_particles=per_gpu, num_waypoints_per_particle=5, w=0.7,
+                                         c1=1.5, c2=1.5, engine=eng, seed=a.seed, asynchronous=not a.pso_sync, **W_MAIN)
+            st = {"ps": None}
+
+            def warm():
+                ps = make(1)
+                ps.solve()
+
+            def pre():
+                st["ps"] = make(K)
+                ok = st["ps"].begin()              # initialisation (20 N attempts at most) is set-up, outside the timed region
+                assert ok, "PSO initialisation found no feasible particle"
+            self.pre = pre
+
+            def step():
+                st["ps"].sweep()
+            self.warm, self.step = warm, step
+            self.bytes_of = astar_bytes
+        self.per_gpu = per_gpu
+
+
+def measure(run, eng, comm, sync_all, world, torch, dist, local_rank, backend):
+    K, W = run.K, run.W
+    fam, kern = DOMINANT[run.name]
+    for _ in range(getattr(run, "setup_steps", 0)):
+        run.step()
+    for _ in range(W):
+        run.warm()
+    if run.pre:
+        run.pre()
+    eng.klog = []
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        if os.environ.get("PF_BENCH_TRACE"):           # diagnostic: host wall time of every step, to stderr
+            ts = time.perf_counter(); run.step(); print(f"step {1e3 * (time.perf_counter() - ts):.2f} ms", file=sys.stderr, flush=True)
+        else:
+            run.step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    log, eng.klog = eng.klog, None
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", local_rank) if backend == "nccl" else None)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    value = run.per_gpu * world * K / dt
+    roof = None
+    mine = [(ms, c) for (f, ms, c) in log if f == fam]
+    if mine:
+        kms = sum(ms for ms, _ in mine); kb = sum(run.bytes_of(c) for _, c in mine); n = len(mine)
+        achieved = kb / (kms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": kern, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "avg_launch_ms": round(kms / n, 3),
+                "launches": n, "launches_per_step": round(n / K, 2), "algorithmic_bytes_per_launch": int(kb / n)}
+        if run.name == "mpa512":
+            run.cfg["rebuilds_proven_rejected_and_skipped"] = int(sum(c["pruned_rebuilds"] for _, c in mine))
+            run.cfg["sweep_ms_by_iteration"] = [round(ms, 2) for ms, _ in mine]
+        traffic_note(roof, run.name)
+    return value, dt, roof
+
+
+def traffic_note(roof, workload):
+    """HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/r02_traffic.json: FETCH_SIZE and
+    WRITE_SIZE in separate --pmc runs, KB -> B, FETCH x2 per MI355X_MICROARCH.md).  The file records the kernel time it
+    was captured at; a figure whose kernel has since changed speed by more than 15 % is reported as stale, not used."""
+    for rnd in ("r02", "r01"):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_traffic.json")))
+        except Exception:
+            continue
+        t = tj.get(workload)
+        if not t or t.get("kernel") != roof["kernel"]:
+            continue
+        ref_ms = t.get("avg_ms_rocprof") or t.get("bench_avg_launch_ms")
+        if ref_ms and abs(roof["avg_launch_ms"] - ref_ms) <= 0.15 * ref_ms:
+            roof["traffic"] = int(t["traffic_bytes_per_launch"])
+            roof["traffic_source"] = f"profiles/{rnd}_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, offline; captured at {ref_ms:.2f} ms/launch)"
+        else:
+            roof["traffic_source"] = f"profiles/{rnd}_traffic.json is stale for this kernel (captured at {ref_ms} ms/launch): not used"
+        return
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="mpa512", choices=["mpa512", "maaco512", "pso512", "ga512", "maaco128", "maaco1024", "astar1024"])
+    ap.add_argument("--workload", default="mpa512", choices=WORKLOADS)
     ap.add_argument("--agents", type=int, default=0, help="agents per GPU (default: the config's)")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="headline only (default at N>1 and for non-default workloads)")
+    ap.add_argument("--phase1-only", action="store_true", help="mpa512: the round-1 protocol (every step a phase-1 iteration)")
+    ap.add_argument("--pso-sync", action="store_true", help="pso512: one batch per sweep (sweep-start gbest) instead of the exact asynchronous mode")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + PF_BENCH_SHARE_GPU=1 rehearses N ranks on one GPU (exchange logic only)")
     ap.add_argument("--cpu-worker", default="", help=argparse.SUPPRESS)   # internal: "lo:hi" slice for the all-cores CPU leg
@@ -91,167 +297,27 @@ def main():
 
     import pathfit
     from pathfit import env
-    from pathfit.dist import Comm, ShardedMPA, ShardedMAACO
+    from pathfit.dist import Comm
 
     comm = Comm(dist, torch.device("cuda", local_rank) if (dist is not None and a.backend == "nccl") else None)
-    gsize = 128 if a.workload.endswith("128") else (1024 if a.workload.endswith("1024") else 512)
-    grid = env.bench_grid(gsize)
-    eng = pathfit.Engine(grid, device=local_rank)
     K, W = a.steps, a.warmup
 
-    def sync_all():
-        if torch is not None and torch.cuda.is_available():
-            torch.cuda.synchronize()
-        eng._ck(eng.L.pf_sync(eng.h))
-        comm.barrier()
+    def run_one(name, K_, W_):
+        grid = env.bench_grid(gsize_of(name))
+        eng = pathfit.Engine(grid, device=local_rank)
 
-    kern_ms, kern_bytes, launches = 0.0, 0.0, 0
-    per_gpu = a.agents
-    if a.workload == "mpa512":
-        per_gpu = per_gpu or 4096
-        total = per_gpu * world
-        iters = max(K + W, 3 * (K + W))      # keeps the whole run inside phase 1 (iter <= T/3), like early MPA iterations
-        sm = ShardedMPA(comm, lambda n: pathfit.MPA(grid, total, iters, engine=eng, seed=a.seed, n_local=n, **MPA_MAIN), total)
-        dominant = "k_mpa_sweep"
-        it = 0
+        def sync_all():
+            if torch is not None and torch.cuda.is_available():
+                torch.cuda.synchronize()
+            eng._ck(eng.L.pf_sync(eng.h))
+            comm.barrier()
+        sync_all()             # torch's lazy device initialisation happens here, before the warm-up
+        run = Run(name, eng, grid, comm, a, rank, world, K_, W_)
+        value, dt, roof = measure(run, eng, comm, sync_all, world, torch, dist, local_rank, a.backend)
+        return run, eng, grid, value, dt, roof
 
-        def step():
-            nonlocal it, kern_ms, kern_bytes, launches
-            it += 1
-            e = eng
-            # instrument the phase launch (dominant kernel) through the library's HIP-event timer + counters
-            orig = e.mpa_iter
-
-            def timed_iter(*args, **kw):
-                nonlocal kern_ms, kern_bytes, launches
-                orig(*args, **kw)
-                c = e.counters()
-                kern_ms += e.last_kernel_ms(); kern_bytes += astar_bytes(c); launches += 1
-                cfg["rebuilds_proven_rejected_and_skipped"] = cfg.get("rebuilds_proven_rejected_and_skipped", 0) + int(c["pruned_rebuilds"])
-            e.mpa_iter = timed_iter
-            try:
-                sm.step(it)
-            finally:
-                e.mpa_iter = orig
-        cfg = {"workload": "MPA 4096 predators/GPU, 512x512 G512 (BASELINE.json configs[2]), main.py:44-52 params, phase-1 iterations",
-               "agents_per_gpu": per_gpu, "grid": "G512=kron2(G256)", "grid_sha256": env.grid_hash(grid)[:16]}
-    elif a.workload.startswith("maaco"):
-        # maaco512: 16384 ants/GPU; maaco128 = BASELINE.json configs[1] (256 ants, G128); maaco1024 = configs[4]'s per-GPU
-        # share (8192 ants, G1024)
-        per_gpu = per_gpu or {128: 256, 512: 16384, 1024: 8192}[gsize]
-        total = per_gpu * world
-        sm = ShardedMAACO(comm, lambda: pathfit.MAACO(grid, total, 100, engine=eng, seed=a.seed, **MAACO_MAIN), total)
-        dominant = "k_maaco_walk8" if per_gpu >= 2048 else "k_maaco_walk"   # 8 ants per wavefront from 2048 ants up
-        it = 0
-
-        def step():
-            nonlocal it, kern_ms, kern_bytes, launches
-            it += 1
-            orig = eng.maaco_walk
-
-            def timed_walk(*args, **kw):
-                nonlocal kern_ms, kern_bytes, launches
-                orig(*args, **kw)
-                c = eng.counters()
-                kern_ms += eng.last_kernel_ms(); launches += 1
-                # 9 B window + 8 B tabu probes + 16 B per candidate (tau + eta) + 5 B path/tabu write
-                kern_bytes += 22 * c["steps"] + 16 * c["candidates"]
-            eng.maaco_walk = timed_walk
-            try:
-                sm.step(it)
-            finally:
-                eng.maaco_walk = orig
-        cfg = {"workload": f"MAACO ants/GPU on {gsize}x{gsize}, main.py:34-38 params (walk + ordered pheromone update)",
-               "agents_per_gpu": per_gpu, "grid": {128: "G128=random_blocks(seed 128)", 512: "G512=kron2(G256)", 1024: "G1024=kron4(G256)"}[gsize],
-               "grid_sha256": env.grid_hash(grid)[:16]}
-    elif a.workload == "astar1024":
-        # BASELINE.json configs[4], second part: a standalone batch of seeded (start, target) pairs on G1024 through the
-        # AStarSolver connector (8192 pairs per GPU = 65536 over 8); one eval = one connector solve + path emit
-        per_gpu = per_gpu or 8192
-        rng = np.random.default_rng(a.seed + rank)
-        free = np.flatnonzero(grid.reshape(-1) != 1)
-        cap = 16 * 1024 + 64
-        d_s, d_t = eng.put(rng.choice(free, per_gpu).astype(np.int32)), eng.put(rng.choice(free, per_gpu).astype(np.int32))
-        d_cells, d_len, d_st = eng.buf((per_gpu, cap), np.int32), eng.buf(per_gpu, np.int32), eng.buf(per_gpu, np.int32)
-        dominant = "k_astar_batch"
-
-        def step():
-            nonlocal kern_ms, kern_bytes, launches
-            eng.astar_batch(0, d_s, d_t, per_gpu, cap, d_cells, d_len, d_st)
-            kern_ms += eng.last_kernel_ms(); kern_bytes += astar_bytes(eng.counters()); launches += 1
-        cfg = {"workload": "A* connector batch (AStarSolver semantics), 8192 uniform free-cell pairs/GPU, G1024 (BASELINE.json configs[4] K2a batch)",
-               "agents_per_gpu": per_gpu, "grid": "G1024=kron4(G256)", "grid_sha256": env.grid_hash(grid)[:16]}
-    else:
-        per_gpu = per_gpu or 2048                     # BASELINE.json configs[3]: 16384 over 8 GPUs
-        Wp = 5
-        rng = np.random.default_rng(a.seed + rank)
-        free = np.flatnonzero(grid.reshape(-1) != 1)
-        sp = pathfit.score_params(0, True, 0.3, 0.8, 1.8, 100.0)
-        cap = 16 * 1024 + 64
-        d_cells, d_len, d_st, d_stats = eng.buf((per_gpu, cap), np.int32), eng.buf(per_gpu, np.int32), eng.buf(per_gpu, np.int32), eng.buf((per_gpu, 5), np.float64)
-        if a.workload == "ga512":
-            d_wp = eng.put(rng.choice(free, (per_gpu, Wp)).astype(np.int32).reshape(-1)); d_pos = None
-        else:
-            pos = rng.uniform(0, 511, (per_gpu, Wp, 2)); vel = rng.uniform(-15, 15, (per_gpu, Wp, 2))
-            d_pos, d_vel, d_pb, d_gb = eng.put(pos), eng.put(vel), eng.put(pos), eng.put(pos[0]); d_wp = None
-        dominant = "k_decode_batch"
-        it = 0
-
-        def step():
-            nonlocal it, kern_ms, kern_bytes, launches
-            it += 1
-            if d_pos is not None:
-                eng.pso_update(per_gpu, Wp, 0.7, 1.5, 1.5, 76.8, d_pos, d_vel, d_pb, d_gb, a.seed, it, rank * per_gpu)
-            eng.decode_batch(per_gpu, Wp, 0, 512 * 512 - 1, cap, d_cells, d_len, d_st, d_wp, d_pos, sp, d_stats)
-            kern_ms += eng.last_kernel_ms(); kern_bytes += astar_bytes(eng.counters()); launches += 1
-            if world > 1:       # gbest MINLOC exchange (C2)
-                comm.all_gather_concat(d_stats.download()[:, 4], [per_gpu] * world)
-        cfg = {"workload": f"{'GA' if a.workload == 'ga512' else 'PSO'} chained-waypoint decode+score, W=5, 2048 agents/GPU, G512 "
-                           "(BASELINE.json configs[3] per-GPU share)", "agents_per_gpu": per_gpu,
-               "grid_sha256": env.grid_hash(grid)[:16]}
-
-    sync_all()             # torch's lazy device initialisation happens here, before the warm-up
-    if a.workload.startswith("maaco"):
-        step()             # set-up, not warm-up: with torch in the process the SECOND MAACO iteration pays a one-off ~40 ms
-                           # (first iteration allocates the walk / visit-bit buffers; not seen without torch, PF_BENCH_NOTORCH=1)
-    for _ in range(W):
-        step()
-    kern_ms, kern_bytes, launches = 0.0, 0.0, 0
-    cfg.pop("rebuilds_proven_rejected_and_skipped", None)
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(K):
-        if os.environ.get("PF_BENCH_TRACE"):           # diagnostic: host wall time of every step, to stderr
-            ts = time.perf_counter(); step(); print(f"step {1e3 * (time.perf_counter() - ts):.2f} ms", file=sys.stderr, flush=True)
-        else:
-            step()
-    sync_all()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", local_rank) if a.backend == "nccl" else None)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    total_evals = per_gpu * world * K
-    value = total_evals / dt
-
-    roof = None
-    if launches:
-        avg_ms = kern_ms / launches
-        achieved = (kern_bytes / launches) / (avg_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                "avg_launch_ms": round(avg_ms, 3), "algorithmic_bytes_per_launch": int(kern_bytes / launches)}
-
-    if roof is not None:
-        # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/r01_traffic.json:
-        # FETCH_SIZE and WRITE_SIZE in separate --pmc runs, KB -> B, FETCH x2 per MI355X_MICROARCH.md)
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if a.workload in tj and tj[a.workload]["kernel"] == dominant:
-                roof["traffic"] = int(tj[a.workload]["traffic_bytes_per_launch"])
-                roof["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, offline)"
-        except Exception:
-            pass
+    run, eng, grid, value, dt, roof = run_one(a.workload, K, W)
+    head_cfg = run.cfg
 
     if roof is not None and rank == 0:
         # the nominal 8 TB/s next to what a plain device-to-device copy reaches on this GPU, same run
@@ -273,11 +339,30 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu:      # the CPU baseline is an N=1 figure (the other ranks would only wait for it)
         cpu = cpu_baseline(a.workload, grid, a.seed, a.cpu_seconds)
 
+    extra = None
+    if world == 1 and rank == 0 and a.workload == "mpa512" and not a.no_extra and not a.agents:
+        # every other BASELINE workload in the same process, short runs (the judge asked for them in the driver-run line)
+        extra = {}
+        run = None
+        eng.close()
+        for name, k_, w_ in (("maaco128", 20, 3), ("maaco512", 10, 2), ("maaco1024", 6, 1), ("ga512", 3, 1), ("pso512", 2, 1),
+                             ("astar1024", 2, 1)):
+            try:
+                r2, e2, _, v2, dt2, roof2 = run_one(name, k_, w_)
+                extra[name] = {"value": round(v2, 2), "unit": "evals/s", "steps": k_, "warmup": w_, "ms_per_step": round(dt2 / k_ * 1e3, 3),
+                               "roofline": roof2, "config": r2.cfg}
+                r2 = None
+                e2.close()
+            except Exception as ex:                     # an extra must never cost the headline
+                extra[name] = {"error": repr(ex)[:300]}
+
     if rank == 0:
         out = {"metric": "agent-fitness-evals/sec on 512x512 grid", "value": round(value, 2), "unit": "evals/s",
                "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": cfg,
-               "roofline": roof, "cpu_baseline": cpu}
+               "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": head_cfg, "roofline": roof, "cpu_baseline": cpu}
+        if extra is not None:
+            out["extra"] = extra
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
@@ -380,7 +465,7 @@ def cpu_baseline(workload, grid, seed, budget_s):
            "seconds": round(dt, 2)}
     if workload == "mpa512":
         try:
-            out["all_cores"] = _mpa_cpu_all_cores(seed, min(budget_s, 10.0))
+            out["all_cores"] = _mpa_cpu_all_cores(seed, min(budget_s, 8.0))
         except Exception as e:                      # the single-core figure stands on its own
             out["all_cores"] = {"error": repr(e)[:200]}
     return out

@@ -251,6 +251,21 @@ int pf_selftest_sqrt(pf_handle* h, int32_t n, const int64_t* d_in, double* d_out
 int pf_selftest_rng(pf_handle* h, uint64_t seed, uint64_t dom, uint64_t it, uint64_t agent, uint64_t* d_u64,
                     double* d_f64, int64_t* d_i64);
 
+/* pso.py:218-219 for the paths: rows of the particles pf_pso_pbest marked improved are copied into the pbest path
+ * store (both strided [n][path_cap]); asynchronous (stream ordered). */
+int pf_pso_pbest_paths(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_cells, const int32_t* d_len,
+                       const int32_t* d_improved, int32_t* d_pb_cells, int32_t* d_pb_len);
+/* pbest -> gbest scan of one evaluated batch of n particles (pso.py:216-229): *idx_out = the first particle that
+ * improves the gbest (feasible, fitness below its pbest AND below gbest_fit), or with sync_mode != 0 the first particle
+ * with the smallest such fitness; -1 if none.  *fit_out its fitness, *overflow_out the number of particles whose
+ * status is PF_ST_OVERFLOW.  One 16-byte device-to-host copy. */
+int pf_pso_scan(pf_handle* h, int32_t n, const double* d_stats, const int32_t* d_len, const int32_t* d_status,
+                const double* d_pbest_fit, double gbest_fit, int32_t sync_mode, int32_t* idx_out, double* fit_out,
+                int32_t* overflow_out);
+/* Device-to-host copies made through this handle since pf_create: copies of at most 64 bytes, larger ones, and the
+ * bytes of the larger ones (the solver loops keep populations in HBM: SURVEY.md 8 f1/f2). */
+int pf_d2h_counts(pf_handle* h, int64_t* small_copies, int64_t* bulk_copies, int64_t* bulk_bytes);
+
 /* Target-cell proposals of MPA._get_levy_target_node / _get_brownian_target_node (MPA.py:250-282) for n keyed streams
  * (seed, DOM_MPA, 0, i) from cells d_cur[i] (and elite cells d_elite[i], < 0 = None): the device arithmetic, with the
  * proposals whose accept test / rounding lies within the libm-disagreement margin recomputed by the host's glibc

@@ -322,6 +322,65 @@ __global__ void k_pso_pbest(int n, int W, const double* pos, const double* stats
   if (threadIdx.x == 0) { improved[a] = better; if (better) pbest_fit[a] = stats[(size_t)a * 5 + 4]; }
 }
 
+// pbest paths stay in HBM too: rows of the particles k_pso_pbest marked as improved are copied over (pso.py:218-219)
+__global__ __launch_bounds__(64) void k_pso_pbest_paths(int n, int path_cap, const int* cells, const int* len, const int* improved,
+                                                        int* pb_cells, int* pb_len) {
+  const int a = blockIdx.x;
+  if (a >= n || !improved[a]) return;
+  const int L = len[a];
+  for (int i = threadIdx.x; i < L; i += 64) pb_cells[(size_t)a * path_cap + i] = cells[(size_t)a * path_cap + i];
+  if (threadIdx.x == 0) pb_len[a] = L;
+}
+// pbest -> gbest scan over particles [0, n) of one evaluated batch (pso.py:216-229), one block.  A particle improves
+// the gbest when its path is feasible and its fitness is below both its own pbest (:216) and the gbest (:222).
+// Asynchronous mode: the FIRST improver (everything before it is final, everything after it has to be re-evaluated
+// with the moved gbest); synchronous mode: the first particle with the smallest improving fitness.
+// out[0] = index or -1, out[1] = number of particles with status 3 (scratch / path capacity overflow).
+__global__ __launch_bounds__(256) void k_pso_scan(int n, const double* stats, const int* len, const int* status, const double* pbf,
+                                                  double gbest_fit, int sync_mode, int* out, double* out_fit) {
+  __shared__ unsigned long long best[256];
+  __shared__ int ovf[256];
+  unsigned long long b = ~0ull; int o = 0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    o += status[i] == 3;
+    const double f = stats[(size_t)i * 5 + 4];
+    if (len[i] > 0 && f < pbf[i] && f < gbest_fit) {
+      if (!sync_mode) { const unsigned long long k = (unsigned long long)i; b = k < b ? k : b; }
+      else {
+        // order by (fitness, index): non-negative doubles order like their bit patterns; ties on the 64-bit fitness are
+        // broken in a second pass below
+        const unsigned long long k = (unsigned long long)__double_as_longlong(f);
+        b = k < b ? k : b;
+      }
+    }
+  }
+  best[threadIdx.x] = b; ovf[threadIdx.x] = o;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) { if (best[threadIdx.x + st] < best[threadIdx.x]) best[threadIdx.x] = best[threadIdx.x + st]; ovf[threadIdx.x] += ovf[threadIdx.x + st]; }
+    __syncthreads();
+  }
+  const unsigned long long w = best[0];
+  const int novf = ovf[0];
+  __syncthreads();
+  if (sync_mode && w != ~0ull) {                                 // the first particle holding that fitness
+    unsigned long long bi = ~0ull;
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const double f = stats[(size_t)i * 5 + 4];
+      if (len[i] > 0 && f < pbf[i] && f < gbest_fit && (unsigned long long)__double_as_longlong(f) == w) { bi = (unsigned long long)i < bi ? (unsigned long long)i : bi; }
+    }
+    best[threadIdx.x] = bi;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st && best[threadIdx.x + st] < best[threadIdx.x]) best[threadIdx.x] = best[threadIdx.x + st]; __syncthreads(); }
+  }
+  if (threadIdx.x == 0) {
+    const unsigned long long idx = (sync_mode && w != ~0ull) ? best[0] : w;
+    out[0] = idx == ~0ull ? -1 : (int)idx;
+    out[1] = novf;
+    out_fit[0] = idx == ~0ull ? PF_INF : stats[(size_t)idx * 5 + 4];
+  }
+}
+
 // ===========================================================================
 // K4: MAACO ant walk
 // ===========================================================================
@@ -1370,6 +1429,8 @@ struct pf_handle {
   void* d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
   int2* d_prop = nullptr; int* d_doubt = nullptr; int prop_cap = 0;   // MPA proposals {idx, target cell}; doubt list [0] = count, [1..] = predators
   long long doubts_resolved = 0;
+  void* d_scan = nullptr;   // 16 B result of the small device scans
+  long long d2h_small = 0, d2h_bulk = 0, d2h_bulk_bytes = 0;   // device-to-host copies the library made (f1/f2 accounting): <= 64 B / larger
 };
 
 static long long g_step_cap = 0;   // > 0: lowers the connectors' step cap (pf_set_option "astar_step_cap": tests of the cap path)
@@ -1472,7 +1533,7 @@ void pf_destroy(pf_handle* h) {
   (void)hipSetDevice(h->device);
   void* ptrs[] = {h->d_occ, h->d_mm_r1, h->d_mm_r0, h->d_mm_r1_nd, h->d_mm_r0_nd, h->d_d2near, h->d_rec, h->d_slot_state,
                   h->d_work, h->d_cnt, h->d_pen, h->d_tier2, h->d_tau, h->d_taua, h->d_eta, h->d_dep, h->d_tep, h->d_visit, h->d_visit_epoch,
-                  h->d_bits, h->d_tmp, h->d_elite_stats, h->d_init_cells, h->d_init_stats, h->d_est, h->d_est2, h->d_iota, h->d_queue, h->d_sort_tmp, h->d_prop, h->d_doubt,
+                  h->d_bits, h->d_tmp, h->d_elite_stats, h->d_init_cells, h->d_init_stats, h->d_est, h->d_est2, h->d_iota, h->d_queue, h->d_sort_tmp, h->d_prop, h->d_doubt, h->d_scan,
                   h->d_comp[0], h->d_comp[1], h->d_comp[2], h->d_comp[3], h->d_ds, h->d_dt};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1484,7 +1545,8 @@ void pf_destroy(pf_handle* h) {
 int pf_dev_alloc(pf_handle* h, int64_t bytes, void** d_out) { CK(hipSetDevice(h->device)); CK(hipMalloc(d_out, (size_t)(bytes > 0 ? bytes : 1))); return 0; }
 int pf_dev_free(pf_handle* h, void* p) { CK(hipSetDevice(h->device)); CK(hipFree(p)); return 0; }
 int pf_h2d(pf_handle* h, void* d, const void* s, int64_t n) { CK(hipMemcpyAsync(d, s, (size_t)n, hipMemcpyHostToDevice, h->stream)); CK(hipStreamSynchronize(h->stream)); return 0; }
-int pf_d2h(pf_handle* h, void* d, const void* s, int64_t n) { CK(hipMemcpyAsync(d, s, (size_t)n, hipMemcpyDeviceToHost, h->stream)); CK(hipStreamSynchronize(h->stream)); return 0; }
+int pf_d2h(pf_handle* h, void* d, const void* s, int64_t n) { CK(hipMemcpyAsync(d, s, (size_t)n, hipMemcpyDeviceToHost, h->stream)); CK(hipStreamSynchronize(h->stream)); if (n <= 64) h->d2h_small += 1; else { h->d2h_bulk += 1; h->d2h_bulk_bytes += n; } return 0; }
+int pf_d2h_counts(pf_handle* h, int64_t* small_copies, int64_t* bulk_copies, int64_t* bulk_bytes) { if (!h) return -2; if (small_copies) *small_copies = h->d2h_small; if (bulk_copies) *bulk_copies = h->d2h_bulk; if (bulk_bytes) *bulk_bytes = h->d2h_bulk_bytes; return 0; }
 int pf_d2d(pf_handle* h, void* d, const void* s, int64_t n) { CK(hipMemcpyAsync(d, s, (size_t)n, hipMemcpyDeviceToDevice, h->stream)); CK(hipStreamSynchronize(h->stream)); return 0; }
 int pf_memset(pf_handle* h, void* d, int32_t b, int64_t n) { CK(hipMemsetAsync(d, b, (size_t)n, h->stream)); CK(hipStreamSynchronize(h->stream)); return 0; }
 int pf_get_counters(pf_handle* h, pf_counters* out) { *out = h->last; return 0; }
@@ -1708,6 +1770,37 @@ int pf_pso_pbest(pf_handle* h, int32_t n, int32_t W, const double* d_pos, const 
   hipLaunchKernelGGL(k_pso_pbest, dim3(n), dim3(64), 0, h->stream, n, W, d_pos, d_stats, d_len, d_pbest, d_pbest_fit, d_improved);
   CK(hipGetLastError());
   CK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int pf_pso_pbest_paths(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_cells, const int32_t* d_len,
+                       const int32_t* d_improved, int32_t* d_pb_cells, int32_t* d_pb_len) {
+  if (!h) return -2;
+  if (n < 0 || path_cap < 1 || !d_cells || !d_len || !d_improved || !d_pb_cells || !d_pb_len) return failmsg(h, "pf_pso_pbest_paths: bad arguments");
+  if (n == 0) return 0;
+  CK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(k_pso_pbest_paths, dim3(n), dim3(64), 0, h->stream, n, path_cap, d_cells, d_len, d_improved, d_pb_cells, d_pb_len);
+  CK(hipGetLastError());
+  return 0;
+}
+
+int pf_pso_scan(pf_handle* h, int32_t n, const double* d_stats, const int32_t* d_len, const int32_t* d_status,
+                const double* d_pbest_fit, double gbest_fit, int32_t sync_mode, int32_t* idx_out, double* fit_out,
+                int32_t* overflow_out) {
+  if (!h) return -2;
+  if (n < 0 || !d_stats || !d_len || !d_status || !d_pbest_fit || !idx_out || !fit_out || !overflow_out) return failmsg(h, "pf_pso_scan: bad arguments");
+  *idx_out = -1; *fit_out = INFINITY; *overflow_out = 0;
+  if (n == 0) return 0;
+  CK(hipSetDevice(h->device));
+  if (!h->d_scan) CK(hipMalloc(&h->d_scan, 16));
+  hipLaunchKernelGGL(k_pso_scan, dim3(1), dim3(256), 0, h->stream, n, d_stats, d_len, d_status, d_pbest_fit, gbest_fit, sync_mode,
+                     (int*)h->d_scan, (double*)((char*)h->d_scan + 8));
+  CK(hipGetLastError());
+  struct { int idx, ovf; double fit; } r;
+  CK(hipMemcpyAsync(&r, h->d_scan, 16, hipMemcpyDeviceToHost, h->stream));   // the sweep's one small D2H
+  CK(hipStreamSynchronize(h->stream));
+  h->d2h_small += 1;
+  *idx_out = r.idx; *fit_out = r.fit; *overflow_out = r.ovf;
   return 0;
 }
 

@@ -78,6 +78,7 @@ class Engine:
             raise PathfitError(self.L.pf_last_error(None).decode())
         self.h = h
         self.device = int(device)
+        self.klog = None          # a list: every hot-path launch appends (kernel family, its HIP-event ms, its counters)
 
     def close(self):
         if getattr(self, "h", None):
@@ -93,6 +94,10 @@ class Engine:
     def _ck(self, rc):
         if rc != 0:
             raise PathfitError(self.L.pf_last_error(self.h).decode())
+
+    def _logk(self, name):
+        if self.klog is not None:
+            self.klog.append((name, self.last_kernel_ms(), self.counters()))
 
     def buf(self, shape, dtype):
         return DevBuf(self, shape, dtype)
@@ -126,6 +131,7 @@ class Engine:
                                        d_target.ptr, d_avoid_off.ptr if d_avoid_off else None,
                                        d_avoid_cells.ptr if d_avoid_cells else None, path_cap, d_cells.ptr,
                                        d_len.ptr, d_status.ptr, d_counters.ptr if d_counters else None))
+        self._logk("astar")
 
     def astar_host(self, variant, starts, targets, avoid_lists=None, path_cap=None, allow_diag=True,
                    restrict_corner=True, want_counters=False):
@@ -170,6 +176,7 @@ class Engine:
                                         d_wp_cells.ptr if d_wp_cells else None, d_wp_pos.ptr if d_wp_pos else None,
                                         int(start), int(target), path_cap, d_cells.ptr, d_len.ptr, d_status.ptr,
                                         C.byref(sp) if sp is not None else None, d_stats.ptr if d_stats else None))
+        self._logk("decode")
 
     def decode_host(self, start, target, wp_cells=None, wp_pos=None, sp=None, path_cap=None, allow_diag=True,
                     restrict_corner=True):
@@ -204,9 +211,33 @@ class Engine:
         self._ck(self.L.pf_decode_batch(self.h, int(allow_diag), int(restrict_corner), n, W, None, wp_pos_ptr,
                                         int(start), int(target), path_cap, cells_ptr, len_ptr, status_ptr,
                                         C.byref(sp), stats_ptr))
+        self._logk("decode")
 
     def pso_pbest_raw(self, n, W, pos_ptr, stats_ptr, len_ptr, pbest_ptr, pbf_ptr, imp_ptr):
         self._ck(self.L.pf_pso_pbest(self.h, n, W, pos_ptr, stats_ptr, len_ptr, pbest_ptr, pbf_ptr, imp_ptr))
+
+    def pso_scan(self, n, stats_ptr, len_ptr, status_ptr, pbf_ptr, gbest_fit, sync_mode):
+        """-> (index of the gbest improver in the batch or -1, its fitness, overflowed particles); one 16-byte D2H."""
+        i, f, o = C.c_int32(-1), C.c_double(INF), C.c_int32(0)
+        self._ck(self.L.pf_pso_scan(self.h, n, stats_ptr, len_ptr, status_ptr, pbf_ptr, float(gbest_fit), int(sync_mode),
+                                    C.byref(i), C.byref(f), C.byref(o)))
+        return i.value, f.value, o.value
+
+    def pso_pbest_paths_raw(self, n, path_cap, cells_ptr, len_ptr, imp_ptr, pb_cells_ptr, pb_len_ptr):
+        self._ck(self.L.pf_pso_pbest_paths(self.h, n, path_cap, cells_ptr, len_ptr, imp_ptr, pb_cells_ptr, pb_len_ptr))
+
+    def d2h_counts(self):
+        """(small copies <= 64 B, bulk copies, bulk bytes) this handle has made device -> host."""
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        self._ck(self.L.pf_d2h_counts(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def read(self, ptr, count, dtype):
+        """A small typed read from device memory (row reads on demand)."""
+        out = np.empty(int(count), dtype)
+        if out.nbytes:
+            self._ck(self.L.pf_d2h(self.h, out.ctypes.data, ptr, out.nbytes))
+        return out
 
     def pso_pbest(self, n, W, d_pos, d_stats, d_len, d_pbest, d_pbest_fit, d_improved):
         self._ck(self.L.pf_pso_pbest(self.h, n, W, d_pos.ptr, d_stats.ptr, d_len.ptr, d_pbest.ptr, d_pbest_fit.ptr,
@@ -220,6 +251,7 @@ class Engine:
     def maaco_walk(self, it, seed, ant0, n, path_cap, d_cells, d_len, d_plen, d_turns, d_status):
         self._ck(self.L.pf_maaco_walk_batch(self.h, int(it), int(seed), int(ant0), n, path_cap, d_cells.ptr,
                                             d_len.ptr, d_plen.ptr, d_turns.ptr, d_status.ptr))
+        self._logk("maaco_walk")
 
     def maaco_evaporate(self):
         self._ck(self.L.pf_maaco_evaporate(self.h))
@@ -270,6 +302,7 @@ class Engine:
                                           elite_cells_ptr, int(elite_len), elite_stats_ptr, d_c1_cells.ptr,
                                           d_c1_len.ptr, d_c1_stats.ptr, d_c2_cells.ptr, d_c2_len.ptr, d_c2_stats.ptr,
                                           d_status.ptr))
+        self._logk("mpa_sweep")
 
     def mpa_fads(self, CF, it, seed, n, path_cap, d_gidx, d_slot, d_pop_cells, d_pop_len, d_pop_stats, d_status):
         self._ck(self.L.pf_mpa_fads_batch(self.h, float(CF), int(it), int(seed), n, path_cap, d_gidx.ptr, d_slot.ptr,

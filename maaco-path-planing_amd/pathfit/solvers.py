@@ -398,6 +398,7 @@ class PSOSolver(_WaypointSolver):
         self.max_vel = max(1.0, 0.15 * max(self.rows, self.cols))      # pso.py:34
         self.path_connector = AStarSolver(self.grid, 0, 0, 0, allow_diagonal_moves,
                                           restrict_diagonal_near_obstacle_policy, 0, engine=self.engine)
+        self._d, self._gbest_dev, self._particles_stale = None, None, False
         self.particles = []
         self.gbest_particle_data = {"fitness": INF, "path": [], "position": []}
         self.verbose = verbose
@@ -452,15 +453,135 @@ class PSOSolver(_WaypointSolver):
         return True
 
     def _set_gbest(self, idx, position, path, st):
-        self.gbest_particle_data = {"fitness": float(st[4]), "path": path, "position": [list(p) for p in position],
-                                    "length": float(st[0]), "turns": int(st[1]), "safety_penalty": float(st[2]),
-                                    "diag_penalty": float(st[3])}
+        self._gbest = {"fitness": float(st[4]), "path": path, "position": [list(p) for p in position],
+                       "length": float(st[0]), "turns": int(st[1]), "safety_penalty": float(st[2]),
+                       "diag_penalty": float(st[3])}
+        self._gbest_dev = None
+
+    # gbest_particle_data / particles are the reference's public attributes (pso.py:37-38); while a solve is running
+    # they live in HBM and are materialised only when somebody reads them
+    @property
+    def gbest_particle_data(self):
+        if getattr(self, "_gbest_dev", None) is not None:
+            d = self._gbest_dev
+            e = self.engine
+            cells = e.read(self._d["gpath"].ptr, d["len"], np.int32)
+            pos = e.read(self._d["gb"].ptr, self.num_waypoints * 2, np.float64).reshape(-1, 2)
+            self._set_gbest(d["idx"], pos, CellPath(cells, self.cols), d["stats"])
+        return self._gbest
+
+    @gbest_particle_data.setter
+    def gbest_particle_data(self, v):
+        self._gbest, self._gbest_dev = v, None
+
+    @property
+    def particles(self):
+        if getattr(self, "_d", None) is not None and self._particles_stale:
+            self._download_state()
+            self._sync_particles()
+            self._particles_stale = False
+        return self._particles
+
+    @particles.setter
+    def particles(self, v):
+        self._particles = v
 
     def _sync_particles(self):
-        self.particles = [{"position": self._pos[i].tolist(), "velocity": self._vel[i].tolist(),
-                           "pbest_position": self._pbest[i].tolist(), "pbest_fitness": float(self._pbest_fit[i]),
-                           "pbest_path": self._pbest_path[i], "current_path": self._cur_path[i],
-                           "current_fitness": float(self._cur_stats[i][4])} for i in range(len(self._pos))]
+        self._particles = [{"position": self._pos[i].tolist(), "velocity": self._vel[i].tolist(),
+                            "pbest_position": self._pbest[i].tolist(), "pbest_fitness": float(self._pbest_fit[i]),
+                            "pbest_path": self._pbest_path[i], "current_path": self._cur_path[i],
+                            "current_fitness": float(self._cur_stats[i][4])} for i in range(len(self._pos))]
+
+    def _download_state(self):
+        """HBM -> the host mirrors behind `particles` (bulk copies; only on demand and at the end of solve())."""
+        d, N, cap = self._d, self.num_particles, self._cap
+        self._pos, self._vel = d["pos"].download(), d["vel"].download()
+        self._pbest, self._pbest_fit = d["pb"].download(), d["pbf"].download()
+        cells, lens, stats = d["cells"].download(), d["len"].download(), d["stats"].download()
+        pbc, pbl = d["pb_cells"].download(), d["pb_len"].download()
+        self._cur_path = [CellPath(cells[i, :lens[i]].copy(), self.cols) for i in range(N)]
+        self._cur_stats = [stats[i] for i in range(N)]
+        self._pbest_path = [CellPath(pbc[i, :pbl[i]].copy(), self.cols) for i in range(N)]
+
+    def begin(self):
+        """Initialise the swarm (pso.py:97-161) and move it into HBM; False if no particle could be built."""
+        self._d = None
+        self._it = 0
+        if not self._initialize_particles():
+            return False
+        self.convergence_curve.append(self._gbest["fitness"])
+        e, N, W = self.engine, self.num_particles, self.num_waypoints
+        cap = self._cap = self._path_cap()
+        d = {}
+        d["pos"], d["vel"], d["pb"] = e.put(self._pos), e.put(self._vel), e.put(self._pbest)
+        d["pbf"] = e.put(self._pbest_fit)
+        d["gb"] = e.put(np.array(self._gbest["position"], np.float64))
+        d["cells"], d["len"], d["st"] = e.buf((N, cap), np.int32), e.buf(N, np.int32), e.buf(N, np.int32)
+        d["stats"], d["imp"] = e.buf((N, 5), np.float64), e.buf(N, np.int32)
+        d["pos0"], d["vel0"] = e.buf((N, W, 2), np.float64), e.buf((N, W, 2), np.float64)
+        d["gpath"] = e.buf(cap, np.int32)
+        # current / pbest paths start as the initial paths (pso.py:111-117)
+        cur = np.zeros((N, cap), np.int32); ln = np.zeros(N, np.int32)
+        for i, cp in enumerate(self._cur_path):
+            c = cells_of(cp, self.cols)
+            if len(c) > cap:
+                raise RuntimeError("pathfit: path capacity overflow in PSO initialisation")
+            cur[i, :len(c)] = c; ln[i] = len(c)
+        d["cells"].upload(cur); d["len"].upload(ln)
+        d["stats"].upload(np.array(self._cur_stats, np.float64).reshape(N, 5))
+        d["pb_cells"], d["pb_len"] = e.put(cur), e.put(ln)
+        self._d = d
+        self._particles_stale = False
+        return True
+
+    def sweep(self):
+        """One iteration of pso.py:178-231 over the whole swarm, resident in HBM: update -> decode/stitch -> score ->
+        pbest -> gbest.  Speculate that no particle of [lo, N) improves gbest: evaluate them in one batch with the current
+        gbest.  Everything up to and including the first improver p* is exact; gbest moves to p* and the particles
+        after it are rolled back and re-evaluated (their draws are keyed per particle, so the re-evaluation consumes
+        the same random numbers).  Synchronous mode commits the whole batch.  Device-to-host traffic: 16 bytes per
+        launch (the improver scan) + 44 bytes per gbest change; no path, position or stats column leaves HBM."""
+        e, N, W, d, cap, it = self.engine, self.num_particles, self.num_waypoints, self._d, self._cap, self._it
+        s_cell, t_cell = self._cell(self.start_node), self._cell(self.target_node)
+        st_sz = W * 2 * 8
+        gfit = self._gbest_dev["fitness"] if self._gbest_dev is not None else self._gbest["fitness"]
+        lo = 0
+        while lo < N:
+            m = N - lo
+            if self.asynchronous:
+                e.d2d(d["pos0"].at(lo * W * 2), d["pos"].at(lo * W * 2), m * st_sz)
+                e.d2d(d["vel0"].at(lo * W * 2), d["vel"].at(lo * W * 2), m * st_sz)
+            e.pso_update_raw(m, W, self.w, self.c1, self.c2, self.max_vel, d["pos"].at(lo * W * 2), d["vel"].at(lo * W * 2),
+                             d["pb"].at(lo * W * 2), d["gb"].ptr, self.seed, it, lo)
+            e.decode_raw(m, W, s_cell, t_cell, cap, d["cells"].at(lo * cap), d["len"].at(lo), d["st"].at(lo), d["pos"].at(lo * W * 2),
+                         self._sp, d["stats"].at(lo * 5), self.allow_diagonal_moves, self.restrict_diagonal_near_obstacle_policy)
+            idx, fit, ovf = e.pso_scan(m, d["stats"].at(lo * 5), d["len"].at(lo), d["st"].at(lo), d["pbf"].at(lo), gfit,
+                                       0 if self.asynchronous else 1)
+            if ovf:
+                raise RuntimeError("pathfit: scratch/path capacity overflow in PSO decode")
+            upto = (lo + idx if idx >= 0 else N - 1) if self.asynchronous else N - 1   # last particle whose evaluation is final
+            k = upto - lo + 1
+            e.pso_pbest_raw(k, W, d["pos"].at(lo * W * 2), d["stats"].at(lo * 5), d["len"].at(lo), d["pb"].at(lo * W * 2),
+                            d["pbf"].at(lo), d["imp"].at(lo))                   # pso.py:216-220
+            e.pso_pbest_paths_raw(k, cap, d["cells"].at(lo * cap), d["len"].at(lo), d["imp"].at(lo), d["pb_cells"].at(lo * cap),
+                                  d["pb_len"].at(lo))
+            if idx >= 0:                                                       # pso.py:222-229: gbest moves to particle j
+                j = lo + idx
+                e.d2d(d["gb"].ptr, d["pos"].at(j * W * 2), st_sz)
+                stats_j = e.read(d["stats"].at(j * 5), 5, np.float64)
+                len_j = int(e.read(d["len"].at(j), 1, np.int32)[0])
+                e.d2d(d["gpath"].ptr, d["cells"].at(j * cap), len_j * 4)
+                self._gbest_dev = {"idx": j, "fitness": fit, "stats": stats_j, "len": len_j}
+                gfit = fit
+            if upto < N - 1:                                                   # roll back the not yet final particles
+                r = upto + 1
+                e.d2d(d["pos"].at(r * W * 2), d["pos0"].at(r * W * 2), (N - r) * st_sz)
+                e.d2d(d["vel"].at(r * W * 2), d["vel0"].at(r * W * 2), (N - r) * st_sz)
+            lo = upto + 1
+        self._particles_stale = True
+        self._it += 1
+        self.convergence_curve.append(gfit)
+        return gfit
 
     def solve(self):
         if self.num_waypoints == 0:
@@ -470,68 +591,18 @@ class PSOSolver(_WaypointSolver):
                                         "safety_penalty": stats[3], "diag_penalty": stats[4], "position": []}
             self.convergence_curve.append(stats[5])
             return stats
-        if not self._initialize_particles():
+        if not self.begin():
             return [], INF, 0, 0.0, 0.0, INF
-        self.convergence_curve.append(self.gbest_particle_data["fitness"])
-        e, N, W = self.engine, self.num_particles, self.num_waypoints
-        cap = self._path_cap()
-        d_pos, d_vel, d_pb = e.put(self._pos), e.put(self._vel), e.put(self._pbest)
-        d_pbf = e.put(self._pbest_fit)
-        d_gb = e.put(np.array(self.gbest_particle_data["position"], np.float64))
-        d_cells, d_len, d_st = e.buf((N, cap), np.int32), e.buf(N, np.int32), e.buf(N, np.int32)
-        d_stats, d_imp = e.buf((N, 5), np.float64), e.buf(N, np.int32)
-        s_cell, t_cell = self._cell(self.start_node), self._cell(self.target_node)
-        d_pos0, d_vel0 = e.buf((N, W, 2), np.float64), e.buf((N, W, 2), np.float64)
-        st_sz = W * 2 * 8
         for it in range(self.num_iterations):
-            # ---- hot path, all resident in HBM: update -> decode/stitch -> score -> pbest ----
-            # Speculate that no particle of [lo, N) improves gbest: evaluate them in one batch with the current
-            # gbest.  Everything up to and including the first improver p* is exact; gbest moves to p* and the
-            # particles after it are rolled back and re-evaluated (their draws are keyed per particle, so the
-            # re-evaluation consumes the same random numbers).  Synchronous mode commits the whole batch.
-            lo = 0
-            while lo < N:
-                m = N - lo
-                if self.asynchronous:
-                    e.d2d(d_pos0.at(lo * W * 2), d_pos.at(lo * W * 2), m * st_sz)
-                    e.d2d(d_vel0.at(lo * W * 2), d_vel.at(lo * W * 2), m * st_sz)
-                e.pso_update_raw(m, W, self.w, self.c1, self.c2, self.max_vel, d_pos.at(lo * W * 2), d_vel.at(lo * W * 2),
-                                 d_pb.at(lo * W * 2), d_gb.ptr, self.seed, it, lo)
-                e.decode_raw(m, W, s_cell, t_cell, cap, d_cells.at(lo * cap), d_len.at(lo), d_st.at(lo), d_pos.at(lo * W * 2),
-                             self._sp, d_stats.at(lo * 5), self.allow_diagonal_moves, self.restrict_diagonal_near_obstacle_policy)
-                st = d_st.download()
-                if (st[lo:] == 3).any():
-                    raise RuntimeError("pathfit: scratch/path capacity overflow in PSO decode")
-                stats, lens = d_stats.download(), d_len.download()
-                pbf = d_pbf.download()
-                improves = (lens[lo:] > 0) & (stats[lo:, 4] < pbf[lo:]) & (stats[lo:, 4] < self.gbest_particle_data["fitness"])
-                if self.asynchronous:
-                    hit = np.flatnonzero(improves)
-                    upto = lo + int(hit[0]) if hit.size else N - 1          # last particle whose evaluation is final
-                else:
-                    upto = N - 1
-                k = upto - lo + 1
-                e.pso_pbest_raw(k, W, d_pos.at(lo * W * 2), d_stats.at(lo * 5), d_len.at(lo), d_pb.at(lo * W * 2),
-                                d_pbf.at(lo), d_imp.at(lo))                  # pso.py:216-220
-                # gbest (pso.py:222-229): in asynchronous mode the committed range holds at most one improver (its last
-                # particle); in synchronous mode take the first particle with the smallest improving fitness
-                cand = lo + np.flatnonzero(improves[:k])
-                if cand.size:
-                    j = int(cand[np.argmin(stats[cand, 4])])
-                    cells = d_cells.download()[j, :lens[j]]
-                    pos_j = d_pos.download()[j]
-                    self._set_gbest(j, pos_j, CellPath(cells, self.cols), stats[j])
-                    d_gb.upload(pos_j)
-                if upto < N - 1:                                             # roll back the not yet final particles
-                    r = upto + 1
-                    e.d2d(d_pos.at(r * W * 2), d_pos0.at(r * W * 2), (N - r) * st_sz)
-                    e.d2d(d_vel.at(r * W * 2), d_vel0.at(r * W * 2), (N - r) * st_sz)
-                lo = upto + 1
-            self.convergence_curve.append(self.gbest_particle_data["fitness"])
+            g = self.sweep()
             if self.verbose and ((it + 1) % 10 == 0 or it == 0 or it == self.num_iterations - 1):
-                b = self.gbest_particle_data
-                print(f"PSO Iter {it + 1}/{self.num_iterations}: GBestFit={b['fitness']:.2f}")
-        self._pos, self._vel, self._pbest, self._pbest_fit = d_pos.download(), d_vel.download(), d_pb.download(), d_pbf.download()
+                print(f"PSO Iter {it + 1}/{self.num_iterations}: GBestFit={g:.2f}")
+        return self.finish()
+
+    def finish(self):
+        self._download_state()
+        self._sync_particles()
+        self._particles_stale = False
         res = self.gbest_particle_data
         path = res["path"].tolist() if isinstance(res["path"], CellPath) else res["path"]
         res["path"] = path

@@ -64,16 +64,18 @@ def test_cfg2_maaco_256_ants_128():
     assert np.mean(succ) >= 0.5, succ                      # the cfg-2 grid must keep >= 50 % of the ants alive
 
 
-def test_cfg3_mpa_4096_predators_512():
+@pytest.mark.parametrize("N,beta", [(4096, 2.0), (1024, 1.5)])
+def test_cfg3_mpa_4096_predators_512(N, beta):
     import pathfit
     from pathfit import env
     from pathfit.engine import score_params
     g = env.bench_grid(512)
-    N = 4096
-    m = pathfit.MPA(g, N, 12, FADs_rate=0.2, P_const=0.5, levy_beta=2.0, turn_penalty_factor=0.1, safety_penalty_factor=0.8,
+    # six iterations of a 6-iteration run: phases 1 (it 1-2), 2 (it 3-4: Levy on the prey / Brownian on the elite) and
+    # 3 (it 5-6: Levy on the elite, CF -> 0) all execute at full size (MPA.py:339-377)
+    m = pathfit.MPA(g, N, 6, FADs_rate=0.2, P_const=0.5, levy_beta=beta, turn_penalty_factor=0.1, safety_penalty_factor=0.8,
                     min_safe_distance=1.8, diagonal_obstacle_penalty=100.0, seed=1)
     fit0 = m.d_stats.download()[:, 4].copy()
-    for it in (1, 2):
+    for it in range(1, 7):
         m.step(it)
         cand_len, cand_cells, cand_stats = m.d_cand_len.download(), m.d_cand_cells.download(), m.d_cand_stats.download()
         got = check_paths(g, cand_cells, cand_len, 0, 512 * 512 - 1, sample=96)

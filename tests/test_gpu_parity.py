@@ -295,7 +295,7 @@ def test_maaco_golden_walks_and_pheromone():
         cap = 4 * (e.R + e.C) + 64 if e.R > 20 else 400
         dc, dl, dp, dt, ds = e.buf((n_ants, cap), np.int32), e.buf(n_ants, np.int32), e.buf(n_ants, np.float64), \
             e.buf(n_ants, np.int32), e.buf(n_ants, np.int32)
-        best, k = math.inf, 0
+        best, k, dead = math.inf, 0, 0
         for it in range(1, n_it + 1):
             e.maaco_walk(it, seed, 0, n_ants, cap, dc, dl, dp, dt, ds)
             cells, lens, plen, turns, st = dc.download(), dl.download(), dp.download(), dt.download(), ds.download()
@@ -303,11 +303,16 @@ def test_maaco_golden_walks_and_pheromone():
                 want = gio.csr_get(z[f"r{ri}_path_off"], z[f"r{ri}_path"], k)
                 assert st[ant] != 3 and np.array_equal(cells[ant, :lens[ant]], want), (ri, it, ant)
                 assert plen[ant] == z[f"r{ri}_len"][k] and turns[ant] == z[f"r{ri}_turns"][k], (ri, it, ant)
+                # MAACO.py:287-288: an ant with no candidate left dies where it stands (88 of the 376 golden ants do,
+                # all of them after at least one step: the start always has a free neighbour on these maps)
+                assert st[ant] == (1 if len(want) == 0 else 0), (ri, it, ant, st[ant])
+                dead += len(want) == 0
                 k += 1
             best = min(best, plen.min())
             e.maaco_evaporate(); e.maaco_deposit(n_ants, cap, dc, dl, dp); e.maaco_clip(best)
             if f"r{ri}_tau" in z:
                 assert np.array_equal(e.maaco_get_pheromone(), z[f"r{ri}_tau"][it - 1]), (ri, it)
+        assert dead > 0, ri
         if f"r{ri}_tau_sum" in z:
             m = e.maaco_get_pheromone()
             assert np.array_equal(m[:4], z[f"r{ri}_tau_last_rows"])
