@@ -2,6 +2,8 @@
 // See include/pathfit.h for the boundary and DESIGN.md for the data layout.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1430,6 +1432,7 @@ struct pf_handle {
   int2* d_prop = nullptr; int* d_doubt = nullptr; int prop_cap = 0;   // MPA proposals {idx, target cell}; doubt list [0] = count, [1..] = predators
   long long doubts_resolved = 0;
   void* d_scan = nullptr;   // 16 B result of the small device scans
+  ncclComm_t comm = nullptr; int comm_rank = 0, comm_world = 1;   // RCCL communicator over xGMI (pf_comm_init); collectives run on `stream`
   long long d2h_small = 0, d2h_bulk = 0, d2h_bulk_bytes = 0;   // device-to-host copies the library made (f1/f2 accounting): <= 64 B / larger
 };
 
@@ -1442,6 +1445,43 @@ static int fail(pf_handle* h, const char* what, hipError_t e) {
 }
 static int failmsg(pf_handle* h, const std::string& m) { if (h) h->err = m; else g_create_err = m; return -2; }
 #define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(h, #call, e_); } while (0)
+
+// RCCL entry points, resolved from librccl on first use (see pf_comm_* at the end of the file)
+namespace {
+struct Rccl {
+  void* so = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+};
+Rccl g_rccl;
+const char* rccl_load() {
+  if (g_rccl.so) return nullptr;
+  void* so = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!so) so = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!so) so = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!so) return "pf_comm: librccl.so not found (dlopen)";
+#define PF_SYM(field, name) do { *(void**)(&g_rccl.field) = dlsym(so, name); if (!g_rccl.field) return "pf_comm: librccl misses " name; } while (0)
+  PF_SYM(GetUniqueId, "ncclGetUniqueId"); PF_SYM(CommInitRank, "ncclCommInitRank"); PF_SYM(CommDestroy, "ncclCommDestroy");
+  PF_SYM(GetErrorString, "ncclGetErrorString"); PF_SYM(AllGather, "ncclAllGather"); PF_SYM(Broadcast, "ncclBroadcast");
+  PF_SYM(AllReduce, "ncclAllReduce"); PF_SYM(Send, "ncclSend"); PF_SYM(Recv, "ncclRecv"); PF_SYM(GroupStart, "ncclGroupStart");
+  PF_SYM(GroupEnd, "ncclGroupEnd");
+#undef PF_SYM
+  g_rccl.so = so;
+  return nullptr;
+}
+int nccl_fail(pf_handle* h, const char* what, ncclResult_t r) {
+  return failmsg(h, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "rccl error"));
+}
+}  // namespace
 
 // Connected components of the free cells under one move-mask policy: host flood fill over the device-built
 // masks (once per policy and grid).  On any failure the labels stay null and the searches simply run in full.
@@ -1531,6 +1571,7 @@ int pf_create(const uint8_t* grid, int32_t R, int32_t C, int32_t device, pf_hand
 void pf_destroy(pf_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
+  if (h->comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(h->stream); g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
   void* ptrs[] = {h->d_occ, h->d_mm_r1, h->d_mm_r0, h->d_mm_r1_nd, h->d_mm_r0_nd, h->d_d2near, h->d_rec, h->d_slot_state,
                   h->d_work, h->d_cnt, h->d_pen, h->d_tier2, h->d_tau, h->d_taua, h->d_eta, h->d_dep, h->d_tep, h->d_visit, h->d_visit_epoch,
                   h->d_bits, h->d_tmp, h->d_elite_stats, h->d_init_cells, h->d_init_stats, h->d_est, h->d_est2, h->d_iota, h->d_queue, h->d_sort_tmp, h->d_prop, h->d_doubt, h->d_scan,
@@ -2488,5 +2529,82 @@ int pf_selftest_mpa_targets(pf_handle* h, uint64_t seed, int32_t n, int32_t is_l
   if (n_doubt) *n_doubt = nd;
   return 0;
 }
+
+
+// ---------------------------------------------------------------------------
+// RCCL over xGMI, bound directly (no torch in the data path).  librccl is opened on first use, so single-GPU users never
+// load it.  Every collective is enqueued on the handle's stream, in order with the kernels: nothing synchronises the
+// host.  The caller ships the 128-byte unique id from rank 0 to the other ranks by any means (a file, an environment
+// variable, torch.distributed's store).
+// ---------------------------------------------------------------------------
+#define NK(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) return nccl_fail(h, #call, r_); } while (0)
+#define NEED_COMM(h) do { if (!(h)) return -2; if (!(h)->comm) return failmsg(h, "pf_comm: call pf_comm_init first"); CK(hipSetDevice((h)->device)); } while (0)
+
+int pf_comm_unique_id(void* id128) {
+  if (!id128) return -2;
+  if (const char* e = rccl_load()) { g_create_err = e; return -2; }
+  ncclUniqueId id;
+  if (g_rccl.GetUniqueId(&id) != ncclSuccess) { g_create_err = "ncclGetUniqueId failed"; return -1; }
+  memcpy(id128, &id, sizeof(id));
+  return 0;
+}
+int pf_comm_init(pf_handle* h, int32_t rank, int32_t world, const void* id128) {
+  if (!h) return -2;
+  if (!id128 || world < 1 || rank < 0 || rank >= world) return failmsg(h, "pf_comm_init: bad arguments");
+  if (h->comm) return failmsg(h, "pf_comm_init: this handle already has a communicator");
+  if (const char* e = rccl_load()) return failmsg(h, e);
+  CK(hipSetDevice(h->device));
+  ncclUniqueId id; memcpy(&id, id128, sizeof(id));
+  NK(g_rccl.CommInitRank(&h->comm, world, id, rank));
+  h->comm_rank = rank; h->comm_world = world;
+  return 0;
+}
+int pf_comm_destroy(pf_handle* h) {
+  if (!h) return -2;
+  if (h->comm) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
+  return 0;
+}
+int pf_comm_all_gather(pf_handle* h, const void* d_send, void* d_recv, int64_t bytes_per_rank) {
+  NEED_COMM(h);
+  if (bytes_per_rank < 0 || !d_send || !d_recv) return failmsg(h, "pf_comm_all_gather: bad arguments");
+  if (bytes_per_rank) NK(g_rccl.AllGather(d_send, d_recv, (size_t)bytes_per_rank, ncclInt8, h->comm, h->stream));
+  return 0;
+}
+int pf_comm_broadcast(pf_handle* h, void* d_buf, int64_t bytes, int32_t root) {
+  NEED_COMM(h);
+  if (bytes < 0 || !d_buf || root < 0 || root >= h->comm_world) return failmsg(h, "pf_comm_broadcast: bad arguments");
+  if (bytes) NK(g_rccl.Broadcast(d_buf, d_buf, (size_t)bytes, ncclInt8, root, h->comm, h->stream));
+  return 0;
+}
+int pf_comm_all_reduce_f64(pf_handle* h, double* d_buf, int64_t count, int32_t op) {   // op: 0 sum, 1 min, 2 max
+  NEED_COMM(h);
+  if (count < 0 || !d_buf || op < 0 || op > 2) return failmsg(h, "pf_comm_all_reduce_f64: bad arguments");
+  if (count) NK(g_rccl.AllReduce(d_buf, d_buf, (size_t)count, ncclDouble, op == 0 ? ncclSum : (op == 1 ? ncclMin : ncclMax), h->comm, h->stream));
+  return 0;
+}
+int pf_comm_send(pf_handle* h, const void* d_buf, int64_t bytes, int32_t peer) {
+  NEED_COMM(h);
+  if (bytes < 0 || !d_buf || peer < 0 || peer >= h->comm_world || peer == h->comm_rank) return failmsg(h, "pf_comm_send: bad arguments");
+  if (bytes) NK(g_rccl.Send(d_buf, (size_t)bytes, ncclInt8, peer, h->comm, h->stream));
+  return 0;
+}
+int pf_comm_recv(pf_handle* h, void* d_buf, int64_t bytes, int32_t peer) {
+  NEED_COMM(h);
+  if (bytes < 0 || !d_buf || peer < 0 || peer >= h->comm_world || peer == h->comm_rank) return failmsg(h, "pf_comm_recv: bad arguments");
+  if (bytes) NK(g_rccl.Recv(d_buf, (size_t)bytes, ncclInt8, peer, h->comm, h->stream));
+  return 0;
+}
+// one step of a ring: send to `to` and receive from `from` as ONE group (both directions progress together)
+int pf_comm_sendrecv(pf_handle* h, const void* d_send, int64_t send_bytes, int32_t to, void* d_recv, int64_t recv_bytes, int32_t from) {
+  NEED_COMM(h);
+  if (send_bytes < 0 || recv_bytes < 0) return failmsg(h, "pf_comm_sendrecv: bad arguments");
+  NK(g_rccl.GroupStart());
+  if (send_bytes && to >= 0) NK(g_rccl.Send(d_send, (size_t)send_bytes, ncclInt8, to, h->comm, h->stream));
+  if (recv_bytes && from >= 0) NK(g_rccl.Recv(d_recv, (size_t)recv_bytes, ncclInt8, from, h->comm, h->stream));
+  NK(g_rccl.GroupEnd());
+  return 0;
+}
+int pf_comm_rank(pf_handle* h) { return h ? h->comm_rank : 0; }
+int pf_comm_world(pf_handle* h) { return h && h->comm ? h->comm_world : 1; }
 
 }  // extern "C"

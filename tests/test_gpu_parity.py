@@ -401,8 +401,9 @@ def test_mpa_target_cells_two_million_draws_vs_oracle():
         got, nd = _targets(e, seed, is_levy, beta, scale, cur, elite)
         want = po.mpa_targets_batch(seed, is_levy, e.R, e.C, cur, elite, scale, beta, _levy_sigma(beta))
         assert np.array_equal(got, want), (is_levy, beta, scale, int((got != want).sum()))
-        if is_levy:
-            assert (got != cur).mean() > 0.5              # the Levy branch really moves at these scales
+        if is_levy and beta == 1.5:
+            assert (got != cur).mean() > 0.5              # the Levy branch really moves at these scales (with beta = 2 the
+                                                          # Mantegna sigma is sin(pi) ~ 1e-16: the step is always 0, MPA.py:251)
         doubts += nd
     assert doubts < 100                                   # the host route is the exception (expected ~0)
 
