@@ -251,6 +251,76 @@ int pf_selftest_sqrt(pf_handle* h, int32_t n, const int64_t* d_in, double* d_out
 int pf_selftest_rng(pf_handle* h, uint64_t seed, uint64_t dom, uint64_t it, uint64_t agent, uint64_t* d_u64,
                     double* d_f64, int64_t* d_i64);
 
+/* ---- iteration control in HBM -------------------------------------------------------------------
+ * list.sort(key=fitness) (MPA.py:321,333,412; ga_solver.py:209): d_order holds the list (position -> id); it is
+ * re-ordered by a STABLE device sort on key[pos] = d_vals[d_order[pos] * stride + offset].  Stream ordered. */
+int pf_sort_order_by_key(pf_handle* h, int32_t n, const double* d_vals, int32_t stride, int32_t offset, int32_t* d_order);
+/* d_dst[i] = d_src[i * stride + offset] (a stats column packed for an all_gather) */
+int pf_gather_col(pf_handle* h, int32_t n, const double* d_src, int32_t stride, int32_t offset, double* d_dst);
+/* The elite of an MPA iteration (MPA.py:334, population[0] after the sort) lives in a library-owned buffer: cells
+ * [R*C] int32, length int32, stats double[5].  pf_mpa_pick_elite copies the row of predator d_order[0] - first_id of
+ * this rank's store into it; a sharded run broadcasts the three pieces from the owner instead.  Passing
+ * elite_len = -1 to pf_mpa_iter_batch makes the sweep read the length from that buffer (the host never learns it). */
+int pf_mpa_elite_buf(pf_handle* h, void** d_cells, void** d_len, void** d_stats);
+int pf_mpa_pick_elite(pf_handle* h, int32_t path_cap, const int32_t* d_pop_cells, const int32_t* d_pop_len,
+                      const double* d_pop_stats, const int32_t* d_order, int32_t first_id);
+/* positions (in the global fitness order d_gorder[N] of ids) and storage slots of the predators with ids in [lo, hi),
+ * in position order: the d_gidx / d_slot arrays of pf_mpa_iter_batch for a rank that stores ids [lo, hi) */
+int pf_mpa_local_view(pf_handle* h, int32_t N, const int32_t* d_gorder, int32_t lo, int32_t hi, int32_t* d_gidx, int32_t* d_slot);
+
+/* ---- one GA generation in HBM (ga_solver.py:178-213) -----------------------------------------------------------------
+ * The population is stored by storage id (= child index of the generation that made the individual): chromosomes
+ * d_chrom_all [N][W] cells, fitness d_fit_all [N]; d_gorder [N] is the fitness-sorted list (position -> storage id).
+ * pf_ga_select_dev: GASolver._selection for all N slots (one sequential stream per generation, replayed by one
+ *   device thread) -> d_psid[s] = storage id of the parent chosen for slot s.
+ * pf_ga_breed_dev: _crossover + _mutate for the children with index in [child0, child0 + nchild) (thread per pair,
+ *   stream (seed, DOM_GA, gen, pair)) -> d_out [nchild][W].
+ * pf_ga_assemble_dev: new individual i = child i if it decoded (d_kid_len > 0) else its fallback parent d_psid[lo + i]
+ *   (ga_solver.py:204-205); a fallback parent's path row is copied when this rank stores it (ids [old_lo, old_hi)),
+ *   else the row is marked absent (length -1).  All stream ordered, no host copies. */
+int pf_ga_select_dev(pf_handle* h, uint64_t seed, int32_t gen, int32_t n, int32_t tournament_size, const double* d_fit_all,
+                     const int32_t* d_gorder, int32_t* d_psid);
+int pf_ga_breed_dev(pf_handle* h, uint64_t seed, int32_t gen, int32_t N, int32_t W, double crossover_rate, double mutation_rate,
+                    const int32_t* d_chrom_all, const int32_t* d_psid, int32_t child0, int32_t nchild, int32_t* d_out);
+int pf_ga_assemble_dev(pf_handle* h, int32_t n_loc, int32_t W, int32_t path_cap, int32_t lo, const int32_t* d_kid_len,
+                       const int32_t* d_kid_chrom, const double* d_kid_stats, const int32_t* d_kid_cells, const int32_t* d_psid,
+                       const int32_t* d_chrom_old, const double* d_stats_old, const int32_t* d_cells_old, const int32_t* d_len_old,
+                       int32_t old_lo, int32_t old_hi, int32_t* d_chrom_new, double* d_stats_new, int32_t* d_cells_new,
+                       int32_t* d_len_new);
+
+/* MAACO.py:306-311 in two steps (the multi-GPU fold works on row chunks): _begin marks the cells of the successful
+ * ants and computes Q / L per ant, _cells adds the deposits of cells [cell0, cell1) in ant order.  pf_maaco_deposit =
+ * _begin + _cells(0, R*C).  All stream ordered. */
+int pf_maaco_deposit_begin(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_cells, const int32_t* d_len,
+                           const double* d_plen);
+int pf_maaco_deposit_cells(pf_handle* h, int32_t cell0, int32_t cell1);
+/* MAACO.py:343-349 (best ant of an iteration: length, then turns within 1e-9) over device columns of n ants;
+ * out3 = {best_len, best_turns, best_idx} (-1: no ant arrived).  One 24-byte device-to-host copy. */
+int pf_maaco_best_dev(pf_handle* h, int32_t n, const double* d_plen, const int32_t* d_turns, double* out3);
+
+/* ---- multi-GPU exchange: RCCL over xGMI, bound directly (no reference counterpart) -------------
+ * One process per GPU.  librccl is opened on first use.  pf_comm_unique_id (rank 0) produces the 128-byte id the
+ * launcher ships to the other ranks (a file, an env var, torch.distributed's store); pf_comm_init joins the
+ * communicator on the handle's device.  Every collective below is ENQUEUED on the handle's stream, in order with the
+ * kernels: no host synchronisation, device pointers only.  Sizes are bytes.  The population solvers need exactly:
+ *   all_gather   per-agent (length, turns) / fitness columns and GA chromosomes          (C2, C3)
+ *   broadcast    the winner's / elite's path row and stats from its owner                 (C2)
+ *   send/recv    the pheromone matrix chunks of the ordered MAACO fold, rank k-1 -> k    (C1, MAACO.py:306-311)
+ *   all_reduce   the non-strict MAACO delta sum, timing maxima                           */
+int pf_comm_unique_id(void* id128);
+int pf_comm_init(pf_handle* h, int32_t rank, int32_t world, const void* id128);
+int pf_comm_destroy(pf_handle* h);
+int pf_comm_rank(pf_handle* h);
+int pf_comm_world(pf_handle* h);
+int pf_comm_all_gather(pf_handle* h, const void* d_send, void* d_recv, int64_t bytes_per_rank);
+int pf_comm_broadcast(pf_handle* h, void* d_buf, int64_t bytes, int32_t root);
+int pf_comm_all_reduce_f64(pf_handle* h, double* d_buf, int64_t count, int32_t op /* 0 sum, 1 min, 2 max */);
+int pf_comm_send(pf_handle* h, const void* d_buf, int64_t bytes, int32_t peer);
+int pf_comm_recv(pf_handle* h, void* d_buf, int64_t bytes, int32_t peer);
+/* one ring step as a single group: send to `to` (skip if < 0) and receive from `from` (skip if < 0) */
+int pf_comm_sendrecv(pf_handle* h, const void* d_send, int64_t send_bytes, int32_t to, void* d_recv, int64_t recv_bytes,
+                     int32_t from);
+
 /* pso.py:218-219 for the paths: rows of the particles pf_pso_pbest marked improved are copied into the pbest path
  * store (both strided [n][path_cap]); asynchronous (stream ordered). */
 int pf_pso_pbest_paths(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_cells, const int32_t* d_len,
@@ -262,7 +332,7 @@ int pf_pso_pbest_paths(pf_handle* h, int32_t n, int32_t path_cap, const int32_t*
 int pf_pso_scan(pf_handle* h, int32_t n, const double* d_stats, const int32_t* d_len, const int32_t* d_status,
                 const double* d_pbest_fit, double gbest_fit, int32_t sync_mode, int32_t* idx_out, double* fit_out,
                 int32_t* overflow_out);
-/* Device-to-host copies made through this handle since pf_create: copies of at most 64 bytes, larger ones, and the
+/* Device-to-host copies made through this handle since pf_create: copies of at most 128 bytes, larger ones, and the
  * bytes of the larger ones (the solver loops keep populations in HBM: SURVEY.md 8 f1/f2). */
 int pf_d2h_counts(pf_handle* h, int64_t* small_copies, int64_t* bulk_copies, int64_t* bulk_bytes);
 

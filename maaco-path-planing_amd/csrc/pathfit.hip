@@ -24,6 +24,8 @@ using namespace pf;
 #define DOM_MPA 2
 #define DOM_PSO 3
 #define DOM_MPA_FADS 5
+#define DOM_GA 4
+#define DOM_GA_SELECT 7
 
 // ===========================================================================
 // device-side launch parameter blocks
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(64) void k_maaco_walk(MaacoArgs p) {
   const bool o1 = !((vcS > 0 && mdc < 0) || (vcS < 0 && mdc > 0) || (vrS > 0 && mdr < 0) || (vrS < 0 && mdr > 0));
   const unsigned O1 = (unsigned)(__ballot(o1 && lane < 8) & 0xFF);
   const double mcost = (mdr != 0 && mdc != 0) ? PF_SQRT2 : 1.0;
-  unsigned long long steps_tot = 0, cand_tot = 0, cells_tot = 0;
+  unsigned long long steps_tot = 0, cand_tot = 0, cells_tot = 0, ovf_tot = 0;
   for (;;) {
     const int a = next_work(p.work, lane);
     if (a >= p.n) break;
@@ -515,11 +517,12 @@ __global__ __launch_bounds__(64) void k_maaco_walk(MaacoArgs p) {
       p.turns[a] = rc == 0 ? nturn : -1;
       p.status[a] = rc;
     }
-    cells_tot += rc == 0 ? n : 0;
+    cells_tot += rc == 0 ? n : 0; ovf_tot += rc == 3;
   }
   if (lane == 0) {
     p.slot_epoch[blockIdx.x] = epoch;
     atomicAdd(&p.cnt->steps, steps_tot); atomicAdd(&p.cnt->candidates, cand_tot); atomicAdd(&p.cnt->path_cells, cells_tot);
+    if (ovf_tot) atomicAdd(&p.cnt->overflow, ovf_tot);
   }
 }
 
@@ -554,7 +557,7 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
   const unsigned O1 = gballot8(o1);
   const double mcost = (mdr != 0 && mdc != 0) ? PF_SQRT2 : 1.0;
   const long long max_steps = (long long)RC * 2;                   // MAACO.py:283
-  unsigned long long steps_tot = 0, cand_tot = 0, cells_tot = 0;
+  unsigned long long steps_tot = 0, cand_tot = 0, cells_tot = 0, ovf_tot = 0;
   // per-ant state (replicated in the 8 lanes of the group)
   int a = -1, cr = 0, cc = 0, n = 0, prev_k = -1, nturn = 0, rc = 0;
   long long steps = 0;
@@ -674,13 +677,56 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
         p.turns[a] = rc == 0 ? nturn : -1;
         p.status[a] = rc;
       }
-      cells_tot += rc == 0 ? n : 0;
+      cells_tot += rc == 0 ? n : 0; ovf_tot += rc == 3;
       need = true;
     }
   }
   if (k == 0) {
     p.slot_epoch[slot] = epoch;
     atomicAdd(&p.cnt->steps, steps_tot); atomicAdd(&p.cnt->candidates, cand_tot); atomicAdd(&p.cnt->path_cells, cells_tot);
+    if (ovf_tot) atomicAdd(&p.cnt->overflow, ovf_tot);
+  }
+}
+
+// Best ant of an iteration, MAACO.py:343-349, without the sequential loop: `L < best` only ever fires up to the first
+// occurrence p of the minimum length, which resets (idx, turns) to ant p; afterwards only ants within 1e-9 of that
+// minimum with strictly fewer turns take over, so the result is the first ant, among p and the later near-minimum ants,
+// that attains their smallest turn count.  out = {best_len, best_turns (inf for none), best_idx as a double (-1 none)}.
+__global__ __launch_bounds__(1024) void k_maaco_best(int n, const double* plen, const int* turns, double* out) {
+  __shared__ unsigned long long red[1024];
+  __shared__ double sL; __shared__ int sP;
+  const int t = threadIdx.x;
+  // (1) minimum length, non-negative doubles compare like their bit patterns (+inf included)
+  unsigned long long b = ~0ull;
+  for (int i = t; i < n; i += 1024) { const unsigned long long k = (unsigned long long)__double_as_longlong(plen[i]); b = k < b ? k : b; }
+  red[t] = b; __syncthreads();
+  for (int st = 512; st > 0; st >>= 1) { if (t < st && red[t + st] < red[t]) red[t] = red[t + st]; __syncthreads(); }
+  const unsigned long long lb = red[0];
+  __syncthreads();
+  // (2) its first occurrence
+  unsigned long long pi = ~0ull;
+  for (int i = t; i < n; i += 1024) if ((unsigned long long)__double_as_longlong(plen[i]) == lb) { pi = (unsigned long long)i < pi ? (unsigned long long)i : pi; }
+  red[t] = pi; __syncthreads();
+  for (int st = 512; st > 0; st >>= 1) { if (t < st && red[t + st] < red[t]) red[t] = red[t + st]; __syncthreads(); }
+  if (t == 0) { sL = __longlong_as_double((long long)lb); sP = (int)red[0]; }
+  __syncthreads();
+  const double Lmin = sL; const int p = sP;
+  if (n == 0 || Lmin == PF_INF) { if (t == 0) { out[0] = PF_INF; out[1] = PF_INF; out[2] = -1.0; } return; }
+  // (3) smallest turn count among p and the later ants within 1e-9 of Lmin, then its first holder: key = turns << 32 | index
+  unsigned long long kb = ~0ull;
+  for (int i = p + t; i < n; i += 1024) {
+    if (i == p || fabs(plen[i] - Lmin) < 1e-9) {
+      const unsigned long long T = turns[i] < 0 ? 0x7FFFFFFFull : (unsigned long long)turns[i];
+      const unsigned long long k = (T << 32) | (unsigned long long)i;
+      kb = k < kb ? k : kb;
+    }
+  }
+  red[t] = kb; __syncthreads();
+  for (int st = 512; st > 0; st >>= 1) { if (t < st && red[t + st] < red[t]) red[t] = red[t + st]; __syncthreads(); }
+  if (t == 0) {
+    const unsigned long long k = red[0];
+    const unsigned T = (unsigned)(k >> 32);
+    out[0] = Lmin; out[1] = T == 0x7FFFFFFFu ? PF_INF : (double)T; out[2] = (double)(unsigned)(k & 0xFFFFFFFFull);
   }
 }
 
@@ -713,10 +759,10 @@ __global__ __launch_bounds__(64) void k_visit_bits(int n, int path_cap, const in
 // Every word of the matrix is read here exactly once, so the kernel also leaves it zeroed for the next iteration (a
 // store per non-zero word) instead of the host clearing n/8 bytes per cell -- 512 MB at 16 384 ants on G512 -- every time.
 __global__ __launch_bounds__(1024) void k_tau_deposit(double* tau, const uint8_t* occ, int RC, unsigned long long* bits, int nwords,
-                                                     const double* dep) {
+                                                     const double* dep, int cell0, int cell1) {
   extern __shared__ __attribute__((aligned(16))) double sdep[];    // [PF_DEP_CHUNK]
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = i < RC;
+  const int i = cell0 + blockIdx.x * blockDim.x + threadIdx.x;     // cells [cell0, cell1): the pipelined multi-GPU fold works on row chunks
+  const bool live = i < cell1;
   double t = live ? tau[i] : 0.0;
   bool touched = false;
   for (int c0 = 0; c0 < nwords; c0 += PF_DEP_CHUNK / 64) {
@@ -850,6 +896,7 @@ struct MpaPhaseArgs {
   const int* gidx;   // [n] index of the predator in the GLOBAL fitness-sorted population (stream key, Levy split)
   const int* slot;   // [n] storage slot of the predator in pop_*
   const int* elite_cells; int elite_len; const double* elite_stats;   // device double[5]
+  const int* elite_len_dev;   // non-null: the elite's length lives in HBM (device-resident iteration: the host never learns it)
   int* out_cells; int* out_len; double* out_stats; int* status;
   // explicit mode (pf_mpa_rebuild_batch): no idx/gate draws
   const int* ex_idx; const int* ex_levy; const double* ex_scale; const int* ex_agent;
@@ -861,19 +908,20 @@ struct MpaPhaseArgs {
 struct MpaPlan { bool is_levy; double scale, gate_p; const int* mod; int modL; const double* mod_stats; const int* ref; int refL;
                  const int* prey; int preyL; const double* prey_stats; int gi, slot; };
 PF_DEV MpaPlan mpa_plan(const MpaPhaseArgs& p, int a) {
+  const int eL = p.elite_len_dev ? *p.elite_len_dev : p.elite_len;
   MpaPlan q;
   q.gi = p.ex_idx ? p.ex_agent[a] : p.gidx[a];                   // index in the fitness-sorted population
   q.slot = p.ex_idx ? a : p.slot[a];
   q.prey = p.pop_cells + (size_t)q.slot * p.path_cap; q.preyL = p.pop_len[q.slot]; q.prey_stats = p.pop_stats + (size_t)q.slot * 5;
-  if (p.ex_idx) { q.is_levy = p.ex_levy[a] != 0; q.scale = p.ex_scale[a]; q.mod = q.prey; q.modL = q.preyL; q.mod_stats = q.prey_stats; q.ref = p.elite_cells; q.refL = p.elite_len; }
-  else if (p.phase == 1) { q.is_levy = false; q.scale = p.m.P; q.mod = q.prey; q.modL = q.preyL; q.mod_stats = q.prey_stats; q.ref = p.elite_cells; q.refL = p.elite_len; }
+  if (p.ex_idx) { q.is_levy = p.ex_levy[a] != 0; q.scale = p.ex_scale[a]; q.mod = q.prey; q.modL = q.preyL; q.mod_stats = q.prey_stats; q.ref = p.elite_cells; q.refL = eL; }
+  else if (p.phase == 1) { q.is_levy = false; q.scale = p.m.P; q.mod = q.prey; q.modL = q.preyL; q.mod_stats = q.prey_stats; q.ref = p.elite_cells; q.refL = eL; }
   else if (p.phase == 2) {
     q.is_levy = q.gi < p.m.N / 2;                                 // :351
     q.scale = q.is_levy ? p.m.P : p.m.P * p.CF;                   // :354
-    q.mod = q.is_levy ? q.prey : p.elite_cells; q.modL = q.is_levy ? q.preyL : p.elite_len;
+    q.mod = q.is_levy ? q.prey : p.elite_cells; q.modL = q.is_levy ? q.preyL : eL;
     q.mod_stats = q.is_levy ? q.prey_stats : p.elite_stats;
-    q.ref = q.is_levy ? p.elite_cells : q.prey; q.refL = q.is_levy ? p.elite_len : q.preyL;
-  } else { q.is_levy = true; q.scale = p.m.P * p.CF; q.mod = p.elite_cells; q.modL = p.elite_len; q.mod_stats = p.elite_stats; q.ref = q.prey; q.refL = q.preyL; }
+    q.ref = q.is_levy ? p.elite_cells : q.prey; q.refL = q.is_levy ? eL : q.preyL;
+  } else { q.is_levy = true; q.scale = p.m.P * p.CF; q.mod = p.elite_cells; q.modL = eL; q.mod_stats = p.elite_stats; q.ref = q.prey; q.refL = q.preyL; }
   q.gate_p = p.phase == 1 ? p.m.P : q.scale;                      // :344 / :359 / :372
   return q;
 }
@@ -1348,6 +1396,130 @@ __global__ __launch_bounds__(64) void k_mpa_memory(int n, int path_cap, const in
   if (threadIdx.x == 0) pop_len[slot] = L;
 }
 
+// ---- device-resident iteration control: sort keys, elite pick, local view ----------------------
+// key[pos] = vals[order[pos] * stride + offset]: list.sort(key=fitness) is a stable sort of the CURRENT list order
+__global__ void k_sort_keys(int n, const double* vals, int stride, int offset, const int* order, double* keys) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) keys[i] = vals[(size_t)order[i] * stride + offset];
+}
+__global__ void k_gather_col(int n, const double* src, int stride, int offset, double* dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[(size_t)i * stride + offset];
+}
+// the elite = population[0] after the sort (MPA.py:334): its row, length and stats into the elite buffer
+__global__ __launch_bounds__(256) void k_mpa_pick_elite(int path_cap, const int* pop_cells, const int* pop_len, const double* pop_stats,
+                                                       const int* order, int lo, int* e_cells, int* e_len, double* e_stats) {
+  const int slot = order[0] - lo;                                  // (sharded: order holds global ids, this rank stores [lo, ...))
+  const int L = pop_len[slot];
+  for (int i = threadIdx.x; i < L; i += 256) e_cells[i] = pop_cells[(size_t)slot * path_cap + i];
+  if (threadIdx.x < 5) e_stats[threadIdx.x] = pop_stats[(size_t)slot * 5 + threadIdx.x];
+  if (threadIdx.x == 0) *e_len = L;
+}
+// positions (in the global sorted order) and storage slots of the predators this rank stores, in position order
+__global__ __launch_bounds__(1024) void k_mpa_local_view(int N, const int* gorder, int lo, int hi, int* gidx, int* slot) {
+  __shared__ int wsum[16];
+  __shared__ int base;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  for (int p0 = 0; p0 < N; p0 += 1024) {
+    const int pos = p0 + threadIdx.x;
+    const int gid = pos < N ? gorder[pos] : -1;
+    const bool mine = gid >= lo && gid < hi;
+    const unsigned long long m = __ballot(mine);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) wsum[w] = __builtin_popcountll(m);
+    __syncthreads();
+    int off = base;
+    for (int k = 0; k < w; ++k) off += wsum[k];
+    if (mine) { const int at = off + __builtin_popcountll(m & ((1ull << lane) - 1ull)); gidx[at] = pos; slot[at] = gid - lo; }
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int k = 0; k < 16; ++k) t += wsum[k]; base += t; }
+    __syncthreads();
+  }
+}
+
+// ---- GA operators on the device (ga_solver.py:136-160, 186-205) ---------------------------------------
+// Tournament selection draws from ONE stream per generation (seed, DOM_GA_SELECT, gen, 0), slot after slot, with
+// data-dependent draw counts (random.sample's rejection loops): inherently sequential, so one thread replays it --
+// N x k draws, microseconds -- against the fitness column in HBM.  psid[s] = storage id of the parent chosen for slot s.
+__global__ void k_ga_select(unsigned long long seed, int gen, int n, int k, const double* fit_all, const int* gorder, int* pool, int* psid) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  Rng r; r.init(seed, DOM_GA_SELECT, (unsigned long long)gen, 0);
+  long long setsize = 21;                                            // random.sample: pool copy for small n, rejection set otherwise
+  if (k > 5) { long long p4 = 1; while (p4 < (long long)k * 3) p4 *= 4; setsize += p4; }
+  int sel[64];
+  for (int s_ = 0; s_ < n; ++s_) {
+    if (n <= setsize) {
+      for (int i = 0; i < n; ++i) pool[i] = i;
+      for (int i = 0; i < k; ++i) { const int j = (int)r.randbelow((unsigned long long)(n - i)); sel[i] = pool[j]; pool[j] = pool[n - i - 1]; }
+    } else {
+      for (int i = 0; i < k; ++i) {
+        int j;
+        for (;;) { j = (int)r.randbelow((unsigned long long)n); bool seen = false; for (int q = 0; q < i; ++q) seen |= sel[q] == j; if (!seen) break; }
+        sel[i] = j;
+      }
+    }
+    int best = sel[0];                                               // min(tournament, key=fitness): the first minimum
+    double bf = fit_all[gorder[best]];
+    for (int i = 1; i < k; ++i) { const double f = fit_all[gorder[sel[i]]]; if (f < bf) { bf = f; best = sel[i]; } }
+    psid[s_] = gorder[best];
+  }
+}
+// crossover + mutation, one thread per pair of children (stream (seed, DOM_GA, gen, pair), ga_solver.py:144-160,186-194):
+// writes the children with index in [child0, child0 + nchild) to out[(index - child0) * W ...]
+__global__ void k_ga_breed(unsigned long long seed, int gen, int N, int W, double cx_rate, double mut_rate, const uint8_t* occ, int R, int C,
+                           const int* chrom_all, const int* psid, int child0, int nchild, int* out) {
+  const int pair = child0 / 2 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int idx = 2 * pair;
+  if (idx >= child0 + nchild) return;
+  const int* p1 = chrom_all + (size_t)psid[idx % N] * W;
+  const int* p2 = chrom_all + (size_t)psid[(idx + 1) % N] * W;
+  Rng r; r.init(seed, DOM_GA, (unsigned long long)gen, (unsigned long long)pair);
+  int point = 0;
+  if (r.random() < cx_rate) point = W > 1 ? (int)r.randint(1, W - 1) : 0;   // :145-148
+  for (int which = 0; which < 2; ++which) {                          // :154-160, child 1 then child 2 on the same stream
+    const int ci = idx + which;
+    const bool keep = ci >= child0 && ci < child0 + nchild && ci < N;
+    for (int i = 0; i < W; ++i) {
+      const bool tail = point > 0 && i >= point;
+      int g_ = which == 0 ? (tail ? p2[i] : p1[i]) : (tail ? p1[i] : p2[i]);
+      if (r.random() < mut_rate)
+        for (;;) {                                                   // :48-53 rejection-sample a free cell
+          const int rr = (int)r.randint(0, R - 1), cc = (int)r.randint(0, C - 1);
+          if (occ[(size_t)rr * C + cc] != 1) { g_ = rr * C + cc; break; }
+        }
+      if (keep) out[(size_t)(ci - child0) * W + i] = g_;
+    }
+  }
+}
+// new_population[i] = child i if it decoded, else the parent it falls back to (ga_solver.py:198-205: parents[i], i.e.
+// p1 for even i, p2 for odd i).  Storage id of the new individual = its child index.  A fallback parent's path is
+// copied when this rank stores it, else the row is marked absent (len -1): a path is decode(chromosome), re-derived on demand.
+__global__ __launch_bounds__(64) void k_ga_assemble(int n_loc, int W, int cap, int lo, const int* kid_len, const int* kid_chrom,
+                                                    const double* kid_stats, const int* kid_cells, const int* psid, const int* chrom_old,
+                                                    const double* stats_old, const int* cells_old, const int* len_old, int old_lo, int old_hi,
+                                                    int* chrom_new, double* stats_new, int* cells_new, int* len_new) {
+  const int i = blockIdx.x;
+  if (i >= n_loc) return;
+  const int t = threadIdx.x;
+  if (kid_len[i] > 0) {
+    for (int k = t; k < W; k += 64) chrom_new[(size_t)i * W + k] = kid_chrom[(size_t)i * W + k];
+    if (t < 5) stats_new[(size_t)i * 5 + t] = kid_stats[(size_t)i * 5 + t];
+    for (int k = t; k < kid_len[i]; k += 64) cells_new[(size_t)i * cap + k] = kid_cells[(size_t)i * cap + k];
+    if (t == 0) len_new[i] = kid_len[i];
+  } else {
+    const int sid = psid[lo + i];
+    for (int k = t; k < W; k += 64) chrom_new[(size_t)i * W + k] = chrom_old[(size_t)sid * W + k];
+    if (t < 5) stats_new[(size_t)i * 5 + t] = stats_old[(size_t)sid * 5 + t];
+    int L = -1;
+    if (sid >= old_lo && sid < old_hi) {
+      L = len_old[sid - old_lo];
+      for (int k = t; k < L; k += 64) cells_new[(size_t)i * cap + k] = cells_old[(size_t)(sid - old_lo) * cap + k];
+    }
+    if (t == 0) len_new[i] = L;
+  }
+}
+
 // ===========================================================================
 // device self-tests
 // ===========================================================================
@@ -1431,9 +1603,13 @@ struct pf_handle {
   void* d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
   int2* d_prop = nullptr; int* d_doubt = nullptr; int prop_cap = 0;   // MPA proposals {idx, target cell}; doubt list [0] = count, [1..] = predators
   long long doubts_resolved = 0;
-  void* d_scan = nullptr;   // 16 B result of the small device scans
+  void* d_scan = nullptr; void* d_scan3 = nullptr;   // results of the small device scans
+  double* d_okey = nullptr; double* d_okey2 = nullptr; int* d_oval2 = nullptr; int okey_cap = 0;   // pf_sort_order_by_key scratch
+  int* d_elite_cells = nullptr; int* d_elite_len = nullptr;   // the elite of the iteration (MPA.py:334), device resident
+  int* d_ga_pool = nullptr; int ga_pool_cap = 0;              // random.sample's pool copy (small populations)
+  int dep_words = 0; long long dep_done = 0;   // MAACO deposit in progress: words of the bit matrix, cells already folded
   ncclComm_t comm = nullptr; int comm_rank = 0, comm_world = 1;   // RCCL communicator over xGMI (pf_comm_init); collectives run on `stream`
-  long long d2h_small = 0, d2h_bulk = 0, d2h_bulk_bytes = 0;   // device-to-host copies the library made (f1/f2 accounting): <= 64 B / larger
+  long long d2h_small = 0, d2h_bulk = 0, d2h_bulk_bytes = 0;   // device-to-host copies the library made (f1/f2 accounting): <= 128 B / larger
 };
 
 static long long g_step_cap = 0;   // > 0: lowers the connectors' step cap (pf_set_option "astar_step_cap": tests of the cap path)
@@ -1574,7 +1750,7 @@ void pf_destroy(pf_handle* h) {
   if (h->comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(h->stream); g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
   void* ptrs[] = {h->d_occ, h->d_mm_r1, h->d_mm_r0, h->d_mm_r1_nd, h->d_mm_r0_nd, h->d_d2near, h->d_rec, h->d_slot_state,
                   h->d_work, h->d_cnt, h->d_pen, h->d_tier2, h->d_tau, h->d_taua, h->d_eta, h->d_dep, h->d_tep, h->d_visit, h->d_visit_epoch,
-                  h->d_bits, h->d_tmp, h->d_elite_stats, h->d_init_cells, h->d_init_stats, h->d_est, h->d_est2, h->d_iota, h->d_queue, h->d_sort_tmp, h->d_prop, h->d_doubt, h->d_scan,
+                  h->d_bits, h->d_tmp, h->d_elite_stats, h->d_init_cells, h->d_init_stats, h->d_est, h->d_est2, h->d_iota, h->d_queue, h->d_sort_tmp, h->d_prop, h->d_doubt, h->d_scan, h->d_scan3, h->d_okey, h->d_okey2, h->d_oval2, h->d_elite_cells, h->d_elite_len, h->d_ga_pool,
                   h->d_comp[0], h->d_comp[1], h->d_comp[2], h->d_comp[3], h->d_ds, h->d_dt};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1586,7 +1762,7 @@ void pf_destroy(pf_handle* h) {
 int pf_dev_alloc(pf_handle* h, int64_t bytes, void** d_out) { CK(hipSetDevice(h->device)); CK(hipMalloc(d_out, (size_t)(bytes > 0 ? bytes : 1))); return 0; }
 int pf_dev_free(pf_handle* h, void* p) { CK(hipSetDevice(h->device)); CK(hipFree(p)); return 0; }
 int pf_h2d(pf_handle* h, void* d, const void* s, int64_t n) { CK(hipMemcpyAsync(d, s, (size_t)n, hipMemcpyHostToDevice, h->stream)); CK(hipStreamSynchronize(h->stream)); return 0; }
-int pf_d2h(pf_handle* h, void* d, const void* s, int64_t n) { CK(hipMemcpyAsync(d, s, (size_t)n, hipMemcpyDeviceToHost, h->stream)); CK(hipStreamSynchronize(h->stream)); if (n <= 64) h->d2h_small += 1; else { h->d2h_bulk += 1; h->d2h_bulk_bytes += n; } return 0; }
+int pf_d2h(pf_handle* h, void* d, const void* s, int64_t n) { CK(hipMemcpyAsync(d, s, (size_t)n, hipMemcpyDeviceToHost, h->stream)); CK(hipStreamSynchronize(h->stream)); if (n <= 128) h->d2h_small += 1; else { h->d2h_bulk += 1; h->d2h_bulk_bytes += n; } return 0; }
 int pf_d2h_counts(pf_handle* h, int64_t* small_copies, int64_t* bulk_copies, int64_t* bulk_bytes) { if (!h) return -2; if (small_copies) *small_copies = h->d2h_small; if (bulk_copies) *bulk_copies = h->d2h_bulk; if (bulk_bytes) *bulk_bytes = h->d2h_bulk_bytes; return 0; }
 int pf_d2d(pf_handle* h, void* d, const void* s, int64_t n) { CK(hipMemcpyAsync(d, s, (size_t)n, hipMemcpyDeviceToDevice, h->stream)); CK(hipStreamSynchronize(h->stream)); return 0; }
 int pf_memset(pf_handle* h, void* d, int32_t b, int64_t n) { CK(hipMemsetAsync(d, b, (size_t)n, h->stream)); CK(hipStreamSynchronize(h->stream)); return 0; }
@@ -1632,6 +1808,10 @@ static int ensure_slots(pf_handle* h, int allow_diag = 1, int restrict_corner = 
   }
   return 0;
 }
+static int ensure_elite_buf(pf_handle* h) {
+  if (!h->d_elite_cells) { CK(hipMalloc(&h->d_elite_cells, sizeof(int) * (size_t)h->RC)); CK(hipMalloc(&h->d_elite_len, sizeof(int))); }
+  return 0;
+}
 static Common make_common(pf_handle* h, int allow_diag, int restrict_corner, int S, int retry) {
   Common c;
   c.G = make_grid(h, allow_diag, restrict_corner);
@@ -1646,6 +1826,7 @@ static int begin_batch(pf_handle* h) {
 static int end_batch(pf_handle* h, DevCounters* dc) {
   CK(hipMemcpyAsync(dc, h->d_cnt, sizeof(DevCounters), hipMemcpyDeviceToHost, h->stream));
   CK(hipStreamSynchronize(h->stream));
+  h->d2h_small += 1;                                              // the 72-byte counter block of every batch
   h->last.pops = dc->pops; h->last.pushes = dc->pushes; h->last.nbr_examined = dc->nbr; h->last.path_cells = dc->path_cells;
   h->last.steps = dc->steps; h->last.candidates = dc->candidates; h->last.decrease_keys = dc->deckey; h->last.overflow_agents = dc->overflow;
   h->last.pruned_rebuilds = dc->pruned;
@@ -2009,13 +2190,16 @@ int pf_maaco_evaporate(pf_handle* h) {
   CK(hipSetDevice(h->device));
   hipLaunchKernelGGL(k_tau_evaporate, dim3((h->RC + 255) / 256), dim3(256), 0, h->stream, h->d_tau, h->RC, 1.0 - h->mp.rho);
   CK(hipGetLastError());
-  CK(hipStreamSynchronize(h->stream));
-  return 0;
+  return 0;                                                        // stream ordered: nothing waits
 }
 
-int pf_maaco_deposit(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_cells, const int32_t* d_len,
-                     const double* d_plen) {
-  if (!h || !h->maaco_ready) return failmsg(h, "pf_maaco_deposit: setup first");
+// MAACO.py:306-311 in two steps so that the multi-GPU fold can work on row chunks: _begin marks which successful ant
+// visited which cell (bit matrix) and computes Q / L per ant; _cells adds the marked deposits, in ant order, to the
+// pheromone of cells [cell0, cell1) (every cell exactly once per update).
+int pf_maaco_deposit_begin(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_cells, const int32_t* d_len,
+                           const double* d_plen) {
+  if (!h || !h->maaco_ready) return failmsg(h, "pf_maaco_deposit_begin: setup first");
+  h->dep_words = 0;
   if (n <= 0) return 0;
   CK(hipSetDevice(h->device));
   const size_t words = (size_t)(n + 63) / 64;
@@ -2032,11 +2216,38 @@ int pf_maaco_deposit(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d
   CK(hipMemsetAsync(h->d_dep, 0, sizeof(double) * words * 64, h->stream));
   hipLaunchKernelGGL(k_visit_bits, dim3(n), dim3(64), 0, h->stream, n, path_cap, d_cells, d_len, d_plen, h->mp.Q, h->d_bits, h->RC, h->d_dep);
   CK(hipGetLastError());
+  h->dep_words = (int)words; h->dep_done = 0;
+  return 0;
+}
+int pf_maaco_deposit_cells(pf_handle* h, int32_t cell0, int32_t cell1) {
+  if (!h || !h->maaco_ready) return failmsg(h, "pf_maaco_deposit_cells: setup first");
+  if (cell0 < 0 || cell1 > h->RC || cell0 > cell1) return failmsg(h, "pf_maaco_deposit_cells: bad cell range");
+  if (h->dep_words == 0 || cell0 == cell1) return 0;
+  CK(hipSetDevice(h->device));
   CK(hipFuncSetAttribute((const void*)k_tau_deposit, hipFuncAttributeMaxDynamicSharedMemorySize, PF_DEP_CHUNK * (int)sizeof(double)));
-  hipLaunchKernelGGL(k_tau_deposit, dim3((h->RC + 1023) / 1024), dim3(1024), PF_DEP_CHUNK * sizeof(double), h->stream, h->d_tau, h->d_occ, h->RC, h->d_bits, (int)words, h->d_dep);
+  hipLaunchKernelGGL(k_tau_deposit, dim3((cell1 - cell0 + 1023) / 1024), dim3(1024), PF_DEP_CHUNK * sizeof(double), h->stream, h->d_tau, h->d_occ,
+                     h->RC, h->d_bits, h->dep_words, h->d_dep, cell0, cell1);
   CK(hipGetLastError());
+  h->dep_done += cell1 - cell0;
+  if (h->dep_done >= h->RC) h->bits_clean = true;                   // every word has been read and zeroed again
+  return 0;
+}
+int pf_maaco_deposit(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_cells, const int32_t* d_len,
+                     const double* d_plen) {
+  if (pf_maaco_deposit_begin(h, n, path_cap, d_cells, d_len, d_plen)) return -1;
+  return pf_maaco_deposit_cells(h, 0, h->RC);
+}
+// MAACO.py:343-349 over device columns: -> out3 = {best_len, best_turns, best_idx} (one 24-byte D2H)
+int pf_maaco_best_dev(pf_handle* h, int32_t n, const double* d_plen, const int32_t* d_turns, double* out3) {
+  if (!h) return -2;
+  if (n < 0 || !d_plen || !d_turns || !out3) return failmsg(h, "pf_maaco_best_dev: bad arguments");
+  CK(hipSetDevice(h->device));
+  if (!h->d_scan3) CK(hipMalloc(&h->d_scan3, 24));
+  hipLaunchKernelGGL(k_maaco_best, dim3(1), dim3(1024), 0, h->stream, n, d_plen, d_turns, (double*)h->d_scan3);
+  CK(hipGetLastError());
+  CK(hipMemcpyAsync(out3, h->d_scan3, 24, hipMemcpyDeviceToHost, h->stream));
   CK(hipStreamSynchronize(h->stream));
-  h->bits_clean = true;
+  h->d2h_small += 1;
   return 0;
 }
 
@@ -2051,8 +2262,7 @@ int pf_maaco_clip(pf_handle* h, double best_len_overall) {
   const double tmin = tmax / (2.0 * mx);                            // :323
   hipLaunchKernelGGL(k_tau_clip, dim3((h->RC + 255) / 256), dim3(256), 0, h->stream, h->d_tau, h->d_occ, h->RC, tmin, tmax);
   CK(hipGetLastError());
-  CK(hipStreamSynchronize(h->stream));
-  return maaco_refresh_taua(h);
+  return maaco_refresh_taua(h);                                    // (alpha == 1: nothing to do, nothing waits)
 }
 
 int pf_maaco_get_pheromone(pf_handle* h, double* tau) {
@@ -2316,11 +2526,14 @@ static int host_brownian(HostRng& g, int R, int C, int cur, int elite, double sc
 static int mpa_resolve_doubts(pf_handle* h, const MpaPhaseArgs& a) {
   int nd = 0;
   if (d2h_one(h, a.doubt_n, &nd)) return -1;
+  h->d2h_small += 1;
   if (nd <= 0) return 0;
   std::vector<int> list((size_t)nd);
   CK(hipMemcpyAsync(list.data(), a.doubt_list, sizeof(int) * (size_t)nd, hipMemcpyDeviceToHost, h->stream));
   CK(hipStreamSynchronize(h->stream));
   const int R = h->R, C = h->C;
+  int elite_len = a.elite_len;
+  if (a.elite_len_dev && d2h_one(h, a.elite_len_dev, &elite_len)) return -1;
   for (int a_ : list) {
     int gi = 0, slot = a_, preyL = 0;
     if (a.ex_idx) { if (d2h_one(h, a.ex_agent + a_, &gi)) return -1; }
@@ -2331,13 +2544,13 @@ static int mpa_resolve_doubts(pf_handle* h, const MpaPhaseArgs& a) {
     if (a.ex_idx) {
       int lv = 0; double sc = 0.0;
       if (d2h_one(h, a.ex_levy + a_, &lv) || d2h_one(h, a.ex_scale + a_, &sc)) return -1;
-      is_levy = lv != 0; scale = sc; mod = prey; modL = preyL; ref = a.elite_cells; refL = a.elite_len;
-    } else if (a.phase == 1) { is_levy = false; scale = a.m.P; mod = prey; modL = preyL; ref = a.elite_cells; refL = a.elite_len; }
+      is_levy = lv != 0; scale = sc; mod = prey; modL = preyL; ref = a.elite_cells; refL = elite_len;
+    } else if (a.phase == 1) { is_levy = false; scale = a.m.P; mod = prey; modL = preyL; ref = a.elite_cells; refL = elite_len; }
     else if (a.phase == 2) {
       is_levy = gi < a.m.N / 2; scale = is_levy ? a.m.P : a.m.P * a.CF;
-      mod = is_levy ? prey : a.elite_cells; modL = is_levy ? preyL : a.elite_len;
-      ref = is_levy ? a.elite_cells : prey; refL = is_levy ? a.elite_len : preyL;
-    } else { is_levy = true; scale = a.m.P * a.CF; mod = a.elite_cells; modL = a.elite_len; ref = prey; refL = preyL; }
+      mod = is_levy ? prey : a.elite_cells; modL = is_levy ? preyL : elite_len;
+      ref = is_levy ? a.elite_cells : prey; refL = is_levy ? elite_len : preyL;
+    } else { is_levy = true; scale = a.m.P * a.CF; mod = a.elite_cells; modL = elite_len; ref = prey; refL = preyL; }
     HostRng g(a.seed, DOM_MPA, (uint64_t)a.iter, (uint64_t)gi);
     int idx;
     if (a.ex_idx) { if (d2h_one(h, a.ex_idx + a_, &idx)) return -1; }
@@ -2373,7 +2586,7 @@ int pf_mpa_phase_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uin
   if (make_scorep(h, &h->mps, &a.sp)) return -1;
   a.m = mpa_dev(h); a.phase = phase; a.iter = iter; a.CF = CF; a.seed = seed; a.n = n; a.path_cap = path_cap;
   a.pop_cells = d_pop_cells; a.pop_len = d_pop_len; a.pop_stats = d_pop_stats; a.gidx = d_gidx; a.slot = d_slot;
-  a.elite_cells = d_elite_cells; a.elite_len = elite_len;
+  a.elite_cells = d_elite_cells; a.elite_len = elite_len; a.elite_len_dev = nullptr;
   a.elite_stats = d_elite_stats;
   a.out_cells = d_out_cells; a.out_len = d_out_len; a.out_stats = d_out_stats; a.status = d_status;
   a.ex_idx = nullptr; a.ex_levy = nullptr; a.ex_scale = nullptr; a.ex_agent = nullptr;
@@ -2399,7 +2612,7 @@ int pf_mpa_rebuild_batch(pf_handle* h, int32_t iter, uint64_t seed, int32_t n, i
   if (make_scorep(h, &h->mps, &a.sp)) return -1;
   a.m = mpa_dev(h); a.phase = 0; a.iter = iter; a.CF = 0.0; a.seed = seed; a.n = n; a.path_cap = path_cap;
   a.pop_cells = d_pop_cells; a.pop_len = d_pop_len; a.pop_stats = d_pop_stats; a.gidx = nullptr; a.slot = nullptr;
-  a.elite_cells = d_elite_cells; a.elite_len = elite_len; a.elite_stats = d_pop_stats;
+  a.elite_cells = d_elite_cells; a.elite_len = elite_len; a.elite_len_dev = nullptr; a.elite_stats = d_pop_stats;
   a.out_cells = d_out_cells; a.out_len = d_out_len; a.out_stats = d_out_stats; a.status = d_status;
   a.ex_idx = d_idx; a.ex_levy = d_is_levy; a.ex_scale = d_scale; a.ex_agent = d_agent;
   if (mpa_launch_propose(h, a, nullptr) || mpa_resolve_doubts(h, a)) return -1;
@@ -2450,6 +2663,8 @@ int pf_mpa_iter_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uint
   a.ph.m = mpa_dev(h); a.ph.phase = phase; a.ph.iter = iter; a.ph.CF = CF; a.ph.seed = seed; a.ph.n = n; a.ph.path_cap = path_cap;
   a.ph.pop_cells = d_pop_cells; a.ph.pop_len = d_pop_len; a.ph.pop_stats = d_pop_stats; a.ph.gidx = d_gidx; a.ph.slot = d_slot;
   a.ph.elite_cells = d_elite_cells; a.ph.elite_len = elite_len; a.ph.elite_stats = d_elite_stats;
+  a.ph.elite_len_dev = nullptr;
+  if (elite_len < 0) { if (ensure_elite_buf(h)) return -1; a.ph.elite_len_dev = h->d_elite_len; }   // device-resident iteration: the length stays in HBM
   a.ph.out_cells = d_c1_cells; a.ph.out_len = d_c1_len; a.ph.out_stats = d_c1_stats; a.ph.status = d_status;
   a.ph.ex_idx = nullptr; a.ph.ex_levy = nullptr; a.ph.ex_scale = nullptr; a.ph.ex_agent = nullptr;
   a.fd.c = a.ph.c; a.fd.sp = a.ph.sp; a.fd.m = a.ph.m; a.fd.iter = iter; a.fd.CF = CF; a.fd.seed = seed; a.fd.n = n; a.fd.path_cap = path_cap;
@@ -2482,6 +2697,110 @@ int pf_mpa_iter_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uint
   DevCounters dc;
   if (end_batch(h, &dc)) return -1;
   CK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  return 0;
+}
+
+// ---- GA generation on the device ----
+int pf_ga_select_dev(pf_handle* h, uint64_t seed, int32_t gen, int32_t n, int32_t tournament_size, const double* d_fit_all,
+                     const int32_t* d_gorder, int32_t* d_psid) {
+  if (!h) return -2;
+  if (n <= 0 || tournament_size <= 0 || tournament_size > 64 || !d_fit_all || !d_gorder || !d_psid) return failmsg(h, "pf_ga_select_dev: bad arguments (1 <= tournament_size <= 64)");
+  CK(hipSetDevice(h->device));
+  const int k = tournament_size < n ? tournament_size : n;
+  if (n > h->ga_pool_cap) { if (h->d_ga_pool) CK(hipFree(h->d_ga_pool)); CK(hipMalloc(&h->d_ga_pool, sizeof(int) * (size_t)n)); h->ga_pool_cap = n; }
+  hipLaunchKernelGGL(k_ga_select, dim3(1), dim3(1), 0, h->stream, (unsigned long long)seed, gen, n, k, d_fit_all, d_gorder, h->d_ga_pool, d_psid);
+  CK(hipGetLastError());
+  return 0;
+}
+int pf_ga_breed_dev(pf_handle* h, uint64_t seed, int32_t gen, int32_t N, int32_t W, double crossover_rate, double mutation_rate,
+                    const int32_t* d_chrom_all, const int32_t* d_psid, int32_t child0, int32_t nchild, int32_t* d_out) {
+  if (!h) return -2;
+  if (N <= 0 || W <= 0 || !d_chrom_all || !d_psid || !d_out || child0 < 0 || nchild < 0 || child0 + nchild > N) return failmsg(h, "pf_ga_breed_dev: bad arguments");
+  if (nchild == 0) return 0;
+  CK(hipSetDevice(h->device));
+  const int pairs = (child0 + nchild - 1) / 2 - child0 / 2 + 1;
+  hipLaunchKernelGGL(k_ga_breed, dim3((pairs + 63) / 64), dim3(64), 0, h->stream, (unsigned long long)seed, gen, N, W, crossover_rate, mutation_rate,
+                     h->d_occ, h->R, h->C, d_chrom_all, d_psid, child0, nchild, d_out);
+  CK(hipGetLastError());
+  return 0;
+}
+int pf_ga_assemble_dev(pf_handle* h, int32_t n_loc, int32_t W, int32_t path_cap, int32_t lo, const int32_t* d_kid_len,
+                       const int32_t* d_kid_chrom, const double* d_kid_stats, const int32_t* d_kid_cells, const int32_t* d_psid,
+                       const int32_t* d_chrom_old, const double* d_stats_old, const int32_t* d_cells_old, const int32_t* d_len_old,
+                       int32_t old_lo, int32_t old_hi, int32_t* d_chrom_new, double* d_stats_new, int32_t* d_cells_new,
+                       int32_t* d_len_new) {
+  if (!h) return -2;
+  if (n_loc < 0 || W <= 0 || path_cap < 1 || !d_kid_len || !d_kid_chrom || !d_kid_stats || !d_kid_cells || !d_psid || !d_chrom_old ||
+      !d_stats_old || !d_cells_old || !d_len_old || !d_chrom_new || !d_stats_new || !d_cells_new || !d_len_new) return failmsg(h, "pf_ga_assemble_dev: bad arguments");
+  if (n_loc == 0) return 0;
+  CK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(k_ga_assemble, dim3(n_loc), dim3(64), 0, h->stream, n_loc, W, path_cap, lo, d_kid_len, d_kid_chrom, d_kid_stats, d_kid_cells,
+                     d_psid, d_chrom_old, d_stats_old, d_cells_old, d_len_old, old_lo, old_hi, d_chrom_new, d_stats_new, d_cells_new, d_len_new);
+  CK(hipGetLastError());
+  return 0;
+}
+
+// ---- device-resident iteration control -------------------------------------------------------------------------
+int pf_sort_order_by_key(pf_handle* h, int32_t n, const double* d_vals, int32_t stride, int32_t offset, int32_t* d_order) {
+  if (!h) return -2;
+  if (n < 0 || !d_vals || !d_order || stride < 1 || offset < 0 || offset >= stride) return failmsg(h, "pf_sort_order_by_key: bad arguments");
+  if (n <= 1) return 0;
+  CK(hipSetDevice(h->device));
+  if (n > h->okey_cap) {
+    for (void* q : {(void*)h->d_okey, (void*)h->d_okey2, (void*)h->d_oval2}) if (q) CK(hipFree(q));
+    CK(hipMalloc(&h->d_okey, sizeof(double) * (size_t)n)); CK(hipMalloc(&h->d_okey2, sizeof(double) * (size_t)n));
+    CK(hipMalloc(&h->d_oval2, sizeof(int) * (size_t)n));
+    h->okey_cap = n;
+  }
+  hipLaunchKernelGGL(k_sort_keys, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, d_vals, stride, offset, d_order, h->d_okey);
+  CK(hipGetLastError());
+  size_t need = 0;
+  CK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, h->d_okey, h->d_okey2, d_order, h->d_oval2, n, 0, 64, h->stream));
+  if (need > h->sort_tmp_bytes) {
+    if (h->d_sort_tmp) CK(hipFree(h->d_sort_tmp));
+    CK(hipMalloc(&h->d_sort_tmp, need)); h->sort_tmp_bytes = need;
+  }
+  // radix sort: stable, and doubles order as list.sort(key=...) orders them (inf last; the fitness is never NaN)
+  CK(hipcub::DeviceRadixSort::SortPairs(h->d_sort_tmp, need, h->d_okey, h->d_okey2, d_order, h->d_oval2, n, 0, 64, h->stream));
+  CK(hipMemcpyAsync(d_order, h->d_oval2, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, h->stream));
+  return 0;
+}
+int pf_gather_col(pf_handle* h, int32_t n, const double* d_src, int32_t stride, int32_t offset, double* d_dst) {
+  if (!h) return -2;
+  if (n < 0 || !d_src || !d_dst || stride < 1 || offset < 0 || offset >= stride) return failmsg(h, "pf_gather_col: bad arguments");
+  if (n == 0) return 0;
+  CK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(k_gather_col, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, d_src, stride, offset, d_dst);
+  CK(hipGetLastError());
+  return 0;
+}
+int pf_mpa_elite_buf(pf_handle* h, void** d_cells, void** d_len, void** d_stats) {
+  if (!h) return -2;
+  CK(hipSetDevice(h->device));
+  if (ensure_elite_buf(h)) return -1;
+  if (d_cells) *d_cells = h->d_elite_cells;
+  if (d_len) *d_len = h->d_elite_len;
+  if (d_stats) *d_stats = h->d_elite_stats;
+  return 0;
+}
+int pf_mpa_pick_elite(pf_handle* h, int32_t path_cap, const int32_t* d_pop_cells, const int32_t* d_pop_len,
+                      const double* d_pop_stats, const int32_t* d_order, int32_t first_id) {
+  if (!h) return -2;
+  if (path_cap < 1 || !d_pop_cells || !d_pop_len || !d_pop_stats || !d_order) return failmsg(h, "pf_mpa_pick_elite: bad arguments");
+  CK(hipSetDevice(h->device));
+  if (ensure_elite_buf(h)) return -1;
+  hipLaunchKernelGGL(k_mpa_pick_elite, dim3(1), dim3(256), 0, h->stream, path_cap, d_pop_cells, d_pop_len, d_pop_stats, d_order, first_id,
+                     h->d_elite_cells, h->d_elite_len, h->d_elite_stats);
+  CK(hipGetLastError());
+  return 0;
+}
+int pf_mpa_local_view(pf_handle* h, int32_t N, const int32_t* d_gorder, int32_t lo, int32_t hi, int32_t* d_gidx, int32_t* d_slot) {
+  if (!h) return -2;
+  if (N < 0 || !d_gorder || !d_gidx || !d_slot || lo < 0 || hi < lo) return failmsg(h, "pf_mpa_local_view: bad arguments");
+  if (N == 0) return 0;
+  CK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(k_mpa_local_view, dim3(1), dim3(1024), 0, h->stream, N, d_gorder, lo, hi, d_gidx, d_slot);
+  CK(hipGetLastError());
   return 0;
 }
 

@@ -84,6 +84,28 @@ SYMBOLS = {
     "pf_set_option": (C.c_int, [_vp, C.c_char_p, _i64]),
     "pf_selftest_sqrt": (C.c_int, [_vp, _i32, _vp, _vp]),
     "pf_selftest_rng": (C.c_int, [_vp, _u64, _u64, _u64, _u64, _vp, _vp, _vp]),
+    "pf_ga_select_dev": (C.c_int, [_vp, _u64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "pf_ga_breed_dev": (C.c_int, [_vp, _u64, _i32, _i32, _i32, _dbl, _dbl, _vp, _vp, _i32, _i32, _vp]),
+    "pf_ga_assemble_dev": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "pf_sort_order_by_key": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp]),
+    "pf_gather_col": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp]),
+    "pf_mpa_elite_buf": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "pf_mpa_pick_elite": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _i32]),
+    "pf_mpa_local_view": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp]),
+    "pf_maaco_deposit_begin": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
+    "pf_maaco_deposit_cells": (C.c_int, [_vp, _i32, _i32]),
+    "pf_maaco_best_dev": (C.c_int, [_vp, _i32, _vp, _vp, _vp]),
+    "pf_comm_unique_id": (C.c_int, [_vp]),
+    "pf_comm_init": (C.c_int, [_vp, _i32, _i32, _vp]),
+    "pf_comm_destroy": (C.c_int, [_vp]),
+    "pf_comm_rank": (C.c_int, [_vp]),
+    "pf_comm_world": (C.c_int, [_vp]),
+    "pf_comm_all_gather": (C.c_int, [_vp, _vp, _vp, _i64]),
+    "pf_comm_broadcast": (C.c_int, [_vp, _vp, _i64, _i32]),
+    "pf_comm_all_reduce_f64": (C.c_int, [_vp, _vp, _i64, _i32]),
+    "pf_comm_send": (C.c_int, [_vp, _vp, _i64, _i32]),
+    "pf_comm_recv": (C.c_int, [_vp, _vp, _i64, _i32]),
+    "pf_comm_sendrecv": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i64, _i32]),
     "pf_pso_pbest_paths": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "pf_pso_scan": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _dbl, _i32, C.POINTER(_i32), C.POINTER(_dbl), C.POINTER(_i32)]),
     "pf_d2h_counts": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),

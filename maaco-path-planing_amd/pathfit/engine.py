@@ -47,6 +47,24 @@ class DevBuf:
     def at(self, elem_offset):
         return self.ptr + int(elem_offset) * self.dtype.itemsize
 
+    def read(self, elem_offset, count):
+        """Host copy of `count` elements from `elem_offset` (row reads on demand)."""
+        out = np.empty(int(count), self.dtype)
+        if out.nbytes:
+            self.eng._ck(self.eng.L.pf_d2h(self.eng.h, out.ctypes.data, self.at(elem_offset), out.nbytes))
+        return out
+
+    def write(self, elem_offset, arr):
+        a = np.ascontiguousarray(arr, self.dtype)
+        if a.nbytes:
+            self.eng._ck(self.eng.L.pf_h2d(self.eng.h, self.at(elem_offset), a.ctypes.data, a.nbytes))
+        return self
+
+    def copy_from(self, elem_offset, src, src_offset, count):
+        """Device-to-device copy of `count` elements."""
+        self.eng.d2d(self.at(elem_offset), src.at(src_offset), int(count) * self.dtype.itemsize)
+        return self
+
     def free(self):
         if self.ptr and getattr(self.eng, "h", None):   # the handle may already be closed
             self.eng.L.pf_dev_free(self.eng.h, self.ptr)
@@ -57,6 +75,18 @@ class DevBuf:
             self.free()
         except Exception:
             pass
+
+
+class _View(DevBuf):
+    """A DevBuf over memory the library owns (never freed here)."""
+
+    def __init__(self, eng, ptr, count, dtype):
+        self.eng, self.ptr = eng, ptr
+        self.shape, self.dtype = (int(count),), np.dtype(dtype)
+        self.nbytes = int(count) * self.dtype.itemsize
+
+    def free(self):
+        self.ptr = 0
 
 
 def score_params(variant=0, restrict_policy=True, w_turn=0.1, w_safe=0.05, min_safe=1.5, diag_pen=1000.0):
@@ -259,6 +289,23 @@ class Engine:
     def maaco_deposit(self, n, path_cap, d_cells, d_len, d_plen):
         self._ck(self.L.pf_maaco_deposit(self.h, n, path_cap, d_cells.ptr, d_len.ptr, d_plen.ptr))
 
+    def maaco_deposit_begin(self, n, path_cap, d_cells, d_len, d_plen):
+        self._ck(self.L.pf_maaco_deposit_begin(self.h, n, path_cap, d_cells.ptr, d_len.ptr, d_plen.ptr))
+
+    def maaco_deposit_cells(self, cell0, cell1):
+        self._ck(self.L.pf_maaco_deposit_cells(self.h, int(cell0), int(cell1)))
+
+    def maaco_best_dev(self, n, d_plen, d_turns):
+        """MAACO.py:343-349 over device columns -> (best_len, best_turns, best_idx); one 24-byte D2H."""
+        out = np.zeros(3)
+        self._ck(self.L.pf_maaco_best_dev(self.h, int(n), d_plen.ptr, d_turns.ptr, out.ctypes.data))
+        return float(out[0]), float(out[1]), int(out[2])
+
+    @property
+    def tau_buf(self):
+        """The pheromone matrix in HBM as a buffer object (R*C doubles, owned by the library)."""
+        return _View(self, self.L.pf_maaco_tau_dev(self.h), self.R * self.C, np.float64)
+
     def maaco_clip(self, best_len_overall):
         self._ck(self.L.pf_maaco_clip(self.h, float(best_len_overall)))
 
@@ -303,6 +350,38 @@ class Engine:
                                           d_c1_len.ptr, d_c1_stats.ptr, d_c2_cells.ptr, d_c2_len.ptr, d_c2_stats.ptr,
                                           d_status.ptr))
         self._logk("mpa_sweep")
+
+    # ------------------------------------------------------------------ GA generation in HBM
+    def ga_select(self, seed, gen, n, k, d_fit_all, d_gorder, d_psid):
+        self._ck(self.L.pf_ga_select_dev(self.h, int(seed), int(gen), int(n), int(k), d_fit_all.ptr, d_gorder.ptr, d_psid.ptr))
+
+    def ga_breed(self, seed, gen, N, W, cx, mut, d_chrom_all, d_psid, child0, nchild, d_out):
+        self._ck(self.L.pf_ga_breed_dev(self.h, int(seed), int(gen), int(N), int(W), float(cx), float(mut), d_chrom_all.ptr, d_psid.ptr,
+                                        int(child0), int(nchild), d_out.ptr))
+
+    def ga_assemble(self, n_loc, W, cap, lo, kid_len, kid_chrom, kid_stats, kid_cells, psid, chrom_old, stats_old, cells_old, len_old,
+                    old_lo, old_hi, chrom_new, stats_new, cells_new, len_new):
+        self._ck(self.L.pf_ga_assemble_dev(self.h, int(n_loc), int(W), int(cap), int(lo), kid_len.ptr, kid_chrom.ptr, kid_stats.ptr,
+                                           kid_cells.ptr, psid.ptr, chrom_old.ptr, stats_old.ptr, cells_old.ptr, len_old.ptr,
+                                           int(old_lo), int(old_hi), chrom_new.ptr, stats_new.ptr, cells_new.ptr, len_new.ptr))
+
+    def sort_order_by_key(self, n, d_vals, stride, offset, d_order):
+        self._ck(self.L.pf_sort_order_by_key(self.h, int(n), d_vals.ptr, int(stride), int(offset), d_order.ptr))
+
+    def gather_col(self, n, d_src, stride, offset, d_dst):
+        self._ck(self.L.pf_gather_col(self.h, int(n), d_src.ptr, int(stride), int(offset), d_dst.ptr))
+
+    def mpa_elite_bufs(self):
+        """(cells, len, stats) views of the library's elite buffer."""
+        c, l, s_ = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._ck(self.L.pf_mpa_elite_buf(self.h, C.byref(c), C.byref(l), C.byref(s_)))
+        return (_View(self, c.value, self.R * self.C, np.int32), _View(self, l.value, 1, np.int32), _View(self, s_.value, 5, np.float64))
+
+    def mpa_pick_elite(self, path_cap, d_pop_cells, d_pop_len, d_pop_stats, d_order, first_id=0):
+        self._ck(self.L.pf_mpa_pick_elite(self.h, int(path_cap), d_pop_cells.ptr, d_pop_len.ptr, d_pop_stats.ptr, d_order.ptr, int(first_id)))
+
+    def mpa_local_view(self, N, d_gorder, lo, hi, d_gidx, d_slot):
+        self._ck(self.L.pf_mpa_local_view(self.h, int(N), d_gorder.ptr, int(lo), int(hi), d_gidx.ptr, d_slot.ptr))
 
     def mpa_fads(self, CF, it, seed, n, path_cap, d_gidx, d_slot, d_pop_cells, d_pop_len, d_pop_stats, d_status):
         self._ck(self.L.pf_mpa_fads_batch(self.h, float(CF), int(it), int(seed), n, path_cap, d_gidx.ptr, d_slot.ptr,

@@ -70,26 +70,32 @@ class MAACO:
                           e.buf(n, np.float64), e.buf(n, np.int32), e.buf(n, np.int32))
         return self._bufs[1:]
 
-    def walk_iteration(self, iter_num, ant0=0, n=None):
-        """Walk ants [ant0, ant0+n) of iteration iter_num; results stay on the device.
-        -> (plen[n], turns[n]) host arrays (turns -1 for a failed ant)."""
+    def walk_iteration_dev(self, iter_num, ant0=0, n=None):
+        """Walk ants [ant0, ant0+n) of iteration iter_num; everything stays in HBM (paths, lengths, turns, status:
+        self.walk_bufs()).  The only device-to-host traffic is the overflow counter the walk batch already returns."""
         n = self.num_ants if n is None else n
         while True:
             dc, dl, dp, dt, ds = self._alloc(n)
             self.engine.maaco_walk(iter_num, self.seed, ant0, n, self.path_cap, dc, dl, dp, dt, ds)
-            st = ds.download()
-            if (st == 3).any() and self.path_cap < self.rows * self.cols:
+            if self.engine.counters()["overflow_agents"] and self.path_cap < self.rows * self.cols:
                 self.path_cap = min(self.rows * self.cols, self.path_cap * 4)     # path buffer too small: redo
                 continue
             break
-        return dp.download(), dt.download()
+        return n
+
+    def walk_bufs(self):
+        """(cells [n][cap], len [n], plen [n], turns [n], status [n]) device buffers of the last walk."""
+        return self._bufs[1:]
+
+    def walk_iteration(self, iter_num, ant0=0, n=None):
+        """walk_iteration_dev + host copies of the (plen[n], turns[n]) columns (turns -1 for a failed ant)."""
+        self.walk_iteration_dev(iter_num, ant0, n)
+        return self._bufs[3].download(), self._bufs[4].download()
 
     def ant_path(self, local_idx):
         dc, dl = self._bufs[1], self._bufs[2]
-        L = int(dl.download()[local_idx])
-        row = np.empty(self.path_cap, np.int32)
-        self.engine._ck(self.engine.L.pf_d2h(self.engine.h, row.ctypes.data, dc.at(local_idx * self.path_cap), row.nbytes))
-        return CellPath(row[:L].copy(), self.cols)
+        L = int(dl.read(local_idx, 1)[0])
+        return CellPath(dc.read(local_idx * self.path_cap, L), self.cols)
 
     def _construct_ant_solution_maaco(self, ant_id, current_iteration_num):
         """MAACO.py:278-302 for one ant -> (path, length, turns)."""
@@ -109,9 +115,9 @@ class MAACO:
 
     def solve_path_planning(self):
         for iter_num in range(1, self.num_iterations + 1):
-            plen, turns = self.walk_iteration(iter_num)
-            # MAACO.py:343-349 sequential best-of-iteration scan
-            ib_len, ib_turns, ib_idx = self.engine.maaco_best_scan(plen, turns, 0, INF, INF, -1)
+            n = self.walk_iteration_dev(iter_num)
+            # MAACO.py:343-349 best-of-iteration scan, on the device columns (24 bytes come back)
+            ib_len, ib_turns, ib_idx = self.engine.maaco_best_dev(n, self._bufs[3], self._bufs[4])
             if ib_len < self.best_path_length_overall:                                   # :351-354
                 self.best_path_length_overall = ib_len
                 self.best_path_overall = self.ant_path(ib_idx).tolist()

@@ -1,10 +1,13 @@
 """MPA with the reference's constructor / solve_path_planning() surface
-(MPA.py:10-18, :320-448).  The population lives in HBM as strided paths; the
-phase sweep (:339-377: target-cell proposal, two A* stitches, scoring), the
+(MPA.py:10-18, :320-448).  The population lives in HBM as strided paths and an
+iteration never leaves it: the stable sort by fitness (:333,:412) is a device
+radix sort of the list order, the elite (:334) is copied into a device buffer,
+the phase sweep (:339-377: target-cell proposal, two A* stitches, scoring), the
 memory step (:381-384) and the FADs sweep (:387-410) are device batches.  The
-host keeps what the reference keeps sequential and tiny: the stable sort by
-fitness (:333,:412), the elite choice (:334), CF (:336) and the 4-level
-best-so-far tie-break (:415-437).
+host keeps the scalars: CF (:336) and the 4-level best-so-far tie-break
+(:415-437) on the 5 stats of the iteration's best predator; its path is read
+only when the best improves.  Device-to-host traffic per iteration: the doubt
+count of the proposals (4 B), the work counters (72 B), the best row (44 B).
 
 Per-predator streams: (seed, DOM_MPA, iter, i) for the phase sweep and
 (seed, DOM_MPA_FADS, iter, i) for FADs, with i the predator's index in the
@@ -92,10 +95,18 @@ class MPA:
         self.d_cand_cells, self.d_cand_len = e.buf((N, cap), np.int32), e.buf(N, np.int32)
         self.d_cand_stats, self.d_status = e.buf((N, 5), np.float64), e.buf(N, np.int32)
         self.d_c2_cells, self.d_c2_len, self.d_c2_stats = e.buf((N, cap), np.int32), e.buf(N, np.int32), e.buf((N, 5), np.float64)
-        self.order = np.arange(N, dtype=np.int32)                        # sorted position -> storage slot
-        self.d_order = e.put(self.order)
+        self.d_order = e.put(np.arange(N, dtype=np.int32))               # the list: sorted position -> storage slot
         self.d_gidx = e.put(np.arange(N, dtype=np.int32))                # single GPU: every predator is local
-        self._stats_host = np.tile(stats, (N, 1))
+        self._el_cells, self._el_len, self._el_stats = e.mpa_elite_bufs()
+
+    @property
+    def order(self):
+        """sorted position -> storage slot (host copy on demand)."""
+        return self.d_order.download()
+
+    @property
+    def _stats_host(self):
+        return self.d_stats.download()
 
     @property
     def population(self):
@@ -110,16 +121,17 @@ class MPA:
         return out
 
     def _path_of_slot(self, slot):
-        L = int(self.d_len.download()[slot])
-        row = np.empty(self.path_cap, np.int32)
-        self.engine._ck(self.engine.L.pf_d2h(self.engine.h, row.ctypes.data, self.d_cells.at(slot * self.path_cap), row.nbytes))
-        return row[:L].copy()
+        L = int(self.d_len.read(slot, 1)[0])
+        return self.d_cells.read(slot * self.path_cap, L)
 
     def _sort(self):
-        """list.sort(key=fitness) is stable (MPA.py:321,:333,:412)."""
-        fit = self._stats_host[self.order, 4]
-        self.order = self.order[np.argsort(fit, kind="stable")].astype(np.int32)
-        self.d_order.upload(self.order)
+        """list.sort(key=fitness) is stable (MPA.py:321,:333,:412): device radix sort of the list order."""
+        self.engine.sort_order_by_key(self.n_local, self.d_stats, 5, 4, self.d_order)
+
+    def _best_row(self):
+        """(storage slot, stats[5]) of population[0] -- two small reads."""
+        slot = int(self.d_order.read(0, 1)[0])
+        return slot, self.d_stats.read(slot * 5, 5)
 
     def _update_best(self, s, slot):
         self.best_fitness_overall = float(s[4])
@@ -133,18 +145,18 @@ class MPA:
         """One iteration of MPA.py:332-440 (it is 1-based)."""
         e, N, cap = self.engine, self.n_local, self.path_cap
         self._sort()                                                     # :333
-        elite_slot = int(self.order[0])                                  # :334
-        elite_len = int(self.d_len.download()[elite_slot])
+        e.mpa_pick_elite(cap, self.d_cells, self.d_len, self.d_stats, self.d_order)   # :334 elite = population[0].copy()
         ratio = it / self.num_iterations
         CF = 0.0 if ratio >= 1.0 else ((1.0 - ratio) ** (2.0 * ratio) if ratio > 0 else 1.0)   # :336
         phase = 1 if it <= self.num_iterations / 3 else (2 if it <= 2 * self.num_iterations / 3 else 3)
-        el_c, el_s = self.d_cells.at(elite_slot * cap), self.d_stats.at(elite_slot * 5)
+        el_c, el_s = self._el_cells.ptr, self._el_stats.ptr
         if self.fused:
             e.mpa_iter(phase, CF, it, self.seed, N, cap, self.d_cells, self.d_len, self.d_stats, self.d_gidx, self.d_order,
-                       el_c, elite_len, el_s, self.d_cand_cells, self.d_cand_len, self.d_cand_stats,
+                       el_c, -1, el_s, self.d_cand_cells, self.d_cand_len, self.d_cand_stats,
                        self.d_c2_cells, self.d_c2_len, self.d_c2_stats, self.d_status)     # :339-410 in one queue
             self._check_overflow()
         else:
+            elite_len = int(self._el_len.read(0, 1)[0])
             e.mpa_phase(phase, CF, it, self.seed, N, cap, self.d_cells, self.d_len, self.d_stats, self.d_gidx, self.d_order,
                         el_c, elite_len, el_s, self.d_cand_cells, self.d_cand_len, self.d_cand_stats, self.d_status)
             self._check_overflow()
@@ -152,10 +164,8 @@ class MPA:
                          self.d_cells, self.d_len, self.d_stats)            # :381-384
             e.mpa_fads(CF, it, self.seed, N, cap, self.d_gidx, self.d_order, self.d_cells, self.d_len, self.d_stats, self.d_status)   # :387-410
             self._check_overflow()
-        self._stats_host = self.d_stats.download()
         self._sort()                                                     # :412
-        slot = int(self.order[0])
-        s = self._stats_host[slot]
+        slot, s = self._best_row()
         # :415-437 best-so-far with the 4-level tie-break
         if s[4] < self.best_fitness_overall:
             self._update_best(s, slot)
@@ -176,15 +186,14 @@ class MPA:
         return s
 
     def _check_overflow(self):
-        st = self.d_status.download()
-        if (st == 3).any() or self.engine.counters()["overflow_agents"]:
-            raise RuntimeError("pathfit: scratch/path capacity overflow on %d predators (path_cap=%d)" %
-                               (int((st == 3).sum()), self.path_cap))
+        n = self.engine.counters()["overflow_agents"]      # counted on the device: no status column leaves HBM
+        if n:
+            raise RuntimeError("pathfit: scratch/path capacity overflow on %d predators (path_cap=%d)" % (n, self.path_cap))
 
     def solve_path_planning(self):
         self._sort()                                                     # :321
-        slot = int(self.order[0])
-        self._update_best(self._stats_host[slot], slot)                  # :322-329
+        slot, s0 = self._best_row()
+        self._update_best(s0, slot)                                      # :322-329
         self.convergence_curve_data.append(self.best_fitness_overall if self.best_fitness_overall != INF else None)
         for it in range(1, self.num_iterations + 1):
             s = self.step(it)

@@ -190,7 +190,7 @@ class GASolver(_WaypointSolver):
     def __init__(self, grid, num_generations, population_size, num_waypoints_per_chromosome, mutation_rate,
                  crossover_rate, tournament_size=3, turn_penalty_factor=0.1, safety_penalty_factor=0.05,
                  min_safe_distance=1.5, allow_diagonal_moves=True, restrict_diagonal_near_obstacle_policy=True,
-                 diagonal_obstacle_penalty_value=1000.0, engine=None, device=0, seed=0, verbose=False):
+                 diagonal_obstacle_penalty_value=1000.0, engine=None, device=0, seed=0, verbose=False, comm=None):
         g = np.asarray(grid)
         start_node = find_marker(g, START_NODE_VAL, "GA")
         target_node = find_marker(g, TARGET_NODE_VAL, "GA")
@@ -206,11 +206,148 @@ class GASolver(_WaypointSolver):
         # the connector obeys GA's diagonal policy (ga_solver.py:38-44); its weights are irrelevant when stitching
         self.path_connector = AStarSolver(self.grid, 0, 0, 0, allow_diagonal_moves,
                                           restrict_diagonal_near_obstacle_policy, 0, engine=self.engine)
+        self._gd = None
         self.population = []
         self.best_solution_overall = {"fitness": INF, "path": []}
         self.verbose = verbose
         self._free = self.grid != 1
-        self.native_operators = True      # selection / crossover / mutation through pf_ga_select / pf_ga_breed
+        self.native_operators = True      # selection / crossover / mutation in native code (device kernels / host C), not Python
+        self.device_loop = True           # the whole generation in HBM (select, breed, decode, assemble, sort): SURVEY.md 8 f1/f2
+        self.comm = comm                  # pathfit.dist.Comm: individuals sharded over ranks by child index (None: one GPU)
+
+    # `population` is the reference's public list of dicts (ga_solver.py:33); while the device loop runs it lives in HBM
+    # and is materialised only when somebody reads it
+    @property
+    def population(self):
+        gd = getattr(self, "_gd", None)
+        if gd is not None and gd.get("stale"):
+            self._population = self._materialize_population()
+            gd["stale"] = False
+        return self._population
+
+    @population.setter
+    def population(self, v):
+        self._population = v
+        if getattr(self, "_gd", None) is not None:
+            self._gd["stale"] = False
+
+    def _decode_rows(self, chroms):
+        """paths of chromosomes whose row is not stored on this rank: a path is decode(chromosome) (deterministic)."""
+        if len(chroms) == 0:
+            return []
+        cps, _, _ = self._evaluate(wp_cells=np.ascontiguousarray(chroms, np.int32))
+        return cps
+
+    def _materialize_population(self):
+        d, N, W, cap = self._gd, self.population_size, self.num_waypoints, self._gd["cap"]
+        chrom = d["chrom_all"].download().reshape(N, W)
+        stats = d["stats_all"].download().reshape(N, 5)
+        gorder = d["gorder"].download()
+        lo, hi, cur = d["lo"], d["hi"], d["cur"]
+        cells = d["cells"][cur].download().reshape(-1, cap)
+        lens = d["len"][cur].download()
+        paths = {}
+        missing = []
+        for sid in gorder:
+            sid = int(sid)
+            if lo <= sid < hi and lens[sid - lo] >= 0:
+                paths[sid] = CellPath(cells[sid - lo, :lens[sid - lo]].copy(), self.cols)
+            else:
+                missing.append(sid)
+        for sid, cp in zip(missing, self._decode_rows(chrom[missing]) if missing else []):
+            paths[sid] = cp
+        C_ = self.cols
+        out = []
+        for sid in gorder:
+            sid = int(sid)
+            s = stats[sid]
+            out.append({"chromosome": [(int(c) // C_, int(c) % C_) for c in chrom[sid]], "path": paths[sid], "fitness": float(s[4]),
+                        "length": float(s[0]), "turns": int(s[1]), "safety_penalty": float(s[2]), "diag_penalty": float(s[3]),
+                        "_cells": chrom[sid].copy()})
+        return out
+
+    def _solve_device(self):
+        """ga_solver.py:178-213 with the population in HBM: selection, crossover + mutation, decode + stitch + score,
+        the child-or-parent assembly and the stable sort are device work; per generation the host reads back the work
+        counters, the head of the sorted list (4 B) and its 5 stats (40 B).  Sharded: individuals are owned by child
+        index; C3 = all_gather of the new chromosomes and stats (N x (4 W + 40) B)."""
+        from .dist import shard_range
+        e, N, W, c = self.engine, self.population_size, self.num_waypoints, self.comm
+        world, rank = (c.world, c.rank) if c is not None else (1, 0)
+        if c is not None and c.transport == "rccl" and c.engine is None:
+            c.attach(e)
+        lo, hi = shard_range(N, rank, world)
+        n = hi - lo
+        m = max(n, 1)
+        cap = self._path_cap()
+        pop = self._population
+        chrom = np.stack([self._chrom_cells(x) for x in pop]).astype(np.int32)
+        stats = np.array([[x["length"], x["turns"], x["safety_penalty"], x["diag_penalty"], x["fitness"]] for x in pop], np.float64)
+        d = {"cap": cap, "lo": lo, "hi": hi, "cur": 0, "stale": False}
+        d["chrom_all"], d["stats_all"], d["fit_all"] = e.put(chrom), e.put(stats), e.put(stats[:, 4].copy())
+        d["iota"] = e.put(np.arange(N, dtype=np.int32))
+        d["gorder"], d["psid"] = e.put(np.arange(N, dtype=np.int32)), e.buf(N, np.int32)
+        d["kid_chrom"], d["kid_cells"] = e.buf((m, W), np.int32), e.buf((m, cap), np.int32)
+        d["kid_len"], d["kid_st"], d["kid_stats"] = e.buf(m, np.int32), e.buf(m, np.int32), e.buf((m, 5), np.float64)
+        d["cells"] = [e.buf((m, cap), np.int32), e.buf((m, cap), np.int32)]
+        d["len"] = [e.buf(m, np.int32), e.buf(m, np.int32)]
+        d["chrom_loc"], d["stats_loc"] = e.buf((m, W), np.int32), e.buf((m, 5), np.float64)
+        cur_cells = np.zeros((m, cap), np.int32); cur_len = np.zeros(m, np.int32)
+        for i in range(n):
+            cc = cells_of(pop[lo + i]["path"], self.cols)
+            if len(cc) > cap:
+                raise RuntimeError("pathfit: path capacity overflow in GA initialisation")
+            cur_cells[i, :len(cc)] = cc; cur_len[i] = len(cc)
+        d["cells"][0].upload(cur_cells); d["len"][0].upload(cur_len)
+        self._gd = d
+        s_cell, t_cell = self._cell(self.start_node), self._cell(self.target_node)
+        counts = [shard_range(N, r, world)[1] - shard_range(N, r, world)[0] for r in range(world)]
+        best_fit = self.best_solution_overall["fitness"]
+        best = None                                   # (storage id, chromosome cells, stats) of an improvement made in the loop
+        for gen in range(self.num_generations):
+            cur = d["cur"]
+            e.ga_select(self.seed, gen, N, self.tournament_size, d["fit_all"], d["gorder"], d["psid"])            # :181
+            e.ga_breed(self.seed, gen, N, W, self.crossover_rate, self.mutation_rate, d["chrom_all"], d["psid"], lo, n, d["kid_chrom"])   # :186-194
+            if n:                                                                                               # :198-200 the hot path
+                e.decode_batch(n, W, s_cell, t_cell, cap, d["kid_cells"], d["kid_len"], d["kid_st"], d["kid_chrom"], None, self._sp,
+                               d["kid_stats"], self.allow_diagonal_moves, self.restrict_diagonal_near_obstacle_policy)
+                if e.counters()["overflow_agents"]:
+                    raise RuntimeError("pathfit: scratch/path capacity overflow in GA decode")
+            e.ga_assemble(n, W, cap, lo, d["kid_len"], d["kid_chrom"], d["kid_stats"], d["kid_cells"], d["psid"], d["chrom_all"],
+                          d["stats_all"], d["cells"][cur], d["len"][cur], lo, hi, d["chrom_loc"], d["stats_loc"], d["cells"][1 - cur],
+                          d["len"][1 - cur])                                                                    # :201-205
+            d["cur"] = 1 - cur
+            if c is not None:
+                c.all_gather(d["chrom_loc"], 0, d["chrom_all"], counts, W)                                      # C3
+                c.all_gather(d["stats_loc"], 0, d["stats_all"], counts, 5)
+            else:
+                d["chrom_all"].copy_from(0, d["chrom_loc"], 0, N * W)
+                d["stats_all"].copy_from(0, d["stats_loc"], 0, N * 5)
+            e.gather_col(N, d["stats_all"], 5, 4, d["fit_all"])
+            d["gorder"].copy_from(0, d["iota"], 0, N)
+            e.sort_order_by_key(N, d["fit_all"], 1, 0, d["gorder"])                                             # :209 stable sort
+            d["stale"] = True
+            gid = int(d["gorder"].read(0, 1)[0])
+            s5 = d["stats_all"].read(gid * 5, 5)
+            if s5[4] < best_fit:                                                                                # :212-213
+                best_fit = float(s5[4])
+                best = (gid, d["chrom_all"].read(gid * W, W), s5)
+                own = lo <= gid < hi
+                L = int(d["len"][d["cur"]].read(gid - lo, 1)[0]) if own else -1
+                self._best_row = d["cells"][d["cur"]].read((gid - lo) * cap, L) if L >= 0 else None
+            self.convergence_curve.append(best_fit)
+            if self.verbose and ((gen + 1) % 10 == 0 or gen == 0 or gen == self.num_generations - 1):
+                print(f"GA Gen {gen + 1}/{self.num_generations}: BestFit={best_fit:.2f}")
+        if best is not None:
+            gid, ch, s5 = best
+            row = self._best_row if self._best_row is not None else self._decode_rows(ch[None, :])[0].cells
+            C_ = self.cols
+            self.best_solution_overall = {"chromosome": [(int(x) // C_, int(x) % C_) for x in ch], "path": CellPath(row, self.cols),
+                                          "fitness": float(s5[4]), "length": float(s5[0]), "turns": int(s5[1]),
+                                          "safety_penalty": float(s5[2]), "diag_penalty": float(s5[3]), "_cells": ch}
+        res = self.best_solution_overall
+        path = res["path"].tolist() if isinstance(res["path"], CellPath) else res["path"]
+        return (path, res["length"], res["turns"], res["safety_penalty"], res["diag_penalty"], res["fitness"])
 
     # ---- host-side genetic operators (ga_solver.py:48-56,136-160), per-agent streams ----
     def _generate_random_waypoint(self, r):
@@ -316,6 +453,9 @@ class GASolver(_WaypointSolver):
         self.convergence_curve.append(self.best_solution_overall["fitness"])
         N = self.population_size
         Wn = self.num_waypoints
+        if self.native_operators and self.device_loop and len(self.population) == N and \
+                all(len(x["chromosome"]) == Wn for x in self.population) and hasattr(self.engine, "ga_select"):
+            return self._solve_device()
         for gen in range(self.num_generations):
             kid_cells = None
             if self.native_operators and len(self.population) == N and all(len(x["chromosome"]) == Wn for x in self.population):
@@ -384,7 +524,7 @@ class PSOSolver(_WaypointSolver):
     def __init__(self, grid, num_iterations, num_particles, num_waypoints_per_particle, w, c1, c2,
                  turn_penalty_factor=0.1, safety_penalty_factor=0.05, min_safe_distance=1.5, allow_diagonal_moves=True,
                  restrict_diagonal_near_obstacle_policy=True, diagonal_obstacle_penalty_value=1000.0, engine=None,
-                 device=0, seed=0, verbose=False, asynchronous=True):
+                 device=0, seed=0, verbose=False, asynchronous=True, comm=None):
         g = np.asarray(grid)
         start_node = find_marker(g, START_NODE_VAL, "PSO")
         target_node = find_marker(g, TARGET_NODE_VAL, "PSO")
@@ -399,6 +539,8 @@ class PSOSolver(_WaypointSolver):
         self.path_connector = AStarSolver(self.grid, 0, 0, 0, allow_diagonal_moves,
                                           restrict_diagonal_near_obstacle_policy, 0, engine=self.engine)
         self._d, self._gbest_dev, self._particles_stale = None, None, False
+        self.comm = comm                  # pathfit.dist.Comm: particles sharded over ranks in contiguous blocks (None: one GPU)
+        self._lo, self._hi = 0, num_particles
         self.particles = []
         self.gbest_particle_data = {"fitness": INF, "path": [], "position": []}
         self.verbose = verbose
@@ -464,8 +606,15 @@ class PSOSolver(_WaypointSolver):
     def gbest_particle_data(self):
         if getattr(self, "_gbest_dev", None) is not None:
             d = self._gbest_dev
-            e = self.engine
-            cells = e.read(self._d["gpath"].ptr, d["len"], np.int32)
+            e, c = self.engine, self.comm
+            if c is not None and c.world > 1:             # the path row and the stats live on the owner: fetch them (collective!)
+                hdr = self._d.setdefault("ghdr", e.buf(8, np.float64))
+                if c.rank == self._gowner:
+                    hdr.write(0, d["stats"])
+                c.broadcast(hdr, 0, 5, self._gowner)
+                c.broadcast(self._d["gpath"], 0, self._cap + 1, self._gowner)
+                d = dict(d, stats=hdr.read(0, 5), len=int(self._d["gpath"].read(0, 1)[0]))
+            cells = self._d["gpath"].read(1, d["len"])
             pos = e.read(self._d["gb"].ptr, self.num_waypoints * 2, np.float64).reshape(-1, 2)
             self._set_gbest(d["idx"], pos, CellPath(cells, self.cols), d["stats"])
         return self._gbest
@@ -493,91 +642,137 @@ class PSOSolver(_WaypointSolver):
                             "current_fitness": float(self._cur_stats[i][4])} for i in range(len(self._pos))]
 
     def _download_state(self):
-        """HBM -> the host mirrors behind `particles` (bulk copies; only on demand and at the end of solve())."""
-        d, N, cap = self._d, self.num_particles, self._cap
+        """HBM -> the host mirrors behind `particles` (bulk copies; only on demand and at the end of solve()).  A sharded
+        run mirrors this rank's particles [lo, hi)."""
+        d, n, cap = self._d, self._hi - self._lo, self._cap
         self._pos, self._vel = d["pos"].download(), d["vel"].download()
         self._pbest, self._pbest_fit = d["pb"].download(), d["pbf"].download()
         cells, lens, stats = d["cells"].download(), d["len"].download(), d["stats"].download()
         pbc, pbl = d["pb_cells"].download(), d["pb_len"].download()
-        self._cur_path = [CellPath(cells[i, :lens[i]].copy(), self.cols) for i in range(N)]
-        self._cur_stats = [stats[i] for i in range(N)]
-        self._pbest_path = [CellPath(pbc[i, :pbl[i]].copy(), self.cols) for i in range(N)]
+        self._cur_path = [CellPath(cells[i, :lens[i]].copy(), self.cols) for i in range(n)]
+        self._cur_stats = [stats[i] for i in range(n)]
+        self._pbest_path = [CellPath(pbc[i, :pbl[i]].copy(), self.cols) for i in range(n)]
 
     def begin(self):
-        """Initialise the swarm (pso.py:97-161) and move it into HBM; False if no particle could be built."""
+        """Initialise the swarm (pso.py:97-161) and move it into HBM; False if no particle could be built.  Sharded
+        (comm.world > 1): every rank replays the same keyed initialisation and keeps its block [lo, hi) of the particles."""
+        from .dist import shard_range
         self._d = None
         self._it = 0
+        c = self.comm
+        self._lo, self._hi = shard_range(self.num_particles, c.rank, c.world) if c is not None else (0, self.num_particles)
         if not self._initialize_particles():
             return False
         self.convergence_curve.append(self._gbest["fitness"])
-        e, N, W = self.engine, self.num_particles, self.num_waypoints
+        e, W = self.engine, self.num_waypoints
+        if c is not None and c.transport == "rccl" and c.engine is None:
+            c.attach(e)
+        lo, hi = self._lo, self._hi
+        n = hi - lo
+        self._pos, self._vel, self._pbest, self._pbest_fit = self._pos[lo:hi], self._vel[lo:hi], self._pbest[lo:hi], self._pbest_fit[lo:hi]
+        self._cur_path, self._cur_stats, self._pbest_path = self._cur_path[lo:hi], self._cur_stats[lo:hi], self._pbest_path[lo:hi]
+        self._sync_particles()
         cap = self._cap = self._path_cap()
+        m = max(n, 1)
         d = {}
-        d["pos"], d["vel"], d["pb"] = e.put(self._pos), e.put(self._vel), e.put(self._pbest)
-        d["pbf"] = e.put(self._pbest_fit)
+        d["pos"], d["vel"], d["pb"] = e.buf((m, W, 2), np.float64), e.buf((m, W, 2), np.float64), e.buf((m, W, 2), np.float64)
+        d["pbf"] = e.buf(m, np.float64)
         d["gb"] = e.put(np.array(self._gbest["position"], np.float64))
-        d["cells"], d["len"], d["st"] = e.buf((N, cap), np.int32), e.buf(N, np.int32), e.buf(N, np.int32)
-        d["stats"], d["imp"] = e.buf((N, 5), np.float64), e.buf(N, np.int32)
-        d["pos0"], d["vel0"] = e.buf((N, W, 2), np.float64), e.buf((N, W, 2), np.float64)
-        d["gpath"] = e.buf(cap, np.int32)
-        # current / pbest paths start as the initial paths (pso.py:111-117)
-        cur = np.zeros((N, cap), np.int32); ln = np.zeros(N, np.int32)
-        for i, cp in enumerate(self._cur_path):
-            c = cells_of(cp, self.cols)
-            if len(c) > cap:
-                raise RuntimeError("pathfit: path capacity overflow in PSO initialisation")
-            cur[i, :len(c)] = c; ln[i] = len(c)
-        d["cells"].upload(cur); d["len"].upload(ln)
-        d["stats"].upload(np.array(self._cur_stats, np.float64).reshape(N, 5))
-        d["pb_cells"], d["pb_len"] = e.put(cur), e.put(ln)
+        d["cells"], d["len"], d["st"] = e.buf((m, cap), np.int32), e.buf(m, np.int32), e.buf(m, np.int32)
+        d["stats"], d["imp"] = e.buf((m, 5), np.float64), e.buf(m, np.int32)
+        d["pos0"], d["vel0"] = e.buf((m, W, 2), np.float64), e.buf((m, W, 2), np.float64)
+        d["gpath"] = e.buf(cap + 1, np.int32)
+        d["pb_cells"], d["pb_len"] = e.buf((m, cap), np.int32), e.buf(m, np.int32)
+        if n:
+            d["pos"].upload(self._pos); d["vel"].upload(self._vel); d["pb"].upload(self._pbest); d["pbf"].upload(self._pbest_fit)
+            # current / pbest paths start as the initial paths (pso.py:111-117)
+            cur = np.zeros((n, cap), np.int32); ln = np.zeros(n, np.int32)
+            for i, cp in enumerate(self._cur_path):
+                cc = cells_of(cp, self.cols)
+                if len(cc) > cap:
+                    raise RuntimeError("pathfit: path capacity overflow in PSO initialisation")
+                cur[i, :len(cc)] = cc; ln[i] = len(cc)
+            d["cells"].upload(cur); d["len"].upload(ln)
+            d["stats"].upload(np.array(self._cur_stats, np.float64).reshape(n, 5))
+            d["pb_cells"].upload(cur); d["pb_len"].upload(ln)
         self._d = d
+        self._gowner = -1                     # rank whose d["gpath"] holds the gbest path (-1: the host copy from the initialisation)
         self._particles_stale = False
         return True
 
     def sweep(self):
         """One iteration of pso.py:178-231 over the whole swarm, resident in HBM: update -> decode/stitch -> score ->
-        pbest -> gbest.  Speculate that no particle of [lo, N) improves gbest: evaluate them in one batch with the current
-        gbest.  Everything up to and including the first improver p* is exact; gbest moves to p* and the particles
-        after it are rolled back and re-evaluated (their draws are keyed per particle, so the re-evaluation consumes
-        the same random numbers).  Synchronous mode commits the whole batch.  Device-to-host traffic: 16 bytes per
-        launch (the improver scan) + 44 bytes per gbest change; no path, position or stats column leaves HBM."""
-        e, N, W, d, cap, it = self.engine, self.num_particles, self.num_waypoints, self._d, self._cap, self._it
+        pbest -> gbest.  Speculate that no particle from `cur` on improves gbest: evaluate them in one batch with the
+        current gbest.  Everything up to and including the first improver p* is exact; gbest moves to p* and the
+        particles after it are rolled back and re-evaluated (their draws are keyed per particle, so the re-evaluation
+        consumes the same random numbers).  Synchronous mode commits the whole batch.  Sharded, the first improver is
+        the smallest GLOBAL index over the ranks (16 B per rank per round), its owner broadcasts the new gbest position.
+        Device-to-host traffic: 16 bytes per launch (the improver scan) + 44 bytes per gbest change; no path, position
+        or stats column leaves HBM."""
+        e, N, W, d, cap, it, c = self.engine, self.num_particles, self.num_waypoints, self._d, self._cap, self._it, self.comm
+        world = c.world if c is not None else 1
+        rank = c.rank if c is not None else 0
+        lo, hi = self._lo, self._hi
         s_cell, t_cell = self._cell(self.start_node), self._cell(self.target_node)
         st_sz = W * 2 * 8
         gfit = self._gbest_dev["fitness"] if self._gbest_dev is not None else self._gbest["fitness"]
-        lo = 0
-        while lo < N:
-            m = N - lo
-            if self.asynchronous:
-                e.d2d(d["pos0"].at(lo * W * 2), d["pos"].at(lo * W * 2), m * st_sz)
-                e.d2d(d["vel0"].at(lo * W * 2), d["vel"].at(lo * W * 2), m * st_sz)
-            e.pso_update_raw(m, W, self.w, self.c1, self.c2, self.max_vel, d["pos"].at(lo * W * 2), d["vel"].at(lo * W * 2),
-                             d["pb"].at(lo * W * 2), d["gb"].ptr, self.seed, it, lo)
-            e.decode_raw(m, W, s_cell, t_cell, cap, d["cells"].at(lo * cap), d["len"].at(lo), d["st"].at(lo), d["pos"].at(lo * W * 2),
-                         self._sp, d["stats"].at(lo * 5), self.allow_diagonal_moves, self.restrict_diagonal_near_obstacle_policy)
-            idx, fit, ovf = e.pso_scan(m, d["stats"].at(lo * 5), d["len"].at(lo), d["st"].at(lo), d["pbf"].at(lo), gfit,
-                                       0 if self.asynchronous else 1)
-            if ovf:
-                raise RuntimeError("pathfit: scratch/path capacity overflow in PSO decode")
-            upto = (lo + idx if idx >= 0 else N - 1) if self.asynchronous else N - 1   # last particle whose evaluation is final
-            k = upto - lo + 1
-            e.pso_pbest_raw(k, W, d["pos"].at(lo * W * 2), d["stats"].at(lo * 5), d["len"].at(lo), d["pb"].at(lo * W * 2),
-                            d["pbf"].at(lo), d["imp"].at(lo))                   # pso.py:216-220
-            e.pso_pbest_paths_raw(k, cap, d["cells"].at(lo * cap), d["len"].at(lo), d["imp"].at(lo), d["pb_cells"].at(lo * cap),
-                                  d["pb_len"].at(lo))
-            if idx >= 0:                                                       # pso.py:222-229: gbest moves to particle j
-                j = lo + idx
-                e.d2d(d["gb"].ptr, d["pos"].at(j * W * 2), st_sz)
-                stats_j = e.read(d["stats"].at(j * 5), 5, np.float64)
-                len_j = int(e.read(d["len"].at(j), 1, np.int32)[0])
-                e.d2d(d["gpath"].ptr, d["cells"].at(j * cap), len_j * 4)
-                self._gbest_dev = {"idx": j, "fitness": fit, "stats": stats_j, "len": len_j}
-                gfit = fit
-            if upto < N - 1:                                                   # roll back the not yet final particles
-                r = upto + 1
-                e.d2d(d["pos"].at(r * W * 2), d["pos0"].at(r * W * 2), (N - r) * st_sz)
-                e.d2d(d["vel"].at(r * W * 2), d["vel0"].at(r * W * 2), (N - r) * st_sz)
-            lo = upto + 1
+        cur = 0                                                            # global index of the first particle not yet final
+        while cur < N:
+            a0 = max(lo, cur)                                              # my particles [a0, hi) are evaluated this round
+            m = max(hi - a0, 0)
+            idx, fit = -1, INF
+            if m:
+                l0 = a0 - lo
+                if self.asynchronous:
+                    e.d2d(d["pos0"].at(l0 * W * 2), d["pos"].at(l0 * W * 2), m * st_sz)
+                    e.d2d(d["vel0"].at(l0 * W * 2), d["vel"].at(l0 * W * 2), m * st_sz)
+                e.pso_update_raw(m, W, self.w, self.c1, self.c2, self.max_vel, d["pos"].at(l0 * W * 2), d["vel"].at(l0 * W * 2),
+                                 d["pb"].at(l0 * W * 2), d["gb"].ptr, self.seed, it, a0)
+                e.decode_raw(m, W, s_cell, t_cell, cap, d["cells"].at(l0 * cap), d["len"].at(l0), d["st"].at(l0), d["pos"].at(l0 * W * 2),
+                             self._sp, d["stats"].at(l0 * 5), self.allow_diagonal_moves, self.restrict_diagonal_near_obstacle_policy)
+                idx, fit, ovf = e.pso_scan(m, d["stats"].at(l0 * 5), d["len"].at(l0), d["st"].at(l0), d["pbf"].at(l0), gfit,
+                                           0 if self.asynchronous else 1)
+                if ovf:
+                    raise RuntimeError("pathfit: scratch/path capacity overflow in PSO decode")
+            mine = a0 + idx if idx >= 0 else -1                            # global index of my improver
+            if world > 1:
+                allv = c.all_gather_host([mine if mine >= 0 else INF, fit])
+                if self.asynchronous:
+                    r_star = int(np.argmin(allv[:, 0]))                    # the smallest global index = the first improver
+                else:                                                      # smallest fitness, then smallest index (rank order = index order)
+                    r_star = int(np.lexsort((allv[:, 0], allv[:, 1]))[0])
+                p_star = int(allv[r_star, 0]) if np.isfinite(allv[r_star, 0]) else -1
+                f_star = float(allv[r_star, 1])
+            else:
+                r_star, p_star, f_star = rank, mine, fit
+            upto = (p_star if p_star >= 0 else N - 1) if self.asynchronous else N - 1   # last particle whose evaluation is final
+            k = min(upto, hi - 1) - a0 + 1                                 # my evaluated particles that are final now
+            if m and k > 0:
+                l0 = a0 - lo
+                e.pso_pbest_raw(k, W, d["pos"].at(l0 * W * 2), d["stats"].at(l0 * 5), d["len"].at(l0), d["pb"].at(l0 * W * 2),
+                                d["pbf"].at(l0), d["imp"].at(l0))                  # pso.py:216-220
+                e.pso_pbest_paths_raw(k, cap, d["cells"].at(l0 * cap), d["len"].at(l0), d["imp"].at(l0), d["pb_cells"].at(l0 * cap),
+                                      d["pb_len"].at(l0))
+            if p_star >= 0:                                                # pso.py:222-229: gbest moves to particle p*
+                if r_star == rank:
+                    j = p_star - lo
+                    e.d2d(d["gb"].ptr, d["pos"].at(j * W * 2), st_sz)
+                    stats_j = e.read(d["stats"].at(j * 5), 5, np.float64)
+                    len_j = int(e.read(d["len"].at(j), 1, np.int32)[0])
+                    e.d2d(d["gpath"].at(1), d["cells"].at(j * cap), len_j * 4)
+                    d["gpath"].write(0, [len_j])
+                    self._gbest_dev = {"idx": p_star, "fitness": f_star, "stats": stats_j, "len": len_j}
+                else:
+                    self._gbest_dev = {"idx": p_star, "fitness": f_star, "stats": None, "len": 0}
+                if world > 1:
+                    c.broadcast(d["gb"], 0, W * 2, r_star)                 # the new gbest position: W x 16 B
+                self._gowner = r_star
+                gfit = f_star
+            if m and upto < hi - 1:                                        # roll back my not yet final particles
+                r0 = max(upto + 1, a0) - lo
+                e.d2d(d["pos"].at(r0 * W * 2), d["pos0"].at(r0 * W * 2), (hi - lo - r0) * st_sz)
+                e.d2d(d["vel"].at(r0 * W * 2), d["vel0"].at(r0 * W * 2), (hi - lo - r0) * st_sz)
+            cur = upto + 1
         self._particles_stale = True
         self._it += 1
         self.convergence_curve.append(gfit)

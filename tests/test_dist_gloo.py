@@ -22,7 +22,7 @@ def _worker(rank, world, port, out_dir, strict):
     from dist_fakes import FakeMAACO
     from pathfit.dist import Comm, ShardedMAACO
     g, s, t = gio.grid("fig7")
-    comm = Comm(dist, None)
+    comm = Comm(dist, None)           # transport: gloo (host staged) -- the exchange logic is transport independent
     sm = ShardedMAACO(comm, lambda: FakeMAACO(g, s, t, 21, 5, 7, **KW), 21, strict=strict)
     path, length, turns = sm.solve_path_planning()
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), path=np.array(path), length=length, turns=turns,
