@@ -540,14 +540,24 @@ PF_DEV double gbcast8_d(double v, int k) {
   return __hiloint2double(hi, lo);
 }
 
+// WIN: the tabu set of an ant is an exact visited BITMAP of a 64 x 64-cell window around it, in LDS (512 B per ant),
+// instead of 4-byte epoch stamps in HBM (1 MB per resident ant at 512^2): candidates are always adjacent cells, so a step
+// only ever probes the 3 x 3 neighbourhood.  That takes one of the three divergent loads and one of the two stores off
+// every step (the walk is bound by the number of divergent vector-memory instructions).  When the ant comes
+// within one cell of the window's edge the window is recentred on it and rebuilt from the ant's own path (the cells it
+// has visited ARE its path): all 64 lanes scan the path with coalesced loads, ~n/64 iterations, every ~31 steps.
+#define PF_WIN 64
+template <bool WIN>
 __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
+  __shared__ unsigned long long win[8][PF_WIN];                    // [ant of the wave][window row] -> 64 column bits
   const Grid& G = p.G;
   const int R = G.R, C = G.C, RC = R * C;
   const int lane = lane_id();
   const int k = lane & 7, grp = lane >> 3;
   const int slot = blockIdx.x * 8 + grp;
-  unsigned* visit = p.visit + (size_t)slot * RC;
-  unsigned epoch = p.slot_epoch[slot];
+  unsigned* visit = WIN ? nullptr : p.visit + (size_t)slot * RC;
+  unsigned epoch = WIN ? 0u : p.slot_epoch[slot];
+  int wr0 = 0, wc0 = 0;                                            // top-left cell of this ant's window (may lie outside the grid)
   const int mdr = AM_DR[k], mdc = AM_DC[k];
   const unsigned hbit = 1u << AM_TO_HM[k];
   const int sr = row_of(G, p.start), sc = p.start - sr * C;
@@ -573,16 +583,25 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
       if (w >= p.n) alive = false;
       else {
         a = w;
-        epoch += 1;
-        if (epoch >= 0xFFFFFFF0u) {
-          for (int i = k; i < RC; i += 8) visit[i] = 0;
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          epoch = 1;
+        if (!WIN) {
+          epoch += 1;
+          if (epoch >= 0xFFFFFFF0u) {
+            for (int i = k; i < RC; i += 8) visit[i] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            epoch = 1;
+          }
         }
         g.init(p.seed, DOM_MAACO, (unsigned long long)p.iter, (unsigned long long)(p.ant0 + a));
         out = p.cells + (size_t)a * p.path_cap;
         cr = sr; cc = sc; n = 1; prev_k = -1; nturn = 0; rc = 0; plen = 0.0; steps = 0;
-        if (k == 0) { out[0] = p.start; visit[p.start] = epoch; }
+        if (k == 0) { out[0] = p.start; if (!WIN) visit[p.start] = epoch; }
+        if (WIN) {                                                 // fresh window centred on the start, only the start marked
+          wr0 = sr - PF_WIN / 2; wc0 = sc - PF_WIN / 2;
+          for (int i = k; i < PF_WIN; i += 8) win[grp][i] = 0ull;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (k == 0) win[grp][sr - wr0] = 1ull << (sc - wc0);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        }
         need = false;
       }
     }
@@ -597,12 +616,13 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
       unsigned vst = 0; double tv = 0.0, ev = 0.0;
       const unsigned M = G.mm[cur];
       if (inb) {
-        vst = visit[nidx];
+        if (WIN) vst = (unsigned)((win[grp][nr - wr0] >> (nc - wc0)) & 1ull);   // (the neighbourhood is inside the window: see the recentring below)
+        else vst = visit[nidx];
         // the step is bound by the number of divergent vector loads: tau and eta'[turn] in one
         const pf_d2u te = *(const pf_d2u*)(p.tep + (size_t)nidx * 3 + turn);
         tv = turn ? te.x : te.y; ev = turn ? te.y : te.x;
       }
-      const bool ok = inb && (M & hbit) && vst != epoch;
+      const bool ok = inb && (M & hbit) && (WIN ? vst == 0u : vst != epoch);
       const unsigned mall = gballot8(ok);
       const int vr = tr - cr, vc = tc - cc;
       const bool o2 = !((vc > 0 && mdc < 0) || (vc < 0 && mdc > 0) || (vr > 0 && mdr < 0) || (vr < 0 && mdr > 0));
@@ -662,9 +682,35 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
           cr += gbcast8_i(mdr, pick); cc += gbcast8_i(mdc, pick);
           if (n >= p.path_cap) { rc = 3; done = true; }
           else {
-            if (k == 0) { out[n] = cr * C + cc; visit[cr * C + cc] = epoch; }
+            if (k == 0) { out[n] = cr * C + cc; if (WIN) win[grp][cr - wr0] |= 1ull << (cc - wc0); else visit[cr * C + cc] = epoch; }
             n += 1; steps += 1;
           }
+        }
+      }
+    }
+    if (WIN) {
+      // ---- recentre + rebuild the windows of the ants that came within a cell of their window's edge ----
+      const bool edge = alive && !need && !done && (cr - wr0 < 1 || cr - wr0 > PF_WIN - 2 || cc - wc0 < 1 || cc - wc0 > PF_WIN - 2);
+      unsigned long long em = __ballot(edge && k == 0);
+      if (em) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");           // the path cells written so far are in L2 before they are read back
+        while (em) {
+          const int l0 = __builtin_ctzll(em); em &= em - 1;          // lane 8 * g of the ant to serve (uniform)
+          const int g_ = l0 >> 3;
+          const int ar = bcast_i(cr, l0), ac = bcast_i(cc, l0), an = bcast_i(n, l0);
+          const int* apath = (const int*)first_u64((uint64_t)(bcast_i((int)((uint64_t)out & 0xFFFFFFFFull), l0) |
+                                                     ((uint64_t)(unsigned)bcast_i((int)((uint64_t)out >> 32), l0) << 32)));
+          const int nr0 = ar - PF_WIN / 2, nc0 = ac - PF_WIN / 2;
+          win[g_][lane] = 0ull;                                       // 64 lanes, 64 rows
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          for (int i = lane; i < an; i += 64) {                       // coalesced; agent scope: never a stale L1 line
+            const int cell = __hip_atomic_load(apath + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int r_ = row_of(G, cell), c_ = cell - r_ * C;
+            const unsigned rr_ = (unsigned)(r_ - nr0), cc_ = (unsigned)(c_ - nc0);
+            if (rr_ < (unsigned)PF_WIN && cc_ < (unsigned)PF_WIN) atomicOr(&win[g_][rr_], 1ull << cc_);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (grp == g_) { wr0 = nr0; wc0 = nc0; }
         }
       }
     }
@@ -682,7 +728,7 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
     }
   }
   if (k == 0) {
-    p.slot_epoch[slot] = epoch;
+    if (!WIN) p.slot_epoch[slot] = epoch;
     atomicAdd(&p.cnt->steps, steps_tot); atomicAdd(&p.cnt->candidates, cand_tot); atomicAdd(&p.cnt->path_cells, cells_tot);
     if (ovf_tot) atomicAdd(&p.cnt->overflow, ovf_tot);
   }
@@ -1641,9 +1687,10 @@ struct Rccl {
 Rccl g_rccl;
 const char* rccl_load() {
   if (g_rccl.so) return nullptr;
-  void* so = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-  if (!so) so = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-  if (!so) so = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  // RTLD_LOCAL: a process that also hosts torch has torch's own bundled librccl loaded; the two must not interpose
+  void* so = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!so) so = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!so) so = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
   if (!so) return "pf_comm: librccl.so not found (dlopen)";
 #define PF_SYM(field, name) do { *(void**)(&g_rccl.field) = dlsym(so, name); if (!g_rccl.field) return "pf_comm: librccl misses " name; } while (0)
   PF_SYM(GetUniqueId, "ncclGetUniqueId"); PF_SYM(CommInitRank, "ncclCommInitRank"); PF_SYM(CommDestroy, "ncclCommDestroy");
@@ -1780,6 +1827,7 @@ static int g_mpa_prune = 1;   // exact bound pruning of MPA rebuilds (pf_set_opt
 static double g_doubt_log = 1.0 / 8589934592.0;   // 2^-33 relative margin on normalvariate's accept test (pf_set_option "mpa_doubt_log_e15" overrides, in 1e-15)
 static double g_doubt_round = 1e-7;                // absolute margin on the fraction fed to round()   ("mpa_doubt_round_e15")
 static int g_maaco_pack8_min = env_int("PF_MAACO_PACK8_MIN", 2048);   // ants per batch from which 8 ants share a wavefront
+static int g_maaco_window = env_int("PF_MAACO_WINDOW", 1);           // 8-ants-per-wave walk: tabu set = LDS bitmap window (1) or HBM epoch stamps (0)
 static const int kLdsS = 16;
 static int ensure_slots(pf_handle* h, int allow_diag = 1, int restrict_corner = 1) {
   CK(hipSetDevice(h->device));
@@ -2050,6 +2098,7 @@ int pf_set_option(pf_handle* h, const char* name, int64_t value) {
   if (!name) return failmsg(h, "pf_set_option: bad arguments");
   if (!strcmp(name, "astar_step_cap")) { g_step_cap = value > 0 ? (long long)value : 0; return 0; }
   if (!strcmp(name, "maaco_pack8_min")) { g_maaco_pack8_min = (int)value; return 0; }
+  if (!strcmp(name, "maaco_window")) { g_maaco_window = value != 0; return 0; }
   if (!strcmp(name, "mpa_prune")) { g_mpa_prune = value != 0; return 0; }
   if (!strcmp(name, "mpa_doubt_log_e15")) { g_doubt_log = value < 0 ? 1.0 / 8589934592.0 : (double)value * 1e-15; return 0; }
   if (!strcmp(name, "mpa_doubt_round_e15")) { g_doubt_round = value < 0 ? 1e-7 : (double)value * 1e-15; return 0; }
@@ -2176,7 +2225,8 @@ int pf_maaco_walk_batch(pf_handle* h, int32_t iter, uint64_t seed, int32_t ant0,
   CK(hipMemsetAsync(h->d_cnt, 0, sizeof(DevCounters), h->stream));
   if (pack8) hipLaunchKernelGGL(k_pack_tep, dim3((h->RC + 255) / 256), dim3(256), 0, h->stream, h->RC, a.tau, a.eta, h->d_tep);
   CK(hipEventRecord(h->ev0, h->stream));
-  if (pack8) hipLaunchKernelGGL(k_maaco_walk8, dim3(grid), dim3(64), 0, h->stream, a);
+  if (pack8 && g_maaco_window) hipLaunchKernelGGL(k_maaco_walk8<true>, dim3(grid), dim3(64), 0, h->stream, a);
+  else if (pack8) hipLaunchKernelGGL(k_maaco_walk8<false>, dim3(grid), dim3(64), 0, h->stream, a);
   else hipLaunchKernelGGL(k_maaco_walk, dim3(grid), dim3(64), 0, h->stream, a);
   CK(hipGetLastError());
   CK(hipEventRecord(h->ev1, h->stream));
