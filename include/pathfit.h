@@ -76,6 +76,8 @@ typedef struct {
   int64_t pops, pushes, nbr_examined, path_cells, steps, candidates, decrease_keys, overflow_agents;
   /* candidates: MAACO candidate cells examined; for the A*-based calls, open-list entries that took the spill list */
   int64_t pruned_rebuilds; /* MPA rebuilds skipped because a length bound proved the candidate could not be accepted */
+  int64_t settled_searches;    /* closed-set searches answered by the parallel label-settling engine (certified equal) */
+  int64_t sequential_searches; /* closed-set searches it could not certify: run by the sequential pop loop */
 } pf_counters;
 
 /* ---- lifecycle ---------------------------------------------------- */
@@ -232,7 +234,10 @@ int pf_mpa_memory(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_sl
                   double* d_pop_stats);
 
 /* Tuning knobs (results never change): "maaco_pack8_min" ants per batch from which eight ants share a wavefront
- * (default 2048); "mpa_prune" 0/1 exact bound pruning of MPA rebuilds (default 1).  Test hook: "astar_step_cap" > 0
+ * (default 2048); "maaco_window" 0/1 tabu set of those walks as an LDS bitmap window (default 1) or HBM stamps;
+ * "mpa_prune" 0/1 exact bound pruning of MPA rebuilds (default 1); "astar_settle" 0/1 closed-set searches (AStarSolver
+ * / Dijkstra / GA / PSO decodes) try the parallel label-settling engine first (default 1; 0 = always the sequential
+ * pop loop, whose pop / push counters are the reference's).  Test hook: "astar_step_cap" > 0
  * lowers the connectors' step cap below the reference's 3RC / 2RC (astar.py:58, MPA.py:118) so that the cap path
  * (PF_ST_STEP_CAP) can be exercised; 0 restores the reference's value.  "mpa_doubt_log_e15" / "mpa_doubt_round_e15":
  * margins (in 1e-15; < 0 = default) inside which an MPA proposal is handed to the host's libm (tests widen them to

@@ -31,7 +31,7 @@ using namespace pf;
 // device-side launch parameter blocks
 // ===========================================================================
 struct DevCounters {
-  unsigned long long pops, pushes, nbr, path_cells, steps, candidates, deckey, overflow, pruned;
+  unsigned long long pops, pushes, nbr, path_cells, steps, candidates, deckey, overflow, pruned, settled, sequential;
 };
 
 struct Common {
@@ -44,6 +44,8 @@ struct Common {
   DevCounters* cnt;
   int S;                 // LDS bin capacity
   int retry;             // only agents whose status == 3
+  // parallel closed-set engine (pf_settle.h): per-slot label / touched / parent arrays, or null (off)
+  unsigned long long* st_lab; int* st_touched; unsigned char* st_par; unsigned* st_epoch;
 };
 
 PF_DEV Open make_open(char* smem, int /*S*/, char* tier2) {
@@ -63,6 +65,11 @@ PF_DEV Slot slot_load(const Common& c, int RC) {
   s.mm = c.G.mm;
   s.tag = c.slot_state[2 * blockIdx.x];
   s.avoid_ep = c.slot_state[2 * blockIdx.x + 1];
+  s.sm.lab = c.st_lab ? c.st_lab + (size_t)blockIdx.x * RC : nullptr;
+  s.sm.touched = c.st_lab ? c.st_touched + (size_t)blockIdx.x * 2 * RC : nullptr;
+  s.sm.par = c.st_lab ? c.st_par + (size_t)blockIdx.x * RC : nullptr;
+  s.sm.epoch = c.st_lab ? c.st_epoch + blockIdx.x : nullptr;
+  s.sm.touched_cap = 2 * RC;
   return s;
 }
 PF_DEV void slot_store(const Common& c, const Slot& s, int lane) {
@@ -93,6 +100,8 @@ PF_DEV void flush_counters(DevCounters* c, const AStat& st, unsigned long long c
     atomicAdd(&c->pops, st.pops); atomicAdd(&c->pushes, st.pushes); atomicAdd(&c->nbr, st.nbr);
     atomicAdd(&c->deckey, st.deckey); atomicAdd(&c->path_cells, cells); atomicAdd(&c->overflow, ovf & 0xFFFFFFFFull);
     if (st.spills) atomicAdd(&c->candidates, (unsigned long long)st.spills);   // A* kernels: spilled open-list entries
+    if (st.settled) atomicAdd(&c->settled, (unsigned long long)st.settled);
+    if (st.sequential) atomicAdd(&c->sequential, (unsigned long long)st.sequential);
     if (ovf >> 32) atomicAdd(&c->pruned, ovf >> 32);           // MPA items count pruned rebuilds in the upper half
   }
 }
@@ -197,8 +206,10 @@ __global__ __launch_bounds__(64) void k_astar_batch(AstarArgs p) {
     // cell indices come straight from the caller: an index outside the grid is "not a valid node" (astar.py:37-39 /
     // MPA.py:109-111 -> []), never an address
     const int sa = p.start[a], ta = p.target[a];
+    const long long ab = p.avoid_off ? p.avoid_off[a] : 0, ae = p.avoid_off ? p.avoid_off[a + 1] : 0;
     const int rc = ((unsigned)sa >= (unsigned)RC || (unsigned)ta >= (unsigned)RC) ? 1 :
-                   astar<VARIANT>(p.c.G, s, O, sa, ta, p.cells + (size_t)a * p.path_cap, p.path_cap, n, st, lane);
+                   astar<VARIANT>(p.c.G, s, O, sa, ta, p.cells + (size_t)a * p.path_cap, p.path_cap, n, st, lane,
+                                  p.avoid_off ? p.avoid_cells + ab : nullptr, (int)(ae - ab));
     if (lane == 0) {
       p.len[a] = rc == 0 ? n : 0;
       p.status[a] = rc;
@@ -208,6 +219,7 @@ __global__ __launch_bounds__(64) void k_astar_batch(AstarArgs p) {
       }
     }
     tot.pops += st.pops; tot.pushes += st.pushes; tot.nbr += st.nbr; tot.deckey += st.deckey; tot.spills += st.spills;
+    tot.settled += st.settled; tot.sequential += st.sequential;
     cells += rc == 0 ? n : 0; ovf += rc == 3;
   }
   slot_store(p.c, s, lane);
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(64) void k_decode_batch(DecodeArgs p) {
         }
       }
       int m = 0;
-      rc = astar<0>(G, s, O, cur, goal, out + n - 1, p.path_cap - (n - 1), m, tot, lane);   // ga_solver.py:68-72
+      rc = astar<0>(G, s, O, cur, goal, out + n - 1, p.path_cap - (n - 1), m, tot, lane, out, n);   // ga_solver.py:68-72 (avoid = the cells visited so far)
       if (rc != 0) break;                                        // :74 / :85 -> []
       mark_avoid(s, out + n, m - 1, lane);                       // :76 nodes_in_path_so_far.update
       n += m - 1;
@@ -1653,6 +1665,7 @@ struct pf_handle {
   double* d_okey = nullptr; double* d_okey2 = nullptr; int* d_oval2 = nullptr; int okey_cap = 0;   // pf_sort_order_by_key scratch
   int* d_elite_cells = nullptr; int* d_elite_len = nullptr;   // the elite of the iteration (MPA.py:334), device resident
   int* d_ga_pool = nullptr; int ga_pool_cap = 0;              // random.sample's pool copy (small populations)
+  unsigned long long* d_st_lab = nullptr; int* d_st_touched = nullptr; unsigned char* d_st_par = nullptr; unsigned* d_st_epoch = nullptr;   // pf_settle.h scratch
   int dep_words = 0; long long dep_done = 0;   // MAACO deposit in progress: words of the bit matrix, cells already folded
   ncclComm_t comm = nullptr; int comm_rank = 0, comm_world = 1;   // RCCL communicator over xGMI (pf_comm_init); collectives run on `stream`
   long long d2h_small = 0, d2h_bulk = 0, d2h_bulk_bytes = 0;   // device-to-host copies the library made (f1/f2 accounting): <= 128 B / larger
@@ -1797,7 +1810,7 @@ void pf_destroy(pf_handle* h) {
   if (h->comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(h->stream); g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
   void* ptrs[] = {h->d_occ, h->d_mm_r1, h->d_mm_r0, h->d_mm_r1_nd, h->d_mm_r0_nd, h->d_d2near, h->d_rec, h->d_slot_state,
                   h->d_work, h->d_cnt, h->d_pen, h->d_tier2, h->d_tau, h->d_taua, h->d_eta, h->d_dep, h->d_tep, h->d_visit, h->d_visit_epoch,
-                  h->d_bits, h->d_tmp, h->d_elite_stats, h->d_init_cells, h->d_init_stats, h->d_est, h->d_est2, h->d_iota, h->d_queue, h->d_sort_tmp, h->d_prop, h->d_doubt, h->d_scan, h->d_scan3, h->d_okey, h->d_okey2, h->d_oval2, h->d_elite_cells, h->d_elite_len, h->d_ga_pool,
+                  h->d_bits, h->d_tmp, h->d_elite_stats, h->d_init_cells, h->d_init_stats, h->d_est, h->d_est2, h->d_iota, h->d_queue, h->d_sort_tmp, h->d_prop, h->d_doubt, h->d_scan, h->d_scan3, h->d_okey, h->d_okey2, h->d_oval2, h->d_elite_cells, h->d_elite_len, h->d_ga_pool, h->d_st_lab, h->d_st_touched, h->d_st_par, h->d_st_epoch,
                   h->d_comp[0], h->d_comp[1], h->d_comp[2], h->d_comp[3], h->d_ds, h->d_dt};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1824,6 +1837,7 @@ static int env_int(const char* name, int dflt) { const char* v = getenv(name); r
 static const int kSlotsPerCU = 8;                       // resident one-agent waves per CU at most
 static const int kWavesPerCU = env_int("PF_WAVES_PER_CU", 8);   // resident one-agent waves per CU (LDS permitting)
 static int g_mpa_prune = 1;   // exact bound pruning of MPA rebuilds (pf_set_option "mpa_prune")
+static int g_settle = env_int("PF_SETTLE", 1);   // closed-set searches try the 64-nodes-per-trip engine first (pf_set_option "astar_settle")
 static double g_doubt_log = 1.0 / 8589934592.0;   // 2^-33 relative margin on normalvariate's accept test (pf_set_option "mpa_doubt_log_e15" overrides, in 1e-15)
 static double g_doubt_round = 1e-7;                // absolute margin on the fraction fed to round()   ("mpa_doubt_round_e15")
 static int g_maaco_pack8_min = env_int("PF_MAACO_PACK8_MIN", 2048);   // ants per batch from which 8 ants share a wavefront
@@ -1841,6 +1855,14 @@ static int ensure_slots(pf_handle* h, int allow_diag = 1, int restrict_corner = 
     CK(hipMalloc(&h->d_rec, bytes));
     CK(hipMalloc(&h->d_slot_state, sizeof(uint32_t) * 2 * h->nslots));
     CK(hipMalloc(&h->d_tier2, (size_t)h->nslots * PF_POOL_STRIDE));
+    // parallel closed-set engine: 17 bytes per cell and slot (labels start as all ones = "older than any search")
+    const size_t rc = (size_t)h->RC, ns = (size_t)h->nslots;
+    if (ns * rc * 17 <= (48ull << 30)) {
+      CK(hipMalloc(&h->d_st_lab, ns * rc * 8)); CK(hipMalloc(&h->d_st_touched, ns * rc * 8)); CK(hipMalloc(&h->d_st_par, ns * rc));
+      CK(hipMalloc(&h->d_st_epoch, ns * sizeof(unsigned)));
+      CK(hipMemsetAsync(h->d_st_lab, 0xFF, ns * rc * 8, h->stream));
+      CK(hipMemsetAsync(h->d_st_epoch, 0, ns * sizeof(unsigned), h->stream));
+    }
   }
   const int policy = (allow_diag ? 2 : 0) | (restrict_corner ? 1 : 0);
   if (h->rec_policy != policy) {
@@ -1864,6 +1886,8 @@ static Common make_common(pf_handle* h, int allow_diag, int restrict_corner, int
   Common c;
   c.G = make_grid(h, allow_diag, restrict_corner);
   c.rec = h->d_rec; c.tier2 = h->d_tier2; c.slot_state = h->d_slot_state; c.work = h->d_work; c.queue = nullptr; c.cnt = h->d_cnt; c.S = S; c.retry = retry;
+  const bool st_on = g_settle && h->d_st_lab;
+  c.st_lab = st_on ? h->d_st_lab : nullptr; c.st_touched = h->d_st_touched; c.st_par = h->d_st_par; c.st_epoch = h->d_st_epoch;
   return c;
 }
 static int begin_batch(pf_handle* h) {
@@ -1877,7 +1901,7 @@ static int end_batch(pf_handle* h, DevCounters* dc) {
   h->d2h_small += 1;                                              // the 72-byte counter block of every batch
   h->last.pops = dc->pops; h->last.pushes = dc->pushes; h->last.nbr_examined = dc->nbr; h->last.path_cells = dc->path_cells;
   h->last.steps = dc->steps; h->last.candidates = dc->candidates; h->last.decrease_keys = dc->deckey; h->last.overflow_agents = dc->overflow;
-  h->last.pruned_rebuilds = dc->pruned;
+  h->last.pruned_rebuilds = dc->pruned; h->last.settled_searches = dc->settled; h->last.sequential_searches = dc->sequential;
   return 0;
 }
 
@@ -2100,6 +2124,7 @@ int pf_set_option(pf_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "maaco_pack8_min")) { g_maaco_pack8_min = (int)value; return 0; }
   if (!strcmp(name, "maaco_window")) { g_maaco_window = value != 0; return 0; }
   if (!strcmp(name, "mpa_prune")) { g_mpa_prune = value != 0; return 0; }
+  if (!strcmp(name, "astar_settle")) { g_settle = value != 0; return 0; }
   if (!strcmp(name, "mpa_doubt_log_e15")) { g_doubt_log = value < 0 ? 1.0 / 8589934592.0 : (double)value * 1e-15; return 0; }
   if (!strcmp(name, "mpa_doubt_round_e15")) { g_doubt_round = value < 0 ? 1e-7 : (double)value * 1e-15; return 0; }
   return failmsg(h, std::string("pf_set_option: unknown option ") + name);

@@ -26,7 +26,15 @@ struct Open {
   double* of;  // this slot's HBM bucket pool (PF_POOL_STRIDE bytes)
 };
 
+struct SettleMem {
+  unsigned long long* lab;          // [RC] epoch-coded labels of this slot
+  int* touched;                     // [2 RC] cells whose label was lowered, in order (duplicates allowed)
+  unsigned char* par;               // [RC] parent move of every certified node (move index FROM the parent TO the node)
+  unsigned* epoch;                  // this slot's label epoch (1..126), in HBM between launches
+  int touched_cap;
+};
 struct Slot {
+  SettleMem sm;       // parallel closed-set engine's scratch (pf_settle.h); sm.lab == nullptr: not available
   Rec* rec;
   const uint8_t* mm;  // move masks the records were initialised from (for the wrap wipe)
   uint32_t tag;       // solve epoch (24 bit)
@@ -37,6 +45,7 @@ struct AStat {
   unsigned long long pops, pushes, nbr, deckey;
   int max_open;
   unsigned spills;   // open-list entries that went through the spill list (full bucket / beyond the circular range)
+  unsigned settled, sequential;   // closed-set searches answered by the parallel engine / handed on to the sequential one
 };
 // diagnostic build only (-DPF_STAMPS): shader-clock time per section of the pop loop, never in the product .so
 #ifdef PF_STAMPS
@@ -66,6 +75,7 @@ PF_DEV int move_dc(int d) { return (int)((0x2252u >> (2 * d)) & 3u) - 1; }   // 
 
 }  // namespace pf
 #include "pf_astar_sw.h"
+#include "pf_settle.h"
 namespace pf {
 
 // ---------------------------------------------------------------------------
@@ -134,9 +144,11 @@ PF_DEV int pocket_flood(const Grid& G, const Slot& s, int* lds, int from, int to
 
 // Returns status (PF_ST_*).  On PF_ST_OK, out[0..out_n) holds the path cells
 // (r*C+c) start..target.  out_cap is the room available at `out`.
+// av_list / av_n: the cells of this search's avoid set as a list (the same cells mark_avoid has stamped into the
+// records); only the closed-set variants use it, to re-mark them under the parallel engine's label epoch.
 template <int VARIANT>
 __device__ __forceinline__ int astar(const Grid& G, Slot& s, const Open& O, int start, int target, int* out, int out_cap,
-                     int& out_n, AStat& st, int lane) {
+                     int& out_n, AStat& st, int lane, const int* av_list = nullptr, int av_n = 0) {
   // VARIANT 0 AStarSolver.solve (astar.py:33-101), 1 MPA._a_star (MPA.py:106-151), 2 DijkstraSolver.solve
   // (dijkstra.py:32-97: the loop of variant 0 with heap entries (g, node), i.e. h == 0 and key (g, g, node))
   constexpr int SEM = VARIANT == 1 ? 1 : 0;
@@ -177,6 +189,13 @@ __device__ __forceinline__ int astar(const Grid& G, Slot& s, const Open& O, int 
     const int ex = SEM == 0 ? start : -1;               // VARIANT 0: start/target may sit in the avoid set
     if (pocket_flood(G, s, (int*)O.lf, target, start, ex, lane) == 1) return 1;
     if (pocket_flood(G, s, (int*)O.lf, start, target, SEM == 0 ? target : -1, lane) == 1) return 1;
+  }
+  // The closed-set variants first try the 64-nodes-per-trip engine (pf_settle.h); it returns PF_ST_SEQ when it cannot
+  // certify that the sequential loop would have produced the same labels and parents, and the search then runs below.
+  if (SEM == 0 && s.sm.lab && G.step_cap == 0) {
+    const int rs = settle<VARIANT>(G, O, s.sm, start, target, tr, tc, av_list, av_n, out, out_cap, out_n, st, lane);
+    if (rs != PF_ST_SEQ) { st.settled += 1; return rs; }
+    st.sequential += 1;
   }
   s.tag = (uint32_t)first_i((int)s.tag) + 1;
   const uint32_t tag = s.tag;

@@ -1,0 +1,210 @@
+// pf_settle.h -- the closed-set connector (AStarSolver.solve astar.py:33-101, DijkstraSolver.solve dijkstra.py:32-97)
+// WITHOUT the sequential pop order: 64 nodes are expanded per trip, one per lane.
+//
+// Why this is exact (CPU study scripts/settle/).  Let g be the least fixpoint of
+//     g(x) = min over expanded neighbours p of fl(g(p) + c(p, x)),   g(start) = 0,
+// where "expanded" = key(p) < key(goal), key(x) = (fl(g(x) + h(x)), g(x), cell(x)).  Any label-correcting schedule
+// reaches it (fl(. + c) is monotone).  Call x REGULAR if some neighbour p with fl(g(p) + c) == g(x) has key(p) < key(x).
+// THEOREM: if every node with key below the goal's is regular, the reference's loop pops exactly those nodes, in key
+// order, closes each with g(x), and came_from[x] is the regular parent with the smallest key.  (Induction over the pops:
+// the k+1-th smallest key has its argmin parent among the first k, so it holds its final label and is the heap minimum;
+// every other open node holds a label >= its final one, hence a larger key.)  Irregular nodes exist -- double rounding can
+// give a node on a ray towards the goal a key one ulp BELOW its only parent's -- in 5-15 % of the searches; the pass below
+// detects every one of them and the search is then handed to the sequential engine (pf_astar_sw.h).  Nothing is assumed.
+//
+// Mapping.  Labels live in a per-slot array of 64-bit words, epoch-coded so that (a) a new search never clears it and
+// (b) ONE atomicMin both compares and updates: word = code << 57 | key57, code = 127 - epoch (newer searches have
+// SMALLER codes, so any stale word loses against a fresh one), key57 = the label's bit pattern minus 1022 << 52 (labels
+// are 0 or >= 1 and < 2^24: 57 bits, order preserving).  Avoid cells are written as key 0 with the current code: no
+// relaxation can ever beat them, which is exactly "excluded from every neighbour list" (astar.py:51-56,80).  The open
+// list is the bucket pool of the sequential engine (floor(64 f), 256 circular buckets in HBM, counts in LDS) used as a
+// plain bag: order inside a bucket is irrelevant for a fixpoint.  Every successful relaxation is also logged in a
+// touched list; afterwards one pass over it checks regularity and writes the parent move of every node, and the path is
+// read off the parents.
+#pragma once
+
+namespace pf {
+
+#define PF_ST_SEQ 5                 /* internal: not certified -> the caller runs the sequential engine */
+#define PF_SETTLE_CAP 1024          /* entries per bucket (16 B each) */
+#define PF_LAB_KEYMASK ((1ull << 57) - 1ull)
+
+PF_DEV unsigned long long lab_enc(double g, unsigned code) {
+  const unsigned long long b = dbits(g);
+  return ((unsigned long long)code << 57) | (b ? b - (1022ull << 52) : 0ull);
+}
+PF_DEV double lab_dec(unsigned long long v) {
+  const unsigned long long k = v & PF_LAB_KEYMASK;
+  return k ? __builtin_bit_cast(double, k + (1022ull << 52)) : 0.0;
+}
+PF_DEV int opposite_move(int m) { return m < 4 ? (m ^ 1) : 11 - m; }   // helper.py:30-36 order: 0<->1 2<->3 4<->7 5<->6
+
+template <int VARIANT>
+__device__ __forceinline__ int settle(const Grid& G, const Open& O, const SettleMem& M, int start, int target, int tr, int tc,
+                                      const int* av_list, int av_n, int* out, int out_cap, int& out_n, AStat& st, int lane) {
+  constexpr int NBK = PF_SW_NBK, CAP = PF_SETTLE_CAP;
+  const int C = G.C, RC = G.R * G.C;
+  int* cnt = (int*)O.lf;                                            // LDS [NBK] entries per bucket
+  double* eg = O.of;                                                // HBM [NBK][CAP] label of the entry
+  int* ec = (int*)(eg + (size_t)NBK * CAP);                         // HBM [NBK][CAP] its cell
+  for (int k = lane; k < NBK; k += 64) cnt[k] = 0;
+  // ---- epoch: newer searches use smaller codes; wipe the label array before the codes run out ----
+  unsigned ep = M.epoch[0] + 1u;
+  if (ep >= 127u) {
+    for (int i = lane; i < RC; i += 64) M.lab[i] = ~0ull;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    ep = 1u;
+  }
+  if (lane == 0) M.epoch[0] = ep;
+  const unsigned code = 127u - ep;
+  const unsigned long long blocked = (unsigned long long)code << 57;          // key 0 under the current code
+  for (int i = lane; i < av_n; i += 64) { const int c = av_list[i]; if (c != start && c != target) M.lab[c] = blocked; }   // astar.py:51-56
+  if (lane == 0) M.lab[start] = blocked;                                       // g(start) = 0 (the same word: told apart by the cell)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  PF_LDS_ORDER();
+  const int sr = row_of(G, start), sc = start - sr * C;
+  long dr0 = sr - tr, dc0 = sc - tc;
+  const double h0 = VARIANT == 2 ? 0.0 : __builtin_sqrt((double)(dr0 * dr0 + dc0 * dc0));
+  int bcur = (int)(h0 * PF_SW_Q);                                    // first bucket (absolute) that may hold entries
+  if (lane == 0) { eg[(size_t)(bcur & (NBK - 1)) * CAP] = 0.0; ec[(size_t)(bcur & (NBK - 1)) * CAP] = start; cnt[bcur & (NBK - 1)] = 1; }
+  PF_LDS_ORDER();
+  int nt = 0;                                                        // touched entries
+  unsigned exp_l = 0, nbr_l = 0, push_l = 0;
+  bool fail = false;
+  for (;;) {
+    // ---- the goal's label bounds the region: nothing with f above it is expanded ----
+    const unsigned long long vt = __hip_atomic_load(&M.lab[target], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (at L2, where the atomics land)
+    const double F = (vt >> 57) == code ? lab_dec(vt) : PF_INF;     // (h(goal) = 0: f = g)
+    // ---- next non-empty bucket ----
+    PF_LDS_ORDER();
+    int c0 = cnt[bcur & (NBK - 1)];
+    if (c0 == 0) {
+      int b0 = -1;
+      for (int base = 0; base < NBK; base += 64) {
+        const int c_ = cnt[(bcur + base + lane) & (NBK - 1)];
+        const unsigned long long nz = __ballot(c_ > 0);
+        if (nz) { b0 = bcur + base + __builtin_ctzll(nz); break; }
+      }
+      if (b0 < 0) break;                                             // open list exhausted
+      bcur = b0;
+      c0 = cnt[bcur & (NBK - 1)];
+    }
+    if (F != PF_INF && (double)bcur > F * PF_SW_Q) break;            // every remaining entry has f above the goal's
+    const int bi = bcur & (NBK - 1);
+    const int m = c0 < 64 ? c0 : 64;
+    PF_LDS_ORDER();
+    if (lane == 0) cnt[bi] = c0 - m;
+    PF_LDS_ORDER();
+    // ---- one entry per lane ----
+    double g = 0.0; int cell = 0;
+    bool have = lane < m;
+    if (have) { g = eg[(size_t)bi * CAP + c0 - m + lane]; cell = ec[(size_t)bi * CAP + c0 - m + lane]; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");           // the entries are read before pushes may overwrite their slots
+    unsigned long long own = 0; unsigned mm = 0;
+    if (have) { own = __hip_atomic_load(&M.lab[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); mm = G.mm[cell]; }   // never a stale L1 copy: a live entry must not be skipped
+    const int r = row_of(G, cell), c = cell - r * C;
+    long hdr = r - tr, hdc = c - tc;
+    const double f = VARIANT == 2 ? g : g + __builtin_sqrt((double)(hdr * hdr + hdc * hdc));
+    have = have && cell != target && own == lab_enc(g, code) && !(own == blocked && cell != start) && f <= F;   // superseded / goal / outside the region
+    if (have) exp_l += 1;
+    // ---- relax the 8 moves: all the label loads first, then the conditional atomics ----
+    unsigned long long vn[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      vn[k] = 0ull;
+      if (have && ((mm >> k) & 1u)) vn[k] = M.lab[cell + move_dr(k) * C + move_dc(k)];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bool ok = have && ((mm >> k) & 1u);
+      const int n = cell + move_dr(k) * C + move_dc(k);
+      const double t = g + (k < 4 ? 1.0 : PF_SQRT2);                 // astar.py:84-85
+      const unsigned long long nv = lab_enc(t, code);
+      bool won = false;
+      if (ok) {
+        nbr_l += 1;
+        if (nv < vn[k]) won = __hip_atomic_fetch_min(&M.lab[n], nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > nv;   // :87
+      }
+      const unsigned long long wm = __ballot(won);
+      if (wm) {
+        const int nr = r + move_dr(k), nc = c + move_dc(k);
+        long dr_ = nr - tr, dc_ = nc - tc;
+        const double fn = VARIANT == 2 ? t : t + __builtin_sqrt((double)(dr_ * dr_ + dc_ * dc_));   // :90
+        int ba = (int)(fn * PF_SW_Q); ba = ba < bcur ? bcur : ba;     // (an ulp below the current band: it is processed with it)
+        if (won) {
+          push_l += 1;
+          const int at = __hip_atomic_fetch_add(&cnt[ba & (NBK - 1)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (at >= CAP || ba - bcur >= NBK) fail = true;
+          else { eg[(size_t)(ba & (NBK - 1)) * CAP + at] = t; ec[(size_t)(ba & (NBK - 1)) * CAP + at] = n; }
+          const int tt = nt + __builtin_popcountll(wm & ((1ull << lane) - 1ull));
+          if (tt < M.touched_cap) M.touched[tt] = n; else fail = true;
+        }
+        nt += __builtin_popcountll(wm);
+      }
+    }
+    if (__ballot(fail)) { fail = true; break; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  }
+  st.pops += (unsigned long long)wave_sum_i((int)exp_l); st.pushes += 1u + (unsigned)wave_sum_i((int)push_l);
+  st.nbr += (unsigned)wave_sum_i((int)nbr_l);
+  if (fail) return PF_ST_SEQ;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                  // the passes below read the labels the atomics left in L2
+  const unsigned long long vt = M.lab[target];
+  if ((vt >> 57) != code || vt == blocked) return 1;                 // the goal was never reached: astar.py:101 -> []
+  const double F = lab_dec(vt);
+  // ---- regularity + parents, one touched node per lane ----
+  bool bad = false;
+  for (int i0 = 0; i0 < nt; i0 += 64) {
+    const bool in = i0 + lane < nt;
+    const int x = in ? M.touched[i0 + lane] : start;
+    const unsigned long long vx = M.lab[x];
+    const double gx = lab_dec(vx);
+    const int r = row_of(G, x), c = x - r * C;
+    long hdr = r - tr, hdc = c - tc;
+    const double fx = VARIANT == 2 ? gx : gx + __builtin_sqrt((double)(hdr * hdr + hdc * hdc));
+    const bool reg = in && x != start && (x == target || fx < F || fx == F);   // key(x) < key(goal): g(x) < g(goal) when the f tie
+    const unsigned mm = reg ? G.mm[x] : 0u;
+    unsigned long long vp[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { vp[k] = ~0ull; if ((mm >> k) & 1u) vp[k] = M.lab[x + move_dr(k) * C + move_dc(k)]; }
+    int best = -1; double bf = 0.0, bg = 0.0; int bc = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int p = x + move_dr(k) * C + move_dc(k);                // moves are symmetric: p -> x is the reverse of move k
+      const bool live = ((mm >> k) & 1u) && (vp[k] >> 57) == code && (vp[k] != blocked || p == start) && p != target;
+      const double gp = lab_dec(vp[k]);
+      const bool arg = live && gp + (k < 4 ? 1.0 : PF_SQRT2) == gx;  // an argmin parent: its offer IS the label
+      const int pr = r + move_dr(k), pc = c + move_dc(k);
+      long dr_ = pr - tr, dc_ = pc - tc;
+      const double fp_ = VARIANT == 2 ? gp : gp + __builtin_sqrt((double)(dr_ * dr_ + dc_ * dc_));
+      const bool earlier = arg && (fp_ < F || fp_ == F) && (fp_ < fx || fp_ == fx);   // expanded, and popped before x (g(p) < g(x))
+      if (earlier && (best < 0 || key_lt(fp_, gp, p, bf, bg, bc))) { best = k; bf = fp_; bg = gp; bc = p; }
+    }
+    if (reg) { if (best < 0) bad = true; else M.par[x] = (unsigned char)opposite_move(best); }
+  }
+  if (__ballot(bad)) return PF_ST_SEQ;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  // ---- the path: parents from the goal (astar.py:65-69), then reverse in place ----
+  int n = 0, cell = target;
+  const int guard = RC;
+  while (cell != start) {
+    if (n >= out_cap - 1 || n > guard) return 3;
+    if (lane == 0) out[n] = cell;
+    const int mv = M.par[cell];
+    cell -= move_dr(mv) * C + move_dc(mv);
+    n += 1;
+  }
+  if (lane == 0) out[n] = start;
+  n += 1;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  for (int i = lane; i < n / 2; i += 64) { const int a = out[i], b = out[n - 1 - i]; out[i] = b; out[n - 1 - i] = a; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  out_n = n;
+  return 0;
+}
+
+}  // namespace pf

@@ -34,7 +34,8 @@ class MpaParams(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("pops", "pushes", "nbr_examined", "path_cells", "steps", "candidates",
-                                         "decrease_keys", "overflow_agents", "pruned_rebuilds")]
+                                         "decrease_keys", "overflow_agents", "pruned_rebuilds", "settled_searches",
+                                         "sequential_searches")]
 
 
 # every symbol include/pathfit.h declares: (name, restype, argtypes)

@@ -12,6 +12,23 @@ import golden_io as gio
 pytestmark = pytest.mark.gpu
 
 _eng = {}
+SEQ = True        # the closed-set searches run on the sequential pop loop: pop / push counters are the reference's
+
+
+@pytest.fixture(autouse=True, params=["sequential", "settle"])
+def closed_set_engine(request):
+    """Every test of this module runs twice: with the closed-set connector on the sequential pop loop (paths AND the
+    reference's pop / push counts are compared) and with the parallel label-settling engine in front of it (pf_settle.h:
+    paths and statuses are compared; its expansion counts are its own)."""
+    global SEQ
+    from pathfit.engine import Engine
+    import golden_io
+    e = eng("fig7")[0]
+    SEQ = request.param == "sequential"
+    e.set_option("astar_settle", 0 if SEQ else 1)
+    yield
+    e.set_option("astar_settle", 1)
+    SEQ = True
 
 
 def eng(name):
@@ -73,11 +90,10 @@ def test_astar_golden_both_variants():
                 assert st[j] != 3
                 assert np.array_equal(paths[j], want), (gname, variant, i)
                 if len(want) > 1:
-                    assert cnt[j, 0] == z["pops"][i], (gname, variant, i, cnt[j], z["pops"][i])
+                    assert (not SEQ and variant == 0) or cnt[j, 0] == z["pops"][i], (gname, variant, i, cnt[j], z["pops"][i])
                     # oracle cross-check of the counter definitions
                     _, ost = o.astar(int(z["start"][i]), int(z["target"][i]), avoid[j], variant)
-                    assert cnt[j, 1] == ost[1] == z["pushes"][i]
-                    assert cnt[j, 3] == ost[4]
+                    assert (not SEQ and variant == 0) or (cnt[j, 1] == ost[1] == z["pushes"][i] and cnt[j, 3] == ost[4])
 
 
 def test_dijkstra_golden_and_facade():
@@ -95,7 +111,7 @@ def test_dijkstra_golden_and_facade():
             want = gio.csr_get(z["path_off"], z["path"], i)
             assert st[j] != 3 and np.array_equal(paths[j], want), (gname, i)
             if len(want) > 1:
-                assert cnt[j, 0] == z["pops"][i] and cnt[j, 1] == z["pushes"][i], (gname, i, cnt[j], z["pops"][i], z["pushes"][i])
+                assert not SEQ or (cnt[j, 0] == z["pops"][i] and cnt[j, 1] == z["pushes"][i]), (gname, i, cnt[j], z["pops"][i], z["pushes"][i])
         if g.shape[0] <= 20:
             C = g.shape[1]
             d = pathfit.DijkstraSolver(g, engine=e)
@@ -123,8 +139,8 @@ def test_astar_random_512_vs_oracle():
             want, ost = o.astar(int(starts[i]), int(targets[i]), avoid[i], variant)
             assert st[i] != 3 and np.array_equal(paths[i], want), (variant, i)
             if len(want) > 1:
-                assert cnt[i, 0] == ost[0]
-        if variant == 0:
+                assert (not SEQ and variant == 0) or cnt[i, 0] == ost[0]
+        if variant == 0 and SEQ:
             assert cnt[0, 0] == 91044
 
 
@@ -189,7 +205,7 @@ def test_astar_clustered_heads_vs_oracle():
                     want, ost = o.astar(int(starts[i]), int(targets[i]), avoid[i], variant)
                     assert st[i] != 3 and np.array_equal(paths[i], want), (g.shape, variant, restrict, i)
                     if len(want) > 1:
-                        assert cnt[i, 0] == ost[0] and cnt[i, 1] == ost[1], (g.shape, variant, restrict, i, cnt[i], ost)
+                        assert (not SEQ and variant != 1) or (cnt[i, 0] == ost[0] and cnt[i, 1] == ost[1]), (g.shape, variant, restrict, i, cnt[i], ost)
         e.close()
 
 
@@ -208,12 +224,13 @@ def test_astar_open_map_plateaus_vs_oracle():
     for variant in (0, 1):
         paths, st, cnt = e.astar_host(variant, starts, targets, None, path_cap=16 * 2048, want_counters=True)
         assert (st == 0).all()
-        assert e.counters()["candidates"] > 0          # for A* calls: entries that went through the spill list
+        if SEQ or variant == 1:
+            assert e.counters()["candidates"] > 0      # for A* calls: entries that went through the spill list
         check = set(np.argsort(-cnt[:, 2])[:6].tolist()) | {0, 1, 2, 3}
         for i in sorted(check):
             want, ost = o.astar(int(starts[i]), int(targets[i]), None, variant)
             assert np.array_equal(paths[i], want), (variant, i)
-            assert cnt[i, 0] == ost[0]
+            assert (not SEQ and variant != 1) or cnt[i, 0] == ost[0]
     e.close()
 
 
