@@ -617,9 +617,9 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
         need = false;
       }
     }
-    if (!alive) continue;
-    bool done = (cr == tr && cc == tc) || steps >= max_steps;
-    if (!done) {
+    // (a group that has run out of ants stays in the loop, inert: the window rebuild below is a 64-lane job)
+    bool done = alive && ((cr == tr && cc == tc) || steps >= max_steps);
+    if (alive && !done) {
       const int cur = cr * C + cc;
       const int nr = cr + mdr, nc = cc + mdc;
       const bool inb = nr >= 0 && nr < R && nc >= 0 && nc < C;
@@ -710,8 +710,8 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
           const int l0 = __builtin_ctzll(em); em &= em - 1;          // lane 8 * g of the ant to serve (uniform)
           const int g_ = l0 >> 3;
           const int ar = bcast_i(cr, l0), ac = bcast_i(cc, l0), an = bcast_i(n, l0);
-          const int* apath = (const int*)first_u64((uint64_t)(bcast_i((int)((uint64_t)out & 0xFFFFFFFFull), l0) |
-                                                     ((uint64_t)(unsigned)bcast_i((int)((uint64_t)out >> 32), l0) << 32)));
+          const int* apath = (const int*)(((uint64_t)(unsigned)bcast_i((int)(unsigned)((uint64_t)out & 0xFFFFFFFFull), l0)) |
+                                          ((uint64_t)(unsigned)bcast_i((int)(unsigned)((uint64_t)out >> 32), l0) << 32));   // (both halves zero-extended)
           const int nr0 = ar - PF_WIN / 2, nc0 = ac - PF_WIN / 2;
           win[g_][lane] = 0ull;                                       // 64 lanes, 64 rows
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -726,7 +726,7 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
         }
       }
     }
-    if (done) {                                                     // emit, then fetch a new ant next round
+    if (alive && done) {                                            // emit, then fetch a new ant next round
       if (rc == 0 && !(cr == tr && cc == tc)) rc = 2;               // :301-302 step cap
       steps_tot += (unsigned long long)steps;
       if (k == 0) {
