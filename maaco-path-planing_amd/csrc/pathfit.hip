@@ -1841,7 +1841,8 @@ static int g_settle = env_int("PF_SETTLE", 1);   // closed-set searches try the 
 static double g_doubt_log = 1.0 / 8589934592.0;   // 2^-33 relative margin on normalvariate's accept test (pf_set_option "mpa_doubt_log_e15" overrides, in 1e-15)
 static double g_doubt_round = 1e-7;                // absolute margin on the fraction fed to round()   ("mpa_doubt_round_e15")
 static int g_maaco_pack8_min = env_int("PF_MAACO_PACK8_MIN", 2048);   // ants per batch from which 8 ants share a wavefront
-static int g_maaco_window = env_int("PF_MAACO_WINDOW", 1);           // 8-ants-per-wave walk: tabu set = LDS bitmap window (1) or HBM epoch stamps (0)
+static int g_maaco_window = env_int("PF_MAACO_WINDOW", 0);           // 8-ants-per-wave walk: tabu set = HBM epoch stamps (0, shipped) or an LDS bitmap window (1: exact, but measured
+                                                                      // 2.6x SLOWER on maaco512 -- 5.94 vs 2.28 ms -- because every recentring rebuilds the window from the path: DESIGN.md 5)
 static const int kLdsS = 16;
 static int ensure_slots(pf_handle* h, int allow_diag = 1, int restrict_corner = 1) {
   CK(hipSetDevice(h->device));
