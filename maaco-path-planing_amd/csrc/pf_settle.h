@@ -77,8 +77,7 @@ __device__ __forceinline__ int settle(const Grid& G, const Open& O, const Settle
     const double F = (vt >> 57) == code ? lab_dec(vt) : PF_INF;     // (h(goal) = 0: f = g)
     // ---- next non-empty bucket ----
     PF_LDS_ORDER();
-    int c0 = cnt[bcur & (NBK - 1)];
-    if (c0 == 0) {
+    if (cnt[bcur & (NBK - 1)] == 0) {
       int b0 = -1;
       for (int base = 0; base < NBK; base += 64) {
         const int c_ = cnt[(bcur + base + lane) & (NBK - 1)];
@@ -87,18 +86,39 @@ __device__ __forceinline__ int settle(const Grid& G, const Open& O, const Settle
       }
       if (b0 < 0) break;                                             // open list exhausted
       bcur = b0;
-      c0 = cnt[bcur & (NBK - 1)];
     }
     if (F != PF_INF && (double)bcur > F * PF_SW_Q) break;            // every remaining entry has f above the goal's
-    const int bi = bcur & (NBK - 1);
-    const int m = c0 < 64 ? c0 : 64;
-    PF_LDS_ORDER();
-    if (lane == 0) cnt[bi] = c0 - m;
-    PF_LDS_ORDER();
-    // ---- one entry per lane ----
+    // ---- one entry per lane: the whole buckets from bcur on that fit 64 lanes (a fixpoint does not care about the order,
+    // and one 1/64-wide band alone rarely holds 64 nodes), or 64 entries of the first one when it is larger ----
     double g = 0.0; int cell = 0;
-    bool have = lane < m;
-    if (have) { g = eg[(size_t)bi * CAP + c0 - m + lane]; cell = ec[(size_t)bi * CAP + c0 - m + lane]; }
+    bool have;
+    {
+      const int lim = F == PF_INF ? 0x7FFFFFFF : (int)(F * PF_SW_Q);  // last band that can hold a node of the region
+      const int cb = bcur + lane <= lim ? cnt[(bcur + lane) & (NBK - 1)] : 0;   // lane k: size of the k-th band from bcur
+      const int c0 = bcast_i(cb, 0);
+      if (c0 > 64) {
+        have = true;
+        g = eg[(size_t)(bcur & (NBK - 1)) * CAP + c0 - 64 + lane]; cell = ec[(size_t)(bcur & (NBK - 1)) * CAP + c0 - 64 + lane];
+        PF_LDS_ORDER();
+        if (lane == 0) cnt[bcur & (NBK - 1)] = c0 - 64;
+      } else {
+        const int incl = wave_incl_sum(cb);
+        const int k = __builtin_popcountll(__ballot(incl <= 64));     // (sizes are >= 0: the bands that fit are a prefix; k >= 1)
+        const int total = bcast_i(incl, k - 1);
+        int* mark = (int*)O.sx;
+        mark[lane] = 0;
+        PF_LDS_ORDER();
+        if (lane < k && cb > 0) mark[incl - cb] = lane;
+        PF_LDS_ORDER();
+        const int kk = wave_incl_max(mark[lane]);                      // my entry's band, counted from bcur
+        const int j = lane - bperm_i(kk, incl - cb);                    // ... and its index in that band
+        have = lane < total;
+        if (have) { const int bi = (bcur + kk) & (NBK - 1); g = eg[(size_t)bi * CAP + j]; cell = ec[(size_t)bi * CAP + j]; }
+        PF_LDS_ORDER();
+        if (lane < k) cnt[(bcur + lane) & (NBK - 1)] = 0;
+      }
+      PF_LDS_ORDER();
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");           // the entries are read before pushes may overwrite their slots
     unsigned long long own = 0; unsigned mm = 0;
     if (have) { own = __hip_atomic_load(&M.lab[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); mm = G.mm[cell]; }   // never a stale L1 copy: a live entry must not be skipped

