@@ -1837,7 +1837,8 @@ static int env_int(const char* name, int dflt) { const char* v = getenv(name); r
 static const int kSlotsPerCU = 8;                       // resident one-agent waves per CU at most
 static const int kWavesPerCU = env_int("PF_WAVES_PER_CU", 8);   // resident one-agent waves per CU (LDS permitting)
 static int g_mpa_prune = 1;   // exact bound pruning of MPA rebuilds (pf_set_option "mpa_prune")
-static int g_settle = env_int("PF_SETTLE", 1);   // closed-set searches try the 64-nodes-per-trip engine first (pf_set_option "astar_settle")
+static int g_settle = env_int("PF_SETTLE", 0);   // 1: closed-set searches try the 64-nodes-per-trip engine first (pf_set_option "astar_settle").  Exact (zero mismatches in
+                                                  // every parity test and soak run) but not yet faster as one wave per search inside the 210-VGPR kernels: off by default
 static double g_doubt_log = 1.0 / 8589934592.0;   // 2^-33 relative margin on normalvariate's accept test (pf_set_option "mpa_doubt_log_e15" overrides, in 1e-15)
 static double g_doubt_round = 1e-7;                // absolute margin on the fraction fed to round()   ("mpa_doubt_round_e15")
 static int g_maaco_pack8_min = env_int("PF_MAACO_PACK8_MIN", 2048);   // ants per batch from which 8 ants share a wavefront
