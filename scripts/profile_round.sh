@@ -1,24 +1,27 @@
 #!/bin/bash
 # One round of profiling runs on the GPU box (run through gpurun from the repo root):
-#   bash scripts/profile_round.sh gpurun_out/prof_r01k
+#   bash scripts/profile_round.sh gpurun_out/prof_r02 [workloads...]
 # per workload: rocprofv3 --kernel-trace --stats, --pmc FETCH_SIZE, --pmc WRITE_SIZE (separate passes, as
-# MI355X_MICROARCH.md prescribes) and the unprofiled bench line; scripts/make_traffic.py turns them into
-# profiles/r01_traffic.json + profiles/r01_<workload>_kernel_stats.csv.
-set -e -o pipefail
-OUT=$(realpath "$1"); mkdir -p "$OUT"
+# MI355X_MICROARCH.md prescribes: the two do not fit one pass) and the unprofiled bench line; scripts/make_traffic.py turns
+# them into profiles/r02_traffic.json + profiles/r02_<workload>_kernel_stats.csv.  The program goes straight after `--`
+# (python3 itself: no env / bash -c hop, the profiler's preload has already initialised the GPU).
+set -o pipefail
+OUT=$(realpath "$1"); shift; mkdir -p "$OUT"
+WL=${@:-mpa512 maaco512 maaco128 maaco1024 ga512 pso512 astar1024}
 ROOT=$(pwd)
 export TMPDIR=/tmp
 cd /tmp
-for W in mpa512 maaco512; do
-  timeout -k 10 200 python3 "$ROOT/bench.py" --workload $W --no-cpu > "$OUT/${W}_bench.json" 2> "$OUT/${W}_bench.err"
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${W}_stats" -- python3 "$ROOT/bench.py" --workload $W --no-cpu > "$OUT/${W}_stats.log" 2>&1
-  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/${W}_fetch" -- python3 "$ROOT/bench.py" --workload $W --no-cpu > "$OUT/${W}_fetch.log" 2>&1
-  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/${W}_write" -- python3 "$ROOT/bench.py" --workload $W --no-cpu > "$OUT/${W}_write.log" 2>&1
+for W in $WL; do
+  case $W in mpa512) ST="--steps 6 --warmup 1";; ga512|astar1024) ST="--steps 2 --warmup 1";; pso512) ST="--steps 2 --warmup 1";; *) ST="--steps 6 --warmup 2";; esac
+  timeout -k 10 200 python3 "$ROOT/bench.py" --workload $W --no-cpu --no-extra $ST > "$OUT/${W}_bench.json" 2> "$OUT/${W}_bench.err" || { echo "$W bench failed"; exit 1; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${W}_stats" -- python3 "$ROOT/bench.py" --workload $W --no-cpu --no-extra $ST > "$OUT/${W}_stats.log" 2>&1 || { echo "$W stats failed"; exit 1; }
+  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/${W}_fetch" -- python3 "$ROOT/bench.py" --workload $W --no-cpu --no-extra $ST > "$OUT/${W}_fetch.log" 2>&1 || { echo "$W fetch failed"; exit 1; }
+  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/${W}_write" -- python3 "$ROOT/bench.py" --workload $W --no-cpu --no-extra $ST > "$OUT/${W}_write.log" 2>&1 || { echo "$W write failed"; exit 1; }
   echo "$W done"
 done
 # keep the merge-back small: drop everything but the CSVs the summary needs
 find "$OUT" -type f \( -name '*.db' -o -name '*kernel_trace.csv' -o -name '*agent_info.csv' \) -delete
 cd "$ROOT"
 python3 scripts/make_traffic.py "$OUT" > "$OUT/traffic_summary.log" 2>&1 || true
-cp profiles/r01_traffic.json profiles/r01_mpa512_kernel_stats.csv profiles/r01_maaco512_kernel_stats.csv "$OUT/" 2>/dev/null || true
-tail -40 "$OUT/traffic_summary.log"
+cp profiles/r02_traffic.json profiles/r02_*_kernel_stats.csv "$OUT/" 2>/dev/null || true
+tail -60 "$OUT/traffic_summary.log"
