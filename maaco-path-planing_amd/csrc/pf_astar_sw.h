@@ -151,16 +151,27 @@ PF_DEV void geo_to_lds(char* smem, int lane) {
 }
 
 #define PF_SW_SPILL 16384
+// A pool entry is 16 bytes: (g, packed cell).  Its f is not stored: f = g + h(cell) is the very fp64 operation that
+// produced it when the entry was pushed (astar.py:90 / MPA.py:140), so reading an entry back recomputes it bit for bit
+// -- one 16-byte store per push and one 16-byte load per refilled entry instead of three scattered ones each
+// (sector traffic: VERDICT r01 item 3).
+struct __attribute__((aligned(16))) PoolEnt { double g; int c; int pad; };
 struct SwPool {
   int* cnt;      // LDS [NBK + 1] entries per bucket; bucket NBK is the FRONT bucket: entries above the window's limit
                  // but below every regular bucket (window evictions, late low pushes of MPA._a_star's stale pops)
-  double* bf;    // HBM [(NBK + 1)*CAP]
-  double* bg;
-  int* bc;
-  double* sf;    // HBM [PF_SW_SPILL] spill list: entries whose bucket was full (a plateau of near-equal f on open maps)
-  double* sg;    //   or beyond the circular range; every refill offers them to the window / their bucket again
-  int* sc;
+  PoolEnt* be;   // HBM [(NBK + 1)*CAP]
+  PoolEnt* se;   // HBM [PF_SW_SPILL] spill list: entries whose bucket was full (a plateau of near-equal f on open maps)
+                 //   or beyond the circular range; every refill offers them to the window / their bucket again
+  int tr, tc;    // the goal (for h)
+  bool hzero;    // Dijkstra: f = g
 };
+PF_DEV void ent_put(PoolEnt* e, double g, int c) { PoolEnt v; v.g = g; v.c = c; v.pad = 0; *e = v; }
+PF_DEV void ent_get(const SwPool& P, const PoolEnt* e, double& f, double& g, int& c) {
+  const PoolEnt v = *e;
+  g = v.g; c = v.c;
+  const int dr = (v.c >> 16) - P.tr, dc = (v.c & 0xFFFF) - P.tc;
+  f = P.hzero ? v.g : v.g + __builtin_sqrt((double)(dr * dr + dc * dc));
+}
 // append one entry (uniform values): to the front bucket when it sorts before every regular bucket (f below the
 // boundary of bucket bcur), else to its f bucket, else (bucket full / out of range) to the spill list;
 // false only when the spill list is full too
@@ -171,11 +182,11 @@ PF_DEV bool pool_put1(const SwPool& P, double f, double g, int c, int bcur, int&
   const int n = P.cnt[b];
   if (n >= PF_SW_CAP || ba - bcur >= PF_SW_NBK) {
     if (n_spill >= PF_SW_SPILL) return false;
-    if (lane == 0) { P.sf[n_spill] = f; P.sg[n_spill] = g; P.sc[n_spill] = c; }
+    if (lane == 0) ent_put(P.se + n_spill, g, c);
     n_spill += 1;
     return true;
   }
-  if (lane == 0) { P.bf[b * PF_SW_CAP + n] = f; P.bg[b * PF_SW_CAP + n] = g; P.bc[b * PF_SW_CAP + n] = c; P.cnt[b] = n + 1; }
+  if (lane == 0) { ent_put(P.be + b * PF_SW_CAP + n, g, c); P.cnt[b] = n + 1; }
   PF_LDS_ORDER();
   return true;
 }
@@ -231,7 +242,7 @@ PF_DEV bool respill(const SwPool& P, SwWin& W, int lane) {
   for (int base = 0; base < n; base += 64) {
     const int m = n - base < 64 ? n - base : 64;
     double ef = 0.0, eg = 0.0; int ec = 0;
-    if (lane < m) { ef = P.sf[base + lane]; eg = P.sg[base + lane]; ec = P.sc[base + lane]; }
+    if (lane < m) ent_get(P, P.se + base + lane, ef, eg, ec);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       // read this chunk before re-spilled entries overwrite it
 #if PF_PLATEAU
     // An entry that is neither below the limit nor offered room by its bucket stays spilled: on a plateau that is nearly
@@ -244,7 +255,7 @@ PF_DEV bool respill(const SwPool& P, SwWin& W, int lane) {
     const unsigned long long sm = __ballot(stays);
     if (stays) {
       const int at = W.n_spill + __builtin_popcountll(sm & ((1ull << lane) - 1ull));   // (<= base + lane: in place)
-      P.sf[at] = ef; P.sg[at] = eg; P.sc[at] = ec;
+      ent_put(P.se + at, eg, ec);
     }
     W.n_spill += __builtin_popcountll(sm); W.n_pool += __builtin_popcountll(sm);
     for (unsigned long long rest = __ballot(lane < m && !stays); rest; rest &= rest - 1) {
@@ -277,7 +288,8 @@ PF_DEV bool respill(const SwPool& P, SwWin& W, int lane) {
 PF_DEV int take_smallest_select(const SwPool& P, char* lds, int bi, int c0, double& wf, double& wg, int& wc, int lane) {
   constexpr int CAP = PF_SW_CAP;
   double* sf = (double*)(lds + PF_SEL_LDS); double* sg = sf + 64; int* sc = (int*)(sg + 64);
-  double pf_ = P.bf[bi * CAP + lane], pg_ = P.bg[bi * CAP + lane]; int pc_ = P.bc[bi * CAP + lane];   // sample: the first 64 entries
+  double pf_, pg_; int pc_;
+  ent_get(P, P.be + bi * CAP + lane, pf_, pg_, pc_);                    // sample: the first 64 entries
   sort_lanes(pf_, pg_, pc_, lane, 64);
   int r = (64 * 64) / c0; r = r < 1 ? 1 : (r > 63 ? 63 : r);           // about 64 keys of the bucket lie below the sample's r-th
   double vf = 0.0, vg = 0.0; int vc = 0, cnt = 0;
@@ -287,7 +299,7 @@ PF_DEV int take_smallest_select(const SwPool& P, char* lds, int bi, int c0, doub
     for (int rd = 0; rd < c0; rd += 64) {
       const bool in = rd + lane < c0;
       double ef = PF_INF, eg = 0.0; int ec = 0;
-      if (in) { ef = P.bf[bi * CAP + rd + lane]; eg = P.bg[bi * CAP + rd + lane]; ec = P.bc[bi * CAP + rd + lane]; }
+      if (in) ent_get(P, P.be + bi * CAP + rd + lane, ef, eg, ec);
       cnt += __builtin_popcountll(__ballot(in && key_lt(ef, eg, ec, vf, vg, vc)));
     }
     if (cnt <= 64) break;                                               // (cnt >= r >= 1: the sample keys below the pivot)
@@ -298,12 +310,12 @@ PF_DEV int take_smallest_select(const SwPool& P, char* lds, int bi, int c0, doub
   for (int rd = 0; rd < c0; rd += 64) {
     const bool in = rd + lane < c0;
     double ef = PF_INF, eg = 0.0; int ec = 0;
-    if (in) { ef = P.bf[bi * CAP + rd + lane]; eg = P.bg[bi * CAP + rd + lane]; ec = P.bc[bi * CAP + rd + lane]; }
+    if (in) ent_get(P, P.be + bi * CAP + rd + lane, ef, eg, ec);
     const bool below = in && key_lt(ef, eg, ec, vf, vg, vc);
     const unsigned long long bm = __ballot(below), km = __ballot(in && !below);
     const unsigned long long lo = (1ull << lane) - 1ull;
     if (below) { const int at = sel + __builtin_popcountll(bm & lo); sf[at] = ef; sg[at] = eg; sc[at] = ec; }
-    if (in && !below) { const int at = wr + __builtin_popcountll(km & lo); P.bf[bi * CAP + at] = ef; P.bg[bi * CAP + at] = eg; P.bc[bi * CAP + at] = ec; }
+    if (in && !below) { const int at = wr + __builtin_popcountll(km & lo); ent_put(P.be + bi * CAP + at, eg, ec); }
     sel += __builtin_popcountll(bm); wr += __builtin_popcountll(km);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");             // write-back before the next chunk is read
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -320,13 +332,13 @@ PF_DEV int take_smallest_select(const SwPool& P, char* lds, int bi, int c0, doub
 
 PF_DEV void take_smallest64(const SwPool& P, int bi, int c0, double& wf, double& wg, int& wc, int lane) {
   constexpr int CAP = PF_SW_CAP;
-  wf = P.bf[bi * CAP + lane]; wg = P.bg[bi * CAP + lane]; wc = P.bc[bi * CAP + lane];
+  ent_get(P, P.be + bi * CAP + lane, wf, wg, wc);
   sort_lanes(wf, wg, wc, lane, 64);
   int wr = 0;
   for (int rd = 64; rd < c0; rd += 64) {
     const int m = c0 - rd < 64 ? c0 - rd : 64;
     double cf = PF_INF, cg = 0.0; int cc = 0;
-    if (lane < m) { cf = P.bf[bi * CAP + rd + lane]; cg = P.bg[bi * CAP + rd + lane]; cc = P.bc[bi * CAP + rd + lane]; }
+    if (lane < m) ent_get(P, P.be + bi * CAP + rd + lane, cf, cg, cc);
     sort_lanes(cf, cg, cc, lane, 64);
     const double rf = bperm_d(63 - lane, cf), rg = bperm_d(63 - lane, cg);   // chunk reversed: window ++ reversed chunk is bitonic
     const int rc_ = bperm_i(63 - lane, cc);
@@ -338,7 +350,7 @@ PF_DEV void take_smallest64(const SwPool& P, int bi, int c0, double& wf, double&
     const unsigned long long fin = __ballot(hf != PF_INF);
     if (hf != PF_INF) {
       const int at = wr + __builtin_popcountll(fin & ((1ull << lane) - 1ull));
-      P.bf[bi * CAP + at] = hf; P.bg[bi * CAP + at] = hg; P.bc[bi * CAP + at] = hc;
+      ent_put(P.be + bi * CAP + at, hg, hc);
     }
     wr += __builtin_popcountll(fin);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                   // write-back before the next chunk is read
@@ -374,8 +386,8 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
   constexpr int NBK = PF_SW_NBK, CAP = PF_SW_CAP;
   const int C = G.C, RC = G.R * G.C;
   SwPool P;
-  P.cnt = (int*)O.lf; P.bf = O.of; P.bg = P.bf + (NBK + 1) * CAP; P.bc = (int*)(P.bg + (NBK + 1) * CAP);
-  P.sf = (double*)(P.bc + (NBK + 1) * CAP); P.sg = P.sf + PF_SW_SPILL; P.sc = (int*)(P.sg + PF_SW_SPILL);
+  P.cnt = (int*)O.lf; P.be = (PoolEnt*)O.of; P.se = P.be + (NBK + 1) * CAP;
+  P.tr = tr; P.tc = tc; P.hzero = VARIANT == 2;
   for (int k = lane; k <= NBK; k += 64) P.cnt[k] = 0;
   PF_LDS_ORDER();
 
@@ -431,7 +443,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
           double nf = PF_INF, ng = 0.0; int nc = 0;
           if (lane < total) {
             const int bi = (b0 + kk) & (NBK - 1);
-            nf = P.bf[bi * CAP + j]; ng = P.bg[bi * CAP + j]; nc = P.bc[bi * CAP + j];
+            ent_get(P, P.be + bi * CAP + j, nf, ng, nc);
           }
           if (lane < k) P.cnt[(b0 + lane) & (NBK - 1)] = 0;
           int live = total;
@@ -457,7 +469,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
       W.wf = PF_INF; W.wg = 0.0; W.wc = 0;
       if (cF > 0) {
         if (cF <= 64) {
-          if (lane < cF) { W.wf = P.bf[NBK * CAP + lane]; W.wg = P.bg[NBK * CAP + lane]; W.wc = P.bc[NBK * CAP + lane]; }
+          if (lane < cF) ent_get(P, P.be + NBK * CAP + lane, W.wf, W.wg, W.wc);
           if (lane == 0) P.cnt[NBK] = 0;
           int live = cF;
           if (SEM == 0) live = drop_superseded(rec, C, W.wf, W.wg, W.wc);
@@ -490,7 +502,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
           // spilled key, which brings the entries that were beyond it back in range
           unsigned minb = 0xFFFFFFFFu;
           for (int base = 0; base < W.n_spill; base += 64)
-            if (base + lane < W.n_spill) { const unsigned b_ = (unsigned)(int)(P.sf[base + lane] * PF_SW_Q); minb = b_ < minb ? b_ : minb; }
+            if (base + lane < W.n_spill) { double f_, g_; int c_; ent_get(P, P.se + base + lane, f_, g_, c_); const unsigned b_ = (unsigned)(int)(f_ * PF_SW_Q); minb = b_ < minb ? b_ : minb; }
           minb = wave_min_u32(minb);
           if ((int)minb > W.bcur) { W.bcur = (int)minb; W.lf = (double)W.bcur * (1.0 / PF_SW_Q); W.lg = -PF_INF; W.lc = 0; }
           if (!respill(P, W, lane)) { status = 3; break; }
@@ -513,7 +525,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
           const int j = lane - bperm_i(kk, incl - cb);                    // ... and its index in that bucket
           if (lane < total) {
             const int bi = (b0 + kk) & (NBK - 1);
-            W.wf = P.bf[bi * CAP + j]; W.wg = P.bg[bi * CAP + j]; W.wc = P.bc[bi * CAP + j];
+            ent_get(P, P.be + bi * CAP + j, W.wf, W.wg, W.wc);
           }
           if (lane < k) P.cnt[(b0 + lane) & (NBK - 1)] = 0;
           int live = total;
@@ -777,13 +789,13 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     SW_T(t6)
     {
       const bool fits = inrange && pat < CAP;
-      if (top && fits) { P.bf[pb * CAP + pat] = fnew; P.bg[pb * CAP + pat] = tent; P.bc[pb * CAP + pat] = nrc; }
+      if (top && fits) ent_put(P.be + pb * CAP + pat, tent, nrc);
       const unsigned long long sm = __ballot(top && !fits);     // bucket full or beyond the circular range: spill list
       if (sm) {
         if (top && !fits) {
           if (inrange) __hip_atomic_fetch_add(&P.cnt[pb], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // a number past the end: give it back
           const int at = W.n_spill + __builtin_popcountll(sm & ((1ull << lane) - 1ull));
-          if (at < PF_SW_SPILL) { P.sf[at] = fnew; P.sg[at] = tent; P.sc[at] = nrc; }
+          if (at < PF_SW_SPILL) ent_put(P.se + at, tent, nrc);
         }
         W.n_spill += __builtin_popcountll(sm);
         st.spills += (unsigned)__builtin_popcountll(sm);
