@@ -88,6 +88,9 @@ int pf_device_count(void);
  * (helper.py:121-125).  device: HIP ordinal. */
 int pf_create(const uint8_t* grid, int32_t R, int32_t C, int32_t device, pf_handle** out);
 void pf_destroy(pf_handle* h);
+/* Dynamic maps: replace the occupancy of an existing handle (same R x C, same cell values as pf_create).  The grid
+ * preparation runs again on the device; call pf_maaco_setup / pf_mpa_setup again before the next solver batch. */
+int pf_update_grid(pf_handle* h, const uint8_t* grid);
 const char* pf_last_error(pf_handle* h); /* h may be NULL for create errors */
 /* the handle's HIP stream (hipStream_t) so callers can order their own work */
 void* pf_stream(pf_handle* h);

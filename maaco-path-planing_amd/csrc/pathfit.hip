@@ -110,8 +110,10 @@ PF_DEV void flush_counters(DevCounters* c, const AStat& st, unsigned long long c
 // K0: grid preparation
 // ===========================================================================
 // static move masks (helper.py:38-52 order) for restrict on/off, and the clipped
-// squared distance to the nearest obstacle inside a radius-7 window.
-__global__ void k_grid_prep(const uint8_t* occ, int R, int C, uint8_t* mm_r1, uint8_t* mm_r0, uint8_t* d2near) {
+// squared distance to the nearest obstacle inside a window of radius `rad` (7: every min_safe_distance up to 7; 15: up to
+// 15.9, the largest distance whose square fits the u8 table -- helper.py:67-80 only ever needs obstacles closer than
+// min_safe_distance).
+__global__ void k_grid_prep(const uint8_t* occ, int R, int C, uint8_t* mm_r1, uint8_t* mm_r0, uint8_t* d2near, int rad) {
   int cell = blockIdx.x * blockDim.x + threadIdx.x;
   if (cell >= R * C) return;
   int r = cell / C, c = cell % C;
@@ -125,7 +127,7 @@ __global__ void k_grid_prep(const uint8_t* occ, int R, int C, uint8_t* mm_r1, ui
   }
   mm_r1[cell] = (uint8_t)m1; mm_r0[cell] = (uint8_t)m0;
   int best = 255;
-  for (int dr = -7; dr <= 7; ++dr) for (int dc = -7; dc <= 7; ++dc) {
+  for (int dr = -rad; dr <= rad; ++dr) for (int dc = -rad; dc <= rad; ++dc) {
     int rr = r + dr, cc = c + dc;
     if (rr < 0 || rr >= R || cc < 0 || cc >= C || occ[rr * C + cc] != 1) continue;
     int d2 = dr * dr + dc * dc;
@@ -1639,6 +1641,7 @@ struct pf_handle {
   pf_counters last = {};
   double* d_pen = nullptr;
   double pen_min_safe = -1.0;
+  int edt_radius = 7;      // radius of the obstacle-distance window d2near was built with
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_ms = 0.f;
   std::string err;
@@ -1791,7 +1794,7 @@ int pf_create(const uint8_t* grid, int32_t R, int32_t C, int32_t device, pf_hand
   CKC(hipMalloc(&h->d_mm_r1_nd, h->RC)); CKC(hipMalloc(&h->d_mm_r0_nd, h->RC)); CKC(hipMalloc(&h->d_d2near, h->RC));
   CKC(hipMemcpyAsync(h->d_occ, h->h_occ.data(), h->RC, hipMemcpyHostToDevice, h->stream));
   const int nb = (h->RC + 255) / 256;
-  k_grid_prep<<<nb, 256, 0, h->stream>>>(h->d_occ, R, C, h->d_mm_r1, h->d_mm_r0, h->d_d2near);
+  k_grid_prep<<<nb, 256, 0, h->stream>>>(h->d_occ, R, C, h->d_mm_r1, h->d_mm_r0, h->d_d2near, 7);
   k_and_mask<<<nb, 256, 0, h->stream>>>(h->d_mm_r1_nd, h->d_mm_r1, h->RC, 0x0Fu);
   k_and_mask<<<nb, 256, 0, h->stream>>>(h->d_mm_r0_nd, h->d_mm_r0, h->RC, 0x0Fu);
   CKC(hipMalloc(&h->d_work, sizeof(int)));
@@ -1817,6 +1820,29 @@ void pf_destroy(pf_handle* h) {
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
+}
+
+// Dynamic maps: replace the occupancy of an existing handle (same R x C).  K0 runs again on the
+// device (move masks, obstacle distances), everything derived from the old map is dropped (component labels, the
+// search records' embedded masks, MPA's initial path and distance bounds are rebuilt by the next pf_mpa_setup).
+int pf_update_grid(pf_handle* h, const uint8_t* grid) {
+  if (!h) return -2;
+  if (!grid) return failmsg(h, "pf_update_grid: bad arguments");
+  CK(hipSetDevice(h->device));
+  for (int i = 0; i < h->RC; ++i) h->h_occ[i] = grid[i] == 1 ? 1 : 0;
+  CK(hipMemcpyAsync(h->d_occ, h->h_occ.data(), h->RC, hipMemcpyHostToDevice, h->stream));
+  const int nb = (h->RC + 255) / 256;
+  k_grid_prep<<<nb, 256, 0, h->stream>>>(h->d_occ, h->R, h->C, h->d_mm_r1, h->d_mm_r0, h->d_d2near, h->edt_radius);
+  k_and_mask<<<nb, 256, 0, h->stream>>>(h->d_mm_r1_nd, h->d_mm_r1, h->RC, 0x0Fu);
+  k_and_mask<<<nb, 256, 0, h->stream>>>(h->d_mm_r0_nd, h->d_mm_r0, h->RC, 0x0Fu);
+  CK(hipGetLastError());
+  CK(hipStreamSynchronize(h->stream));
+  for (int k = 0; k < 4; ++k) if (h->d_comp[k]) { (void)hipFree(h->d_comp[k]); h->d_comp[k] = nullptr; }
+  h->rec_policy = -1;                                               // the records embed the old move masks
+  h->mpa_ready = false; h->maaco_ready = false;                     // their tables (initial path, bounds, tau / eta) belong to the old map
+  if (h->d_ds) { (void)hipFree(h->d_ds); h->d_ds = nullptr; }
+  if (h->d_dt) { (void)hipFree(h->d_dt); h->d_dt = nullptr; }
+  return 0;
 }
 
 int pf_dev_alloc(pf_handle* h, int64_t bytes, void** d_out) { CK(hipSetDevice(h->device)); CK(hipMalloc(d_out, (size_t)(bytes > 0 ? bytes : 1))); return 0; }
@@ -1954,7 +1980,13 @@ static int launch_with_retry(pf_handle* h, Kern kern, KArgs& args, int n) {
 }
 
 static int ensure_pen(pf_handle* h, double min_safe) {
-  if (min_safe > 7.0) return failmsg(h, "min_safe_distance > 7 is not supported (obstacle-distance window radius is 7)");
+  if (min_safe > 15.9) return failmsg(h, "min_safe_distance > 15.9 is not supported (squared obstacle distances are kept in a u8 table)");
+  if (min_safe > (double)h->edt_radius) {                           // widen the obstacle-distance window once (K0 again, radius 15)
+    CK(hipSetDevice(h->device));
+    k_grid_prep<<<(h->RC + 255) / 256, 256, 0, h->stream>>>(h->d_occ, h->R, h->C, h->d_mm_r1, h->d_mm_r0, h->d_d2near, 15);
+    CK(hipGetLastError());
+    h->edt_radius = 15; h->pen_min_safe = -1.0;
+  }
   if (h->pen_min_safe == min_safe) return 0;
   double pen[256];
   for (int d2 = 0; d2 < 256; ++d2) {

@@ -45,6 +45,7 @@ SYMBOLS = {
     "pf_device_count": (C.c_int, []),
     "pf_create": (C.c_int, [_vp, _i32, _i32, _i32, C.POINTER(_vp)]),
     "pf_destroy": (None, [_vp]),
+    "pf_update_grid": (C.c_int, [_vp, _vp]),
     "pf_last_error": (C.c_char_p, [_vp]),
     "pf_stream": (_vp, [_vp]),
     "pf_sync": (C.c_int, [_vp]),

@@ -110,6 +110,14 @@ class Engine:
         self.device = int(device)
         self.klog = None          # a list: every hot-path launch appends (kernel family, its HIP-event ms, its counters)
 
+    def update_grid(self, grid):
+        """Dynamic maps: replace the occupancy (same shape); solvers built on the old map must be set up again."""
+        g = np.ascontiguousarray(np.asarray(grid), dtype=np.int64)
+        if g.shape != (self.R, self.C):
+            raise ValueError("update_grid: the new grid must have the handle's shape")
+        self.grid_u8 = np.ascontiguousarray(np.clip(g, 0, 255).astype(np.uint8))
+        self._ck(self.L.pf_update_grid(self.h, self.grid_u8.ctypes.data))
+
     def close(self):
         if getattr(self, "h", None):
             self.L.pf_destroy(self.h)

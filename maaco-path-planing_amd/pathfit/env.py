@@ -49,6 +49,73 @@ def random_blocks(R, C, density=0.2, seed=0, block=(2, 6), start=None, target=No
     return mark(occ, s, t)
 
 
+def grid_from_image(image, size=None, obstacle_below=0.5, invert=False, start=None, target=None):
+    """An occupancy grid from an image, the way the reference's `grid_map_from_image_data*` literals (env.py:46-114) were
+    made: dark pixels are obstacles.  `image`: a 2-D / 3-D array (grey, RGB or RGBA; uint8 or float), or a file name --
+    `.npy`, binary / ASCII PGM or PPM are read with numpy alone, anything else through matplotlib.image.imread if
+    matplotlib is importable.  `size` = (R, C) resamples by block-wise minimum for downscaling (an obstacle anywhere in a
+    block keeps the cell blocked) or nearest neighbour for upscaling.  Returns the marked int64 grid (S = (0,0), T =
+    (R-1,C-1) by default; both cells are forced free)."""
+    if isinstance(image, str):
+        image = _read_image(image)
+    a = np.asarray(image)
+    if a.ndim == 3:
+        a = a[..., :3].astype(np.float64).mean(axis=2)
+    a = a.astype(np.float64)
+    if a.max() > 1.0:
+        a = a / 255.0
+    if invert:
+        a = 1.0 - a
+    if size is not None:
+        R, C = int(size[0]), int(size[1])
+        ri = (np.arange(R + 1) * a.shape[0]) // R
+        ci = (np.arange(C + 1) * a.shape[1]) // C
+        if R <= a.shape[0] and C <= a.shape[1]:
+            a = np.array([[a[ri[i]:max(ri[i + 1], ri[i] + 1), ci[j]:max(ci[j + 1], ci[j] + 1)].min() for j in range(C)] for i in range(R)])
+        else:
+            a = a[np.minimum(ri[:-1], a.shape[0] - 1)][:, np.minimum(ci[:-1], a.shape[1] - 1)]
+    occ = (a < obstacle_below).astype(np.int64)
+    R, C = occ.shape
+    s = start or (0, 0)
+    t = target or (R - 1, C - 1)
+    occ[tuple(s)] = 0
+    occ[tuple(t)] = 0
+    return mark(occ, s, t)
+
+
+def _read_image(path):
+    if path.endswith(".npy"):
+        return np.load(path, allow_pickle=False)
+    with open(path, "rb") as f:
+        head = f.read(2)
+        if head in (b"P2", b"P3", b"P5", b"P6"):
+            data = head + f.read()
+            toks, pos = [], 2
+            while len(toks) < 3:                                   # width, height, maxval (comments allowed)
+                while data[pos:pos + 1].isspace():
+                    pos += 1
+                if data[pos:pos + 1] == b"#":
+                    pos = data.index(b"\n", pos) + 1
+                    continue
+                end = pos
+                while not data[end:end + 1].isspace():
+                    end += 1
+                toks.append(int(data[pos:end])); pos = end
+            w, h_, mx = toks
+            ch = 3 if head in (b"P3", b"P6") else 1
+            if head in (b"P5", b"P6"):
+                arr = np.frombuffer(data[pos + 1:], np.uint8 if mx < 256 else ">u2", count=w * h_ * ch)
+            else:
+                arr = np.array(data[pos:].split(), np.int64)[: w * h_ * ch]
+            arr = arr.reshape((h_, w, ch) if ch == 3 else (h_, w)).astype(np.float64) / mx
+            return arr
+    try:
+        import matplotlib.image as mpimg
+    except Exception as e:                                         # pragma: no cover
+        raise ValueError(f"grid_from_image: cannot read {path!r} without matplotlib ({e})")
+    return mpimg.imread(path)
+
+
 def grid_hash(grid):
     g = np.ascontiguousarray(np.asarray(grid), np.uint8)
     return hashlib.sha256(bytes(g.shape[0].to_bytes(4, "little")) + bytes(g.shape[1].to_bytes(4, "little")) + g.tobytes()).hexdigest()

@@ -23,13 +23,26 @@ def match(name, kern):
     return kern in name
 
 
-def pmc(dirname, counter, kern):
-    tot, calls = 0.0, set()
+def pmc(dirname, counter, kern, last):
+    """Sum of `counter` over the LAST `last` dispatches of the kernel (the timed region of the same command) -> (sum, n)."""
+    per = {}
     for f in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if match(r["Kernel_Name"], kern) and r["Counter_Name"] == counter:
-                tot += float(r["Counter_Value"]); calls.add(r["Dispatch_Id"])
-    return tot, len(calls)
+                per[int(r["Dispatch_Id"])] = per.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
+    ids = sorted(per)[-last:] if last else sorted(per)
+    return sum(per[i] for i in ids), len(ids)
+
+
+def timed_avg_ms(d, w, kern, last):
+    """Average duration of the last `last` dispatches of the kernel in the --kernel-trace run (= the timed region)."""
+    f = os.path.join(d, w + "_dominant_trace.csv")
+    if not os.path.exists(f):
+        return None
+    rows = [r for r in csv.DictReader(open(f)) if match(r["Kernel_Name"], kern)]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    rows = rows[-last:] if last else rows
+    return sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows) / max(len(rows), 1) / 1e6
 
 
 for w, k in KERN.items():
@@ -40,13 +53,16 @@ for w, k in KERN.items():
     if not rows:
         continue
     calls = sum(int(r["Calls"]) for r in rows); tot_ns = sum(float(r["TotalDurationNs"]) for r in rows)
-    fetch, nf = pmc(os.path.join(d, w + "_fetch"), "FETCH_SIZE", k)
-    write, nw = pmc(os.path.join(d, w + "_write"), "WRITE_SIZE", k)
     bench = json.loads(open(os.path.join(d, w + "_bench.json")).read().strip().splitlines()[-1])
-    fb, wb = fetch * 1024 / max(nf, 1), write * 1024 / max(nw, 1)
     roof = bench["roofline"]
-    # the stats run covers warm-up and set-up launches too: its average is over all launches of the kernel
-    out[w] = {"kernel": roof["kernel"], "calls": calls, "avg_ms_rocprof": tot_ns / max(calls, 1) / 1e6,
+    last = int(roof.get("launches", 0))                     # launches of the timed region: the last ones of the process
+    fetch, nf = pmc(os.path.join(d, w + "_fetch"), "FETCH_SIZE", k, last)
+    write, nw = pmc(os.path.join(d, w + "_write"), "WRITE_SIZE", k, last)
+    fb, wb = fetch * 1024 / max(nf, 1), write * 1024 / max(nw, 1)
+    tavg = timed_avg_ms(d, w, k, last)
+    # the --stats summary covers warm-up and set-up launches too; avg_ms_rocprof is over the timed region's dispatches
+    out[w] = {"kernel": roof["kernel"], "calls_all": calls, "avg_ms_rocprof_all_launches": tot_ns / max(calls, 1) / 1e6,
+              "timed_launches": last, "avg_ms_rocprof": tavg if tavg is not None else tot_ns / max(calls, 1) / 1e6,
               "bench_avg_launch_ms": roof["avg_launch_ms"], "bench_value": bench["value"], "bench_ms_per_step": bench["ms_per_step"],
               "FETCH_SIZE_bytes_per_launch_raw": fb, "WRITE_SIZE_bytes_per_launch": wb,
               "traffic_bytes_per_launch": 2 * fb + wb,

@@ -19,7 +19,21 @@ for W in $WL; do
   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/${W}_write" -- python3 "$ROOT/bench.py" --workload $W --no-cpu --no-extra $ST > "$OUT/${W}_write.log" 2>&1 || { echo "$W write failed"; exit 1; }
   echo "$W done"
 done
-# keep the merge-back small: drop everything but the CSVs the summary needs
+# keep the merge-back small: the per-dispatch trace is reduced to the workload's dominant kernel (make_traffic.py averages the
+# dispatches of the timed region only), everything else but the summaries goes
+for W in $WL; do
+  for f in $(find "$OUT/${W}_stats" -name '*kernel_trace.csv'); do
+    python3 - "$f" "$OUT/${W}_dominant_trace.csv" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+keep = [r for r in rows if any(k in r["Kernel_Name"] for k in ("k_mpa_sweep", "k_maaco_walk", "k_decode_batch", "k_astar_batch<0>", "k_astar_batch<2>"))]
+w = csv.writer(open(sys.argv[2], "w"))
+w.writerow(["Kernel_Name", "Start_Timestamp", "End_Timestamp"])
+for r in keep:
+    w.writerow([r["Kernel_Name"], r["Start_Timestamp"], r["End_Timestamp"]])
+PY
+  done
+done
 find "$OUT" -type f \( -name '*.db' -o -name '*kernel_trace.csv' -o -name '*agent_info.csv' \) -delete
 cd "$ROOT"
 python3 scripts/make_traffic.py "$OUT" > "$OUT/traffic_summary.log" 2>&1 || true

@@ -228,3 +228,38 @@ def test_two_ranks_equal_one(tmp_path, what):
             assert np.array_equal(zz["path"], np.array(res[0])) and np.array_equal(zz["stats"], np.array(res[1:], float))
             assert np.array_equal(zz["curve"], np.array(ga.convergence_curve))
             assert np.array_equal(zz["popfit"], np.array([p["fitness"] for p in ga.population]))
+
+
+def test_wide_safety_windows_and_dynamic_maps():
+    """helper.calculate_path_safety_penalty (helper.py:67-80) accepts any min_safe_distance -- the device
+    window widens to radius 15 on demand (up to 15.9; beyond that the call fails loudly) -- and a handle's map can be
+    replaced in place (pf_update_grid re-runs the grid preparation on the device)."""
+    import pathfit, pf_oracle as po
+    from pathfit.engine import score_params, PathfitError
+    g, s, t = gio.grid("g256")
+    e, o = pathfit.Engine(g), po.Oracle(g)
+    rnd = np.random.default_rng(3)
+    free = np.flatnonzero(g.reshape(-1) != 1)
+    paths = [o.astar(int(a), int(b), None, 0)[0] for a, b in zip(rnd.choice(free, 12), rnd.choice(free, 12))]
+    paths = [p for p in paths if len(p) > 1]
+    for ms in (1.8, 3.2, 7.0, 7.5, 9.25, 15.9):
+        got = e.score_host(paths, score_params(0, True, 0.3, 0.8, ms, 100.0))
+        for p, row in zip(paths, got):
+            assert np.array_equal(row, o.score(p, 0, 0.3, 0.8, ms, True, 100.0)), ms
+    with pytest.raises(PathfitError):
+        e.score_host(paths, score_params(0, True, 0.3, 0.8, 16.5, 100.0))
+    # a new map in the same handle: searches and scores follow it
+    g2 = g.copy(); g2[g2 > 1] = 0
+    g2[100:140, 60:200] = 1; g2[0, 0] = 2; g2[-1, -1] = 3
+    e.update_grid(g2)
+    o2 = po.Oracle(g2)
+    free2 = np.flatnonzero(g2.reshape(-1) != 1)
+    st_, tg_ = rnd.choice(free2, 16), rnd.choice(free2, 16)
+    for variant in (0, 1):
+        got, status = e.astar_host(variant, st_, tg_, path_cap=4096)
+        for i in range(16):
+            assert np.array_equal(got[i], o2.astar(int(st_[i]), int(tg_[i]), None, variant)[0]), (variant, i)
+    p2 = [p for p in got if len(p) > 1]
+    sc = e.score_host(p2, score_params(0, True, 0.3, 0.8, 9.25, 100.0))
+    for p, row in zip(p2, sc):
+        assert np.array_equal(row, o2.score(p, 0, 0.3, 0.8, 9.25, True, 100.0))
