@@ -185,7 +185,7 @@ struct AstarArgs {
   int* cells; int* len; int* status; long long* counters;
 };
 
-template <int VARIANT>
+template <int VARIANT, bool PLAT>
 __global__ __launch_bounds__(64) void k_astar_batch(AstarArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = lane_id();
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(64) void k_astar_batch(AstarArgs p) {
     const int sa = p.start[a], ta = p.target[a];
     const long long ab = p.avoid_off ? p.avoid_off[a] : 0, ae = p.avoid_off ? p.avoid_off[a + 1] : 0;
     const int rc = ((unsigned)sa >= (unsigned)RC || (unsigned)ta >= (unsigned)RC) ? 1 :
-                   astar<VARIANT>(p.c.G, s, O, sa, ta, p.cells + (size_t)a * p.path_cap, p.path_cap, n, st, lane,
+                   astar<VARIANT, PLAT>(p.c.G, s, O, sa, ta, p.cells + (size_t)a * p.path_cap, p.path_cap, n, st, lane,
                                   p.avoid_off ? p.avoid_cells + ab : nullptr, (int)(ae - ab));
     if (lane == 0) {
       p.len[a] = rc == 0 ? n : 0;
@@ -253,6 +253,7 @@ struct DecodeArgs {
   const int* wp_cells; const double* wp_pos;
   int* cells; int* len; int* status; double* stats;
 };
+template <bool PLAT>
 __global__ __launch_bounds__(64) void k_decode_batch(DecodeArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = lane_id();
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(64) void k_decode_batch(DecodeArgs p) {
         }
       }
       int m = 0;
-      rc = astar<0>(G, s, O, cur, goal, out + n - 1, p.path_cap - (n - 1), m, tot, lane, out, n);   // ga_solver.py:68-72 (avoid = the cells visited so far)
+      rc = astar<0, PLAT>(G, s, O, cur, goal, out + n - 1, p.path_cap - (n - 1), m, tot, lane, out, n);   // ga_solver.py:68-72 (avoid = the cells visited so far)
       if (rc != 0) break;                                        // :74 / :85 -> []
       mark_avoid(s, out + n, m - 1, lane);                       // :76 nodes_in_path_so_far.update
       n += m - 1;
@@ -1642,6 +1643,7 @@ struct pf_handle {
   double* d_pen = nullptr;
   double pen_min_safe = -1.0;
   int edt_radius = 7;      // radius of the obstacle-distance window d2near was built with
+  double obst_frac = -1.0; // share of obstacle cells (lazy; picks the plateau kernels on open maps)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_ms = 0.f;
   std::string err;
@@ -1839,6 +1841,7 @@ int pf_update_grid(pf_handle* h, const uint8_t* grid) {
   CK(hipStreamSynchronize(h->stream));
   for (int k = 0; k < 4; ++k) if (h->d_comp[k]) { (void)hipFree(h->d_comp[k]); h->d_comp[k] = nullptr; }
   h->rec_policy = -1;                                               // the records embed the old move masks
+  h->obst_frac = -1.0;
   h->mpa_ready = false; h->maaco_ready = false;                     // their tables (initial path, bounds, tau / eta) belong to the old map
   if (h->d_ds) { (void)hipFree(h->d_ds); h->d_ds = nullptr; }
   if (h->d_dt) { (void)hipFree(h->d_dt); h->d_dt = nullptr; }
@@ -1905,6 +1908,14 @@ static int ensure_slots(pf_handle* h, int allow_diag = 1, int restrict_corner = 
     h->rec_policy = policy;
   }
   return 0;
+}
+// Open maps keep thousands of open entries within 1/64 of f (straight runs): they are dispatched to the kernels compiled
+// with the plateau refills.  "Open" = fewer than 10 % obstacle cells (pf_set_option "plateau_kernels": -1 auto, 0 never, 1 always).
+static int g_plateau_mode = env_int("PF_PLATEAU_KERNELS", -1);
+static bool plateau_map(pf_handle* h) {
+  if (g_plateau_mode >= 0) return g_plateau_mode != 0;
+  if (h->obst_frac < 0.0) { size_t n = 0; for (uint8_t v : h->h_occ) n += v == 1; h->obst_frac = (double)n / (double)h->RC; }
+  return h->obst_frac < 0.10;
 }
 static int ensure_elite_buf(pf_handle* h) {
   if (!h->d_elite_cells) { CK(hipMalloc(&h->d_elite_cells, sizeof(int) * (size_t)h->RC)); CK(hipMalloc(&h->d_elite_len, sizeof(int))); }
@@ -2024,9 +2035,11 @@ int pf_astar_batch(pf_handle* h, int32_t variant, int32_t allow_diag, int32_t re
     if (make_queue(h, n, [&](float* est) { hipLaunchKernelGGL(k_plan_astar, dim3((n + 255) / 256), dim3(256), 0, h->stream, a.c.G, n, d_start, d_target, est); })) return -1;
     a.c.queue = h->d_queue;
   }
-  if (variant == PF_ASTAR_REF) return launch_with_retry(h, k_astar_batch<0>, a, n);
-  if (variant == PF_ASTAR_MPA) return launch_with_retry(h, k_astar_batch<1>, a, n);
-  if (variant == PF_ASTAR_DIJKSTRA) return launch_with_retry(h, k_astar_batch<2>, a, n);
+  // sparse maps (plateaus of equal f along open runs) go to the separately compiled kernels with the plateau refills
+  const bool plat = plateau_map(h);
+  if (variant == PF_ASTAR_REF) return plat ? launch_with_retry(h, k_astar_batch<0, true>, a, n) : launch_with_retry(h, k_astar_batch<0, false>, a, n);
+  if (variant == PF_ASTAR_MPA) return plat ? launch_with_retry(h, k_astar_batch<1, true>, a, n) : launch_with_retry(h, k_astar_batch<1, false>, a, n);
+  if (variant == PF_ASTAR_DIJKSTRA) return plat ? launch_with_retry(h, k_astar_batch<2, true>, a, n) : launch_with_retry(h, k_astar_batch<2, false>, a, n);
   return failmsg(h, "pf_astar_batch: unknown variant");
 }
 
@@ -2069,7 +2082,7 @@ int pf_decode_batch(pf_handle* h, int32_t allow_diag, int32_t restrict_corner, i
     if (make_queue(h, n, [&](float* est) { hipLaunchKernelGGL(k_plan_decode, dim3((n + 255) / 256), dim3(256), 0, h->stream, a.c.G, n, W, d_wp_cells, d_wp_pos, start, target, est); })) return -1;
     a.c.queue = h->d_queue;
   }
-  return launch_with_retry(h, k_decode_batch, a, n);
+  return plateau_map(h) ? launch_with_retry(h, k_decode_batch<true>, a, n) : launch_with_retry(h, k_decode_batch<false>, a, n);
 }
 
 int pf_pso_update(pf_handle* h, int32_t n, int32_t W, double w, double c1, double c2, double max_vel, double* d_pos,
@@ -2159,6 +2172,7 @@ int pf_set_option(pf_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "maaco_window")) { g_maaco_window = value != 0; return 0; }
   if (!strcmp(name, "mpa_prune")) { g_mpa_prune = value != 0; return 0; }
   if (!strcmp(name, "astar_settle")) { g_settle = value != 0; return 0; }
+  if (!strcmp(name, "plateau_kernels")) { g_plateau_mode = (int)value; return 0; }
   if (!strcmp(name, "mpa_doubt_log_e15")) { g_doubt_log = value < 0 ? 1.0 / 8589934592.0 : (double)value * 1e-15; return 0; }
   if (!strcmp(name, "mpa_doubt_round_e15")) { g_doubt_round = value < 0 ? 1e-7 : (double)value * 1e-15; return 0; }
   return failmsg(h, std::string("pf_set_option: unknown option ") + name);

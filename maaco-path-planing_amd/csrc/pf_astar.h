@@ -146,7 +146,7 @@ PF_DEV int pocket_flood(const Grid& G, const Slot& s, int* lds, int from, int to
 // (r*C+c) start..target.  out_cap is the room available at `out`.
 // av_list / av_n: the cells of this search's avoid set as a list (the same cells mark_avoid has stamped into the
 // records); only the closed-set variants use it, to re-mark them under the parallel engine's label epoch.
-template <int VARIANT>
+template <int VARIANT, bool PLAT = false>
 __device__ __forceinline__ int astar(const Grid& G, Slot& s, const Open& O, int start, int target, int* out, int out_cap,
                      int& out_n, AStat& st, int lane, const int* av_list = nullptr, int av_n = 0) {
   // VARIANT 0 AStarSolver.solve (astar.py:33-101), 1 MPA._a_star (MPA.py:106-151), 2 DijkstraSolver.solve
@@ -211,7 +211,7 @@ __device__ __forceinline__ int astar(const Grid& G, Slot& s, const Open& O, int 
   long long cap_steps = (long long)G.R * C * (SEM == 0 ? 3 : 2);   // astar.py:58 / MPA.py:118 (R,C <= 4096)
   if (G.step_cap > 0 && G.step_cap < cap_steps) cap_steps = G.step_cap;   // test hook, see pf_set_option("astar_step_cap")
   const int max_steps = (int)cap_steps;
-  const int status4 = pop_loop_sw<VARIANT>(G, rec, O, tag, avm, start, target, tr, tc, max_steps, h0, (sr << 16) | sc_, st, lane);
+  const int status4 = pop_loop_sw<VARIANT, PLAT>(G, rec, O, tag, avm, start, target, tr, tc, max_steps, h0, (sr << 16) | sc_, st, lane);
   if (status4 != 0) return status4;
 
   // ---- walk parents target -> start (astar.py:65-69 / MPA.py:124-130), then reverse in place ----

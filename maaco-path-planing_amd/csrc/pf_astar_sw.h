@@ -236,6 +236,7 @@ PF_DEV bool sw_add(const SwPool& P, SwWin& W, double kf, double kg, int kc, int 
 }
 // After a refill: offer every spilled entry to the window (key below the new limit) or to its bucket (room again,
 // or inside the circular range now); what still does not fit stays spilled.
+template <bool PLAT>
 PF_DEV bool respill(const SwPool& P, SwWin& W, int lane) {
   const int n = W.n_spill;
   W.n_spill = 0; W.n_pool -= n;
@@ -244,7 +245,7 @@ PF_DEV bool respill(const SwPool& P, SwWin& W, int lane) {
     double ef = 0.0, eg = 0.0; int ec = 0;
     if (lane < m) ent_get(P, P.se + base + lane, ef, eg, ec);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       // read this chunk before re-spilled entries overwrite it
-#if PF_PLATEAU
+    if (PLAT) {
     // An entry that is neither below the limit nor offered room by its bucket stays spilled: on a plateau that is nearly
     // all of them, so they are put back 64 at a time; only the others go through sw_add one by one.
     PF_LDS_ORDER();
@@ -262,10 +263,10 @@ PF_DEV bool respill(const SwPool& P, SwWin& W, int lane) {
       const int k = __builtin_ctzll(rest);
       if (!sw_add(P, W, bcast_d(ef, k), bcast_d(eg, k), bcast_i(ec, k), lane)) return false;
     }
-#else
+    } else {
     for (int k = 0; k < m; ++k)
       if (!sw_add(P, W, bcast_d(ef, k), bcast_d(eg, k), bcast_i(ec, k), lane)) return false;
-#endif
+    }
   }
   return true;
 }
@@ -275,12 +276,10 @@ PF_DEV bool respill(const SwPool& P, SwWin& W, int lane) {
 // sorted sample of the bucket, one cheap pass counts the keys below it (retried with a lower pivot while more than 64), a
 // second pass moves those keys to LDS and compacts the others in place; the <= 64 selected keys ARE the bucket's smallest.
 // Returns how many were taken (>= 1), sorted in the lanes; 0 = no usable pivot (the caller falls back).
-#ifndef PF_PLATEAU
-#define PF_PLATEAU 0   /* 1: cheaper refills on plateaus of equal f (open maps): pivot selection for buckets of many windows' worth and
-                        bulk re-spilling.  Exact either way; off by default because the extra code costs the bench sweep 3-4 %
-                        (register allocation / code layout of the hot loop), on: empty 1024^2 closed-set batch 284 -> 169 ms */
-#endif
-#define PF_USE_SELECT PF_PLATEAU
+// PLAT (template parameter of the pop loop): cheaper refills on plateaus of equal f (open maps): pivot selection for
+// buckets of many windows' worth and bulk re-spilling.  Exact either way (empty 1024^2 closed-set batch 284 -> 169 ms).  Its
+// mere presence costs the hot loop 3-4 % (register allocation / code layout), so it lives in SEPARATELY compiled kernels
+// that only sparse maps are dispatched to (pathfit.hip: plateau_map); the MPA sweep never carries it.
 #ifndef PF_SELECT_MIN
 #define PF_SELECT_MIN 256   /* bucket size from which the pivot selection replaces the sort-and-merge pass */
 #endif
@@ -379,7 +378,7 @@ PF_DEV int drop_superseded(const Rec* rec, int C, double& wf, double wg, int wc)
   return __builtin_popcountll(__ballot(live));
 }
 
-template <int VARIANT>
+template <int VARIANT, bool PLAT>
 __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& O, uint32_t tag, uint32_t avm, int start, int target,
                                            int tr, int tc, int max_steps, double h0, int src, AStat& st, int lane) {
   constexpr int SEM = VARIANT == 1 ? 1 : 0;                   // 0: closed set + decrease-key (A*, Dijkstra), 1: MPA._a_star
@@ -484,7 +483,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
 #ifdef PF_STAMPS
           sw_cnt[2] += 1; sw_cnt[3] += cF;
 #endif
-          int nt = PF_USE_SELECT && cF >= PF_SELECT_MIN ? take_smallest_select(P, (char*)O.lf, NBK, cF, W.wf, W.wg, W.wc, lane) : 0;
+          int nt = PLAT && cF >= PF_SELECT_MIN ? take_smallest_select(P, (char*)O.lf, NBK, cF, W.wf, W.wg, W.wc, lane) : 0;
           if (nt == 0) { take_smallest64(P, NBK, cF, W.wf, W.wg, W.wc, lane); nt = 64; }
           W.wp = 0; W.wn = nt; W.n_pool -= nt;
           W.lf = bcast_d(W.wf, nt - 1); W.lg = bcast_d(W.wg, nt - 1); W.lc = bcast_i(W.wc, nt - 1);   // the rest of the front bucket is above this key
@@ -505,7 +504,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
             if (base + lane < W.n_spill) { double f_, g_; int c_; ent_get(P, P.se + base + lane, f_, g_, c_); const unsigned b_ = (unsigned)(int)(f_ * PF_SW_Q); minb = b_ < minb ? b_ : minb; }
           minb = wave_min_u32(minb);
           if ((int)minb > W.bcur) { W.bcur = (int)minb; W.lf = (double)W.bcur * (1.0 / PF_SW_Q); W.lg = -PF_INF; W.lc = 0; }
-          if (!respill(P, W, lane)) { status = 3; break; }
+          if (!respill<PLAT>(P, W, lane)) { status = 3; break; }
           continue;
         }
         const int cb = P.cnt[(b0 + lane) & (NBK - 1)]; // lane k: size of the k-th bucket from b0 (wraps onto empty ones)
@@ -542,7 +541,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
 #ifdef PF_STAMPS
           sw_cnt[4] += 1; sw_cnt[5] += c0;
 #endif
-          int nt = PF_USE_SELECT && c0 >= PF_SELECT_MIN ? take_smallest_select(P, (char*)O.lf, b0 & (NBK - 1), c0, W.wf, W.wg, W.wc, lane) : 0;
+          int nt = PLAT && c0 >= PF_SELECT_MIN ? take_smallest_select(P, (char*)O.lf, b0 & (NBK - 1), c0, W.wf, W.wg, W.wc, lane) : 0;
           if (nt == 0) { take_smallest64(P, b0 & (NBK - 1), c0, W.wf, W.wg, W.wc, lane); nt = 64; }
           W.wp = 0; W.wn = nt; W.n_pool -= nt;
           W.bcur = b0;
@@ -550,7 +549,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
         }
       }
       PF_LDS_ORDER();
-      if (W.n_spill > 0 && !respill(P, W, lane)) { status = 3; break; }
+      if (W.n_spill > 0 && !respill<PLAT>(P, W, lane)) { status = 3; break; }
       if (W.wn == 0) continue;                                    // everything taken was superseded: take the next buckets
     }
     SW_T(t1)

@@ -209,14 +209,17 @@ def test_astar_clustered_heads_vs_oracle():
         e.close()
 
 
-def test_astar_open_map_plateaus_vs_oracle():
-    """An empty 1024 x 1024 map: thousands of open entries within 1/64 of f (near-ties along straight runs) overflow
+@pytest.mark.parametrize("plateau_kernels", [1, 0])
+def test_astar_open_map_plateaus_vs_oracle(plateau_kernels):
+    """(Both builds of the pop loop: the separately compiled kernels with the plateau refills that open maps are dispatched
+    to, and the plain ones.)  An empty 1024 x 1024 map: thousands of open entries within 1/64 of f (near-ties along straight runs) overflow
     single buckets of the open-list pool, so the spill list and its re-offer at refill time are exercised; nothing
     may overflow and the searches with the largest open lists must match the oracle."""
     from pathfit.engine import Engine
     import pf_oracle as po
     g = np.zeros((1024, 1024), np.uint8)
     e, o = Engine(g), po.Oracle(g)
+    e.set_option("plateau_kernels", plateau_kernels)
     rnd = np.random.default_rng(7)
     n = 256
     starts = rnd.integers(0, g.size, n).astype(np.int32); targets = rnd.integers(0, g.size, n).astype(np.int32)
@@ -231,6 +234,7 @@ def test_astar_open_map_plateaus_vs_oracle():
             want, ost = o.astar(int(starts[i]), int(targets[i]), None, variant)
             assert np.array_equal(paths[i], want), (variant, i)
             assert (not SEQ and variant != 1) or cnt[i, 0] == ost[0]
+    e.set_option("plateau_kernels", -1)
     e.close()
 
 
