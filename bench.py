@@ -299,12 +299,22 @@ def main():
     from pathfit import env
     from pathfit.dist import Comm
 
-    comm = Comm(dist, torch.device("cuda", local_rank) if (dist is not None and a.backend == "nccl") else None)
+    # N > 1: RCCL over xGMI bound directly (pf_comm_*, device pointers on the engine's stream); torch.distributed only ships the
+    # 128-byte unique id and, below, reduces the wall time.  PF_BENCH_TRANSPORT=torch keeps the host-staged torch collectives.
+    use_rccl = dist is not None and a.backend == "nccl" and os.environ.get("PF_BENCH_TRANSPORT", "rccl") == "rccl"
+    comm = Comm(dist, torch.device("cuda", local_rank) if (dist is not None and a.backend == "nccl") else None,
+                transport="rccl" if use_rccl else None)
     K, W = a.steps, a.warmup
 
     def run_one(name, K_, W_):
         grid = env.bench_grid(gsize_of(name))
         eng = pathfit.Engine(grid, device=local_rank)
+        if comm.transport == "rccl" and comm.engine is None:
+            try:
+                comm.attach(eng)
+            except Exception as ex:             # the direct binding could not start: host-staged torch collectives instead
+                print(f"[bench] pf_comm (RCCL direct) unavailable on rank {rank}: {ex!r}; falling back to torch.distributed", file=sys.stderr)
+                comm.transport = "torch"
 
         def sync_all():
             if torch is not None and torch.cuda.is_available():
@@ -361,6 +371,8 @@ def main():
                "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": head_cfg, "roofline": roof, "cpu_baseline": cpu}
+        if world > 1:
+            head_cfg["exchange"] = {"transport": comm.transport, "bytes_per_rank": comm.bytes_moved, "calls": comm.calls}
         if extra is not None:
             out["extra"] = extra
         print(json.dumps(out), flush=True)

@@ -25,8 +25,10 @@ iteration, on DEVICE buffers:
 
 Transports.  `rccl`: pf_comm_* of libpathfit.so, i.e. RCCL over xGMI called directly on the engine's stream with device
 pointers -- no torch tensor, no host staging, nothing synchronises (torch.distributed, when present, only ships the
-128-byte unique id).  `gloo`: torch.distributed on the CPU with host staging, for the world-size-2 tests and rehearsals
-on one GPU.  Both move the same bytes between the same buffers, so the solver code below is transport independent.
+128-byte unique id).  `gloo` / `torch`: torch.distributed with host staging (CPU tensors for the gloo backend -- the
+world-size-2 tests and rehearsals on one GPU --, this rank's GPU for the nccl backend -- the fallback bench.py takes if
+the direct binding cannot be initialised).  All move the same bytes between the same buffers, so the solver code below
+is transport independent.
 """
 import os
 import time
@@ -154,8 +156,14 @@ class Comm:
         self.calls += 1
 
     def _t(self, arr):
+        """host array -> the tensor the torch.distributed backend wants (CPU for gloo, this rank's GPU for nccl)"""
         import torch
-        return torch.from_numpy(np.ascontiguousarray(arr))
+        t = torch.from_numpy(np.ascontiguousarray(arr))
+        return t.to(self.device) if self.device is not None else t
+
+    @staticmethod
+    def _n(t):
+        return t.cpu().numpy()
 
     # ---- collectives ----
     def all_gather(self, src, src_off, dst, counts, row_elems=1):
@@ -188,7 +196,7 @@ class Comm:
         self.dist.all_gather(outs, t)
         self._acct(mine * isz * (self.world - 1))
         for r in range(self.world):
-            dst.write(int(offs[r]), outs[r].numpy()[: counts[r] * row_elems])
+            dst.write(int(offs[r]), self._n(outs[r])[: counts[r] * row_elems])
 
     def broadcast(self, buf, off, count, root):
         if self.world == 1 or count == 0:
@@ -202,7 +210,7 @@ class Comm:
         t = self._t(buf.read(off, count) if self.rank == root else np.zeros(int(count), buf.dtype))
         self.dist.broadcast(t, root)
         if self.rank != root:
-            buf.write(off, t.numpy())
+            buf.write(off, self._n(t))
 
     def send(self, buf, off, count, peer):
         isz = np.dtype(buf.dtype).itemsize
@@ -221,7 +229,7 @@ class Comm:
             return
         t = self._t(np.zeros(int(count), buf.dtype))
         self.dist.recv(t, peer)
-        buf.write(off, t.numpy())
+        buf.write(off, self._n(t))
 
     def all_reduce_sum_f64(self, buf, off, count):
         if self.world == 1:
@@ -233,7 +241,7 @@ class Comm:
             return
         t = self._t(buf.read(off, count))
         self.dist.all_reduce(t)
-        buf.write(off, t.numpy())
+        buf.write(off, self._n(t))
 
     def all_gather_host(self, arr):
         """A few host scalars per rank (e.g. PSO's per-round (first improver, fitness)) -> [world][k] float64."""
@@ -253,7 +261,7 @@ class Comm:
         outs = [torch.empty_like(t) for _ in range(self.world)]
         self.dist.all_gather(outs, t)
         self._acct(a.size * 8 * (self.world - 1))
-        return np.stack([o.numpy() for o in outs])
+        return np.stack([self._n(o) for o in outs])
 
     def barrier(self):
         if self.world > 1 and self.dist is not None:

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KW = dict(alpha=1.0, beta=2.0, rho=0.1, Q=2.5, a_turn_coef=1.0, wh_max=0.9, wh_min=0.2, k_h_adaptive=0.9, q0_initial=0.5)
 
 
-def _worker(rank, world, port, out_dir, strict):
+def _worker(rank, world, port, out_dir, strict, ants=21, chunks=8):
     for p in (os.path.join(ROOT, "maaco-path-planing_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
     import torch.distributed as dist
@@ -23,7 +23,7 @@ def _worker(rank, world, port, out_dir, strict):
     from pathfit.dist import Comm, ShardedMAACO
     g, s, t = gio.grid("fig7")
     comm = Comm(dist, None)           # transport: gloo (host staged) -- the exchange logic is transport independent
-    sm = ShardedMAACO(comm, lambda: FakeMAACO(g, s, t, 21, 5, 7, **KW), 21, strict=strict)
+    sm = ShardedMAACO(comm, lambda: FakeMAACO(g, s, t, ants, 5, 7, **KW), ants, strict=strict, chunks=chunks)
     path, length, turns = sm.solve_path_planning()
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), path=np.array(path), length=length, turns=turns,
              tau=sm.local.engine.maaco_get_pheromone(), curve=np.array(sm.local.convergence_curve_data, float))
@@ -31,12 +31,12 @@ def _worker(rank, world, port, out_dir, strict):
     dist.destroy_process_group()
 
 
-def _single(strict=True):
+def _single(strict=True, ants=21):
     import golden_io as gio
     from dist_fakes import FakeMAACO
     from pathfit.dist import Comm, ShardedMAACO
     g, s, t = gio.grid("fig7")
-    sm = ShardedMAACO(Comm(None), lambda: FakeMAACO(g, s, t, 21, 5, 7, **KW), 21, strict=strict)
+    sm = ShardedMAACO(Comm(None), lambda: FakeMAACO(g, s, t, ants, 5, 7, **KW), ants, strict=strict)
     path, length, turns = sm.solve_path_planning()
     return np.array(path), length, turns, sm.local.engine.maaco_get_pheromone(), np.array(sm.local.convergence_curve_data, float)
 
@@ -55,6 +55,19 @@ def test_sharded_maaco_two_ranks_equals_one(tmp_path, strict):
             assert np.array_equal(z["tau"], ref[3])          # ordered fold == sequential deposits, bit for bit
         else:
             assert np.allclose(z["tau"], ref[3], rtol=1e-12)  # all_reduce(SUM): ulp-level deviation only
+
+
+def test_sharded_maaco_three_ranks_uneven_blocks_pipelined_fold(tmp_path):
+    """20 ants over 3 ranks (7 + 7 + 6: the uneven all_gather path) with the ordered fold pipelined over 5 row chunks:
+    rank 1 folds chunk j while rank 2 folds chunk j - 1; the matrix every rank ends with is the sequential one."""
+    import torch.multiprocessing as mp
+    port = 27300 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(3, port, str(tmp_path), True, 20, 5), nprocs=3, join=True)
+    ref = _single(True, 20)
+    for r in (0, 1, 2):
+        z = np.load(tmp_path / f"r{r}.npz")
+        assert np.array_equal(z["path"], ref[0]) and float(z["length"]) == ref[1] and float(z["turns"]) == ref[2]
+        assert np.array_equal(z["curve"], ref[4]) and np.array_equal(z["tau"], ref[3])
 
 
 def test_single_rank_sharded_equals_oracle_loop():
