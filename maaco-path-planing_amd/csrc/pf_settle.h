@@ -71,10 +71,13 @@ __device__ __forceinline__ int settle(const Grid& G, const Open& O, const Settle
   int nt = 0;                                                        // touched entries
   unsigned exp_l = 0, nbr_l = 0, push_l = 0;
   bool fail = false;
+  // Latency is what a trip costs (one wave, dependent memory round trips), so each trip is three of them and no more:
+  // (1) the entries, (2) ONE batch with the entry's own label, its move mask and all eight neighbour labels, (3) ONE batch
+  // with the atomics that survive the pre-check.  The goal's label (the region bound F) is requested at the top and
+  // consumed at the bottom: a bound that is one trip old only ever over-expands, which the certificate below catches.
+  double F = PF_INF;
   for (;;) {
-    // ---- the goal's label bounds the region: nothing with f above it is expanded ----
     const unsigned long long vt = __hip_atomic_load(&M.lab[target], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (at L2, where the atomics land)
-    const double F = (vt >> 57) == code ? lab_dec(vt) : PF_INF;     // (h(goal) = 0: f = g)
     // ---- next non-empty bucket ----
     PF_LDS_ORDER();
     if (cnt[bcur & (NBK - 1)] == 0) {
@@ -90,15 +93,13 @@ __device__ __forceinline__ int settle(const Grid& G, const Open& O, const Settle
     if (F != PF_INF && (double)bcur > F * PF_SW_Q) break;            // every remaining entry has f above the goal's
     // ---- one entry per lane: the whole buckets from bcur on that fit 64 lanes (a fixpoint does not care about the order,
     // and one 1/64-wide band alone rarely holds 64 nodes), or 64 entries of the first one when it is larger ----
-    double g = 0.0; int cell = 0;
-    bool have;
+    int eidx = -1;                                                   // my entry's index in the pool
     {
       const int lim = F == PF_INF ? 0x7FFFFFFF : (int)(F * PF_SW_Q);  // last band that can hold a node of the region
       const int cb = bcur + lane <= lim ? cnt[(bcur + lane) & (NBK - 1)] : 0;   // lane k: size of the k-th band from bcur
       const int c0 = bcast_i(cb, 0);
       if (c0 > 64) {
-        have = true;
-        g = eg[(size_t)(bcur & (NBK - 1)) * CAP + c0 - 64 + lane]; cell = ec[(size_t)(bcur & (NBK - 1)) * CAP + c0 - 64 + lane];
+        eidx = (bcur & (NBK - 1)) * CAP + c0 - 64 + lane;
         PF_LDS_ORDER();
         if (lane == 0) cnt[bcur & (NBK - 1)] = c0 - 64;
       } else {
@@ -112,41 +113,53 @@ __device__ __forceinline__ int settle(const Grid& G, const Open& O, const Settle
         PF_LDS_ORDER();
         const int kk = wave_incl_max(mark[lane]);                      // my entry's band, counted from bcur
         const int j = lane - bperm_i(kk, incl - cb);                    // ... and its index in that band
-        have = lane < total;
-        if (have) { const int bi = (bcur + kk) & (NBK - 1); g = eg[(size_t)bi * CAP + j]; cell = ec[(size_t)bi * CAP + j]; }
+        if (lane < total) eidx = ((bcur + kk) & (NBK - 1)) * CAP + j;
         PF_LDS_ORDER();
         if (lane < k) cnt[(bcur + lane) & (NBK - 1)] = 0;
       }
       PF_LDS_ORDER();
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");           // the entries are read before pushes may overwrite their slots
-    unsigned long long own = 0; unsigned mm = 0;
-    if (have) { own = __hip_atomic_load(&M.lab[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); mm = G.mm[cell]; }   // never a stale L1 copy: a live entry must not be skipped
+    // (1) the entries (read where the stores of earlier trips landed: never a stale L1 line of a recycled slot)
+    double g = 0.0; int cell = start;
+    bool have = eidx >= 0;
+    if (have) {
+      g = __builtin_bit_cast(double, __hip_atomic_load((const unsigned long long*)eg + eidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      cell = __hip_atomic_load(ec + eidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // (2) own label + move mask + the eight neighbour labels, one batch (addresses clamped: the move mask rejects what the clamp invents)
+    unsigned long long own = 0, vn[8]; unsigned mm = 0;
+    if (have) {
+      own = __hip_atomic_load(&M.lab[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // a live entry must never be mistaken for a superseded one
+      mm = G.mm[cell];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { int n = cell + move_dr(k) * C + move_dc(k); n = n < 0 ? 0 : (n >= RC ? RC - 1 : n); vn[k] = M.lab[n]; }
+    }
     const int r = row_of(G, cell), c = cell - r * C;
     long hdr = r - tr, hdc = c - tc;
     const double f = VARIANT == 2 ? g : g + __builtin_sqrt((double)(hdr * hdr + hdc * hdc));
     have = have && cell != target && own == lab_enc(g, code) && !(own == blocked && cell != start) && f <= F;   // superseded / goal / outside the region
     if (have) exp_l += 1;
-    // ---- relax the 8 moves: all the label loads first, then the conditional atomics ----
-    unsigned long long vn[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      vn[k] = 0ull;
-      if (have && ((mm >> k) & 1u)) vn[k] = M.lab[cell + move_dr(k) * C + move_dc(k)];
-    }
+    // (3) the atomics, all in flight together; a label only ever falls, so a pre-check against the (possibly stale) loaded
+    // value never drops a relaxation that would have won
+    unsigned long long old[8];
+    unsigned wonm = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const bool ok = have && ((mm >> k) & 1u);
-      const int n = cell + move_dr(k) * C + move_dc(k);
-      const double t = g + (k < 4 ? 1.0 : PF_SQRT2);                 // astar.py:84-85
-      const unsigned long long nv = lab_enc(t, code);
-      bool won = false;
-      if (ok) {
-        nbr_l += 1;
-        if (nv < vn[k]) won = __hip_atomic_fetch_min(&M.lab[n], nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > nv;   // :87
-      }
+      const unsigned long long nv = lab_enc(g + (k < 4 ? 1.0 : PF_SQRT2), code);      // astar.py:84-85
+      old[k] = 0ull;
+      if (ok) { nbr_l += 1; if (nv < vn[k]) old[k] = __hip_atomic_fetch_min(&M.lab[cell + move_dr(k) * C + move_dc(k)], nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }   // :87
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wonm |= (old[k] > lab_enc(g + (k < 4 ? 1.0 : PF_SQRT2), code)) ? (1u << k) : 0u;
+    // ---- pushes of the winners (LDS slot atomics + fire-and-forget stores) and the touched log ----
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bool won = (wonm >> k) & 1u;
       const unsigned long long wm = __ballot(won);
       if (wm) {
+        const int n = cell + move_dr(k) * C + move_dc(k);
+        const double t = g + (k < 4 ? 1.0 : PF_SQRT2);
         const int nr = r + move_dr(k), nc = c + move_dc(k);
         long dr_ = nr - tr, dc_ = nc - tc;
         const double fn = VARIANT == 2 ? t : t + __builtin_sqrt((double)(dr_ * dr_ + dc_ * dc_));   // :90
@@ -163,7 +176,7 @@ __device__ __forceinline__ int settle(const Grid& G, const Open& O, const Settle
       }
     }
     if (__ballot(fail)) { fail = true; break; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    F = (vt >> 57) == code ? lab_dec(vt) : PF_INF;                   // (h(goal) = 0: f = g) -- the bound the NEXT trip works with
   }
   st.pops += (unsigned long long)wave_sum_i((int)exp_l); st.pushes += 1u + (unsigned)wave_sum_i((int)push_l);
   st.nbr += (unsigned)wave_sum_i((int)nbr_l);
@@ -172,7 +185,7 @@ __device__ __forceinline__ int settle(const Grid& G, const Open& O, const Settle
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                  // the passes below read the labels the atomics left in L2
   const unsigned long long vt = M.lab[target];
   if ((vt >> 57) != code || vt == blocked) return 1;                 // the goal was never reached: astar.py:101 -> []
-  const double F = lab_dec(vt);
+  F = lab_dec(vt);
   // ---- regularity + parents, one touched node per lane ----
   bool bad = false;
   for (int i0 = 0; i0 < nt; i0 += 64) {
