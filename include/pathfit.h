@@ -239,8 +239,9 @@ int pf_mpa_memory(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_sl
 /* Tuning knobs (results never change): "maaco_pack8_min" ants per batch from which eight ants share a wavefront
  * (default 2048); "maaco_window" 0/1 tabu set of those walks as HBM epoch stamps (default 0) or an LDS bitmap window (1: slower);
  * "mpa_prune" 0/1 exact bound pruning of MPA rebuilds (default 1); "astar_settle" 0/1 closed-set searches (AStarSolver
- * / Dijkstra / GA / PSO decodes) try the parallel label-settling engine first (default 0 = always the sequential pop
- * loop, whose pop / push counters are the reference's; 1 is exact too -- certified or handed back -- see DESIGN.md 4.3).  Test hook: "astar_step_cap" > 0
+ * / Dijkstra / GA / PSO decodes) try the parallel label-settling engine first: -1 (default) the Dijkstra variant only,
+ * which it always certifies; 1 the A* variant too (exact -- certified or handed back to the sequential loop -- but no
+ * faster on tail-bound batches); 0 never (the sequential loop's pop / push counters are the reference's).  Test hook: "astar_step_cap" > 0
  * lowers the connectors' step cap below the reference's 3RC / 2RC (astar.py:58, MPA.py:118) so that the cap path
  * (PF_ST_STEP_CAP) can be exercised; 0 restores the reference's value.  "mpa_doubt_log_e15" / "mpa_doubt_round_e15":
  * margins (in 1e-15; < 0 = default) inside which an MPA proposal is handed to the host's libm (tests widen them to

@@ -46,6 +46,7 @@ struct Common {
   int retry;             // only agents whose status == 3
   // parallel closed-set engine (pf_settle.h): per-slot label / touched / parent arrays, or null (off)
   unsigned long long* st_lab; int* st_touched; unsigned char* st_par; unsigned* st_epoch;
+  bool st_astar;         // also for the A* variant (else Dijkstra only)
 };
 
 PF_DEV Open make_open(char* smem, int /*S*/, char* tier2) {
@@ -70,6 +71,7 @@ PF_DEV Slot slot_load(const Common& c, int RC) {
   s.sm.par = c.st_lab ? c.st_par + (size_t)blockIdx.x * RC : nullptr;
   s.sm.epoch = c.st_lab ? c.st_epoch + blockIdx.x : nullptr;
   s.sm.touched_cap = 2 * RC;
+  s.sm.astar_too = c.st_astar;
   return s;
 }
 PF_DEV void slot_store(const Common& c, const Slot& s, int lane) {
@@ -1866,8 +1868,10 @@ static int env_int(const char* name, int dflt) { const char* v = getenv(name); r
 static const int kSlotsPerCU = 8;                       // resident one-agent waves per CU at most
 static const int kWavesPerCU = env_int("PF_WAVES_PER_CU", 8);   // resident one-agent waves per CU (LDS permitting)
 static int g_mpa_prune = 1;   // exact bound pruning of MPA rebuilds (pf_set_option "mpa_prune")
-static int g_settle = env_int("PF_SETTLE", 0);   // 1: closed-set searches try the 64-nodes-per-trip engine first (pf_set_option "astar_settle").  Exact (zero mismatches in
-                                                  // every parity test and soak run) but not yet faster as one wave per search inside the 210-VGPR kernels: off by default
+static int g_settle = env_int("PF_SETTLE", -1);  // closed-set searches try the 64-nodes-per-trip engine first (pf_settle.h; pf_set_option "astar_settle"):
+                                                  // -1 (default) Dijkstra only -- h == 0 makes every node regular, so it is never handed back, and it measures
+                                                  // 1.6x (2048 concurrent searches) to 3.5x (one search) faster; 1 also A* (exact too -- certified or handed back --
+                                                  // but 5-7 % of the searches ARE handed back and then cost both engines: no gain on the tail-bound batches); 0 never
 static double g_doubt_log = 1.0 / 8589934592.0;   // 2^-33 relative margin on normalvariate's accept test (pf_set_option "mpa_doubt_log_e15" overrides, in 1e-15)
 static double g_doubt_round = 1e-7;                // absolute margin on the fraction fed to round()   ("mpa_doubt_round_e15")
 static int g_maaco_pack8_min = env_int("PF_MAACO_PACK8_MIN", 2048);   // ants per batch from which 8 ants share a wavefront
@@ -1925,8 +1929,8 @@ static Common make_common(pf_handle* h, int allow_diag, int restrict_corner, int
   Common c;
   c.G = make_grid(h, allow_diag, restrict_corner);
   c.rec = h->d_rec; c.tier2 = h->d_tier2; c.slot_state = h->d_slot_state; c.work = h->d_work; c.queue = nullptr; c.cnt = h->d_cnt; c.S = S; c.retry = retry;
-  const bool st_on = g_settle && h->d_st_lab;
-  c.st_lab = st_on ? h->d_st_lab : nullptr; c.st_touched = h->d_st_touched; c.st_par = h->d_st_par; c.st_epoch = h->d_st_epoch;
+  const bool st_on = g_settle != 0 && h->d_st_lab;
+  c.st_lab = st_on ? h->d_st_lab : nullptr; c.st_astar = g_settle > 0; c.st_touched = h->d_st_touched; c.st_par = h->d_st_par; c.st_epoch = h->d_st_epoch;
   return c;
 }
 static int begin_batch(pf_handle* h) {
@@ -2171,7 +2175,7 @@ int pf_set_option(pf_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "maaco_pack8_min")) { g_maaco_pack8_min = (int)value; return 0; }
   if (!strcmp(name, "maaco_window")) { g_maaco_window = value != 0; return 0; }
   if (!strcmp(name, "mpa_prune")) { g_mpa_prune = value != 0; return 0; }
-  if (!strcmp(name, "astar_settle")) { g_settle = value != 0; return 0; }
+  if (!strcmp(name, "astar_settle")) { g_settle = value < 0 ? -1 : (value != 0); return 0; }
   if (!strcmp(name, "plateau_kernels")) { g_plateau_mode = (int)value; return 0; }
   if (!strcmp(name, "mpa_doubt_log_e15")) { g_doubt_log = value < 0 ? 1.0 / 8589934592.0 : (double)value * 1e-15; return 0; }
   if (!strcmp(name, "mpa_doubt_round_e15")) { g_doubt_round = value < 0 ? 1e-7 : (double)value * 1e-15; return 0; }

@@ -32,6 +32,7 @@ struct SettleMem {
   unsigned char* par;               // [RC] parent move of every certified node (move index FROM the parent TO the node)
   unsigned* epoch;                  // this slot's label epoch (1..126), in HBM between launches
   int touched_cap;
+  bool astar_too;                   // run it for VARIANT 0 as well (default: Dijkstra only, which it always certifies)
 };
 struct Slot {
   SettleMem sm;       // parallel closed-set engine's scratch (pf_settle.h); sm.lab == nullptr: not available
@@ -192,7 +193,7 @@ __device__ __forceinline__ int astar(const Grid& G, Slot& s, const Open& O, int 
   }
   // The closed-set variants first try the 64-nodes-per-trip engine (pf_settle.h); it returns PF_ST_SEQ when it cannot
   // certify that the sequential loop would have produced the same labels and parents, and the search then runs below.
-  if (SEM == 0 && s.sm.lab && G.step_cap == 0) {
+  if (SEM == 0 && s.sm.lab && G.step_cap == 0 && (VARIANT == 2 || s.sm.astar_too)) {
     const int rs = settle<VARIANT>(G, O, s.sm, start, target, tr, tc, av_list, av_n, out, out_cap, out_n, st, lane);
     if (rs != PF_ST_SEQ) { st.settled += 1; return rs; }
     st.sequential += 1;

@@ -27,6 +27,7 @@ vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
 L.orc_ws_create.restype = vp; L.orc_ws_create.argtypes = [i32, i32]
 L.settle_v0.restype = i64; L.settle_v0.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, i64, vp, vp]
 L.ref_v0_labels.restype = i64; L.ref_v0_labels.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, i64, vp, vp]
+L.settle_v0_T.restype = i64; L.settle_v0_T.argtypes = L.settle_v0.argtypes
 L.ref_v1.restype = i64; L.ref_v1.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i64, vp]
 
 
@@ -50,9 +51,22 @@ class Study:
         same_path = na == nb and np.array_equal(self.out_a[:max(na, 0)], self.out_b[:max(nb, 0)])
         closed = np.isfinite(self.gb)
         same_lab = bool(np.array_equal(self.ga[closed], self.gb[closed]))
+        # the T-order certificate on the same input
+        st_t = np.zeros(8, np.int64)
+        gt = np.zeros(self.RC)
+        out_t = np.zeros(self.RC, np.int32)
+        nt_ = L.settle_v0_T(self.occ.ctypes.data, self.R, self.Cc, 1, 1, int(s), int(t), av, hzero, out_t.ctypes.data, self.RC,
+                            st_t.ctypes.data, gt.ctypes.data)
+        t_cert = int(st_t[2]) == 0
+        t_ok = True
+        if t_cert and int(st_t[6]) == 0:
+            t_ok = nt_ == nb and np.array_equal(out_t[:max(nt_, 0)], self.out_b[:max(nb, 0)]) and bool(np.array_equal(gt[closed], self.gb[closed]))
+            if nb > 0:
+                t_ok = t_ok and int(st_t[0]) + 1 == int(st_b[0])      # expanded nodes + start == the reference's pops
         return dict(n=int(nb), region=int(st_a[0]), delayed=int(st_a[1]), unsafe=int(st_a[2]), expansions=int(st_a[3]),
                     multi=int(st_a[4]), viol=int(st_a[5]), pops=int(st_b[0]), same_path=bool(same_path), same_lab=same_lab,
-                    path_delayed=int(st_a[7]), path=self.out_b[:max(nb, 0)].copy())
+                    path_delayed=int(st_a[7]), path=self.out_b[:max(nb, 0)].copy(), t_cert=t_cert, t_ok=bool(t_ok), t_why=int(st_t[2]),
+                    t_delayed=int(st_t[1]))
 
     def v1_vs_model(self, s, t):
         st_a = np.zeros(8, np.int64); st_b = np.zeros(6, np.int64)
@@ -75,6 +89,12 @@ def summarize(name, rows):
     viol = sum(r["viol"] for r in rows)
     pops = sum(r["pops"] for r in rows); exp = sum(r["expansions"] for r in rows)
     dl = sum(r["delayed"] for r in rows)
+    tc = sum(r["t_cert"] for r in rows); tbad = sum(r["t_cert"] and not r["t_ok"] for r in rows)
+    why = {}
+    for r in rows:
+        if not r["t_cert"]:
+            why[r["t_why"]] = why.get(r["t_why"], 0) + 1
+    print(f"{name:28s} T-order certificate: certified {tc}/{n}, certified-but-different {tbad}, give-up reasons {why}", flush=True)
     print(f"{name:28s} cases {n:5d} | all-regular {reg:5d} | certified (no unsafe delayed) {safe:5d} | path== {okp:5d} labels== {okl:5d} | "
           f"certified-but-different {bad_safe} | fixpoint violations {viol} | delayed/search {dl / n:.2f} | expansions/pops {exp / max(pops, 1):.3f}",
           flush=True)

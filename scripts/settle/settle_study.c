@@ -194,3 +194,145 @@ ORC_API int64_t ref_v1(orc_ws* w, const uint8_t* occ, int R, int C, int allow_di
   memcpy(st, s6, sizeof(s6));
   return n;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * T-order certificate (second half).  A delayed node x (every argmin parent has a LARGER key) waits in the
+ * open list with a worse label until its earliest parent p* pops, then pops right after it (its final key is below
+ * everything else in the heap).  So the sequential pop time of a node is
+ *     T(x) = (K(x), 0)                       if some argmin parent has T(p) < K(x)          "on time"
+ *          = (base(p*), depth(p*) + 1)       otherwise, p* = the argmin parent with the smallest T   "delayed"
+ * provided x is not popped EARLIER with a worse label (I1: every offer it received before p* pops keys it above the
+ * base) and the delayed nodes hanging off one base form a simple chain (one node per depth).  Under these conditions:
+ * labels = the fixpoint, came_from[x] = the argmin parent with the smallest T, expanded nodes = { T(x) < T(goal) }.
+ * out stats: [0] region size, [1] delayed nodes, [2] reasons for giving up (0 = certified), [3] expansions,
+ * [6] status, [7] delayed nodes on the path */
+typedef struct { double bf, bg; int32_t bc; int32_t d; } tkey;   /* base key (f, g, cell) + depth */
+static inline int t_lt(const tkey* a, const tkey* b) {
+  if (a->bc == b->bc) return a->d < b->d;
+  return sk_lt(a->bf, a->bg, a->bc, b->bf, b->bg, b->bc);
+}
+ORC_API int64_t settle_v0_T(const uint8_t* occ, int R, int C, int allow_diag, int restrict_corner, int start, int target,
+                            const uint8_t* avoid, int hzero, int32_t* out, int64_t cap, int64_t* stats, double* g_out) {
+  const int RC = R * C;
+  memset(stats, 0, sizeof(int64_t) * 8);
+  int sr = start / C, sc = start % C, tr = target / C, tc = target % C;
+  stats[6] = 1;
+  if (!orc_free(occ, R, C, sr, sc) || !orc_free(occ, R, C, tr, tc)) return 0;
+  if (start == target) { out[0] = start; stats[6] = 0; return 1; }
+  double* g = g_out;
+  for (int i = 0; i < RC; ++i) g[i] = INFINITY;
+  int hn = 0, hcap = 1024; lz* hp = (lz*)malloc(sizeof(lz) * hcap);
+  g[start] = 0.0;
+  lz e0 = {hzero ? 0.0 : orc_dist(sr, sc, tr, tc), start, 0.0};
+  lz_push(&hp, &hn, &hcap, e0);
+  const int nm = allow_diag ? 8 : 4;
+  /* label-correcting pass with SLACK: everything that could be popped before a delayed goal is expanded too */
+  while (hn > 0) {
+    lz cur = lz_pop(hp, &hn);
+    if (cur.g != g[cur.cell]) continue;
+    if (cur.cell == target) continue;
+    if (cur.f > g[target] * (1.0 + 1e-12)) break;
+    stats[3]++;
+    int r = cur.cell / C, c = cur.cell % C;
+    for (int m = 0; m < nm; ++m) {
+      int nr = r + HM_DR[m], nc = c + HM_DC[m];
+      if (!orc_free(occ, R, C, nr, nc)) continue;
+      int n = nr * C + nc;
+      if (BLOCKED(n)) continue;
+      if (m >= 4 && restrict_corner && (!orc_free(occ, R, C, r + HM_DR[m], c) || !orc_free(occ, R, C, r, c + HM_DC[m]))) continue;
+      double t = cur.g + orc_dist(r, c, nr, nc);
+      if (t < g[n]) { g[n] = t; lz e = {hzero ? t : t + orc_dist(nr, nc, tr, tc), n, t}; lz_push(&hp, &hn, &hcap, e); }
+    }
+  }
+  free(hp);
+  if (g[target] == INFINITY) return 0;
+  const double Fs = g[target] * (1.0 + 1e-12);                    /* nodes with f <= Fs were expanded by the pass */
+#define EXPD(n) (g[n] != INFINITY && (n) != target && KF(n) <= Fs)
+  tkey* T = (tkey*)malloc(sizeof(tkey) * (size_t)RC);
+  int32_t* par = (int32_t*)malloc(sizeof(int32_t) * (size_t)RC);
+  int32_t* list = (int32_t*)malloc(sizeof(int32_t) * (size_t)RC);
+  int nl = 0;
+  for (int x = 0; x < RC; ++x) {
+    par[x] = -1;
+    if (occ[x] == 1 || g[x] == INFINITY) continue;
+    if (x != target && !(KF(x) <= Fs)) continue;
+    T[x].bf = KF(x); T[x].bg = g[x]; T[x].bc = x; T[x].d = 0;
+    list[nl++] = x;
+  }
+  int giveup = 0, rounds = 0, changed = 1;
+  while (changed && !giveup) {
+    changed = 0;
+    if (++rounds > 12) { giveup = 1; break; }
+    for (int li = 0; li < nl; ++li) {
+      int x = list[li];
+      if (x == start) continue;
+      int r = x / C, c = x % C;
+      int best = -1;
+      for (int m = 0; m < nm; ++m) {
+        int pr = r + HM_DR[m], pc = c + HM_DC[m];
+        if (!orc_free(occ, R, C, pr, pc)) continue;
+        int p = pr * C + pc;
+        if (m >= 4 && restrict_corner && (!orc_free(occ, R, C, r + HM_DR[m], c) || !orc_free(occ, R, C, r, c + HM_DC[m]))) continue;
+        if (BLOCKED(p) || !EXPD(p)) continue;
+        if (g[p] + orc_dist(pr, pc, r, c) != g[x]) continue;
+        if (best < 0 || t_lt(&T[p], &T[best])) best = p;
+      }
+      if (best < 0) { giveup = 2; break; }                       /* its label is not explained by an expanded node */
+      tkey kx = {KF(x), g[x], x, 0}, nt;
+      if (t_lt(&T[best], &kx)) nt = kx;
+      else { nt = T[best]; nt.d += 1; }
+      if (nt.bc != T[x].bc || nt.d != T[x].d) { T[x] = nt; changed = 1; }
+      par[x] = best;
+    }
+  }
+  /* delayed nodes: simple chains only, and nobody pops early (I1) */
+  if (!giveup) {
+    for (int li = 0; li < nl && !giveup; ++li) {
+      int x = list[li];
+      if (T[x].d == 0) continue;
+      stats[1]++;
+      for (int lj = 0; lj < nl; ++lj) { int y = list[lj]; if (y != x && T[y].d == T[x].d && T[y].bc == T[x].bc) { giveup = 3; break; } }
+      if (giveup) break;
+      int r = x / C, c = x % C;
+      tkey base = {KF(T[x].bc), g[T[x].bc], T[x].bc, 0};
+      for (int m = 0; m < nm; ++m) {
+        int pr = r + HM_DR[m], pc = c + HM_DC[m];
+        if (!orc_free(occ, R, C, pr, pc)) continue;
+        int q = pr * C + pc;
+        if (m >= 4 && restrict_corner && (!orc_free(occ, R, C, r + HM_DR[m], c) || !orc_free(occ, R, C, r, c + HM_DC[m]))) continue;
+        if (BLOCKED(q) || !EXPD(q) || q == par[x]) continue;
+        if (!t_lt(&T[q], &T[par[x]])) continue;                  /* arrives after the parent: irrelevant */
+        double off = g[q] + orc_dist(pr, pc, r, c);
+        double of_ = hzero ? off : off + orc_dist(r, c, tr, tc);
+        if (!sk_lt(base.bf, base.bg, base.bc, of_, off, x)) { giveup = 4; break; }   /* x would pop before its parent */
+      }
+    }
+  }
+  /* every parent must be expanded BEFORE the goal pops; nodes popped after the goal never offer */
+  if (!giveup) {
+    for (int li = 0; li < nl && !giveup; ++li) {
+      int x = list[li];
+      if (x == start) continue;
+      if (x != target && !t_lt(&T[x], &T[target])) continue;     /* not part of the run */
+      stats[0]++;
+      if (!t_lt(&T[par[x]], &T[target]) ) giveup = 5;
+      /* its label must be the minimum over the offers of the nodes that really popped before it */
+    }
+    /* and no node that pops before the goal may have been left unexpanded by the pass (covered by the slack) */
+  }
+  stats[2] = giveup;
+  int64_t ret = 0;
+  if (!giveup) {
+    int64_t n = 0; int t = target;
+    int32_t* tmp = (int32_t*)malloc(sizeof(int32_t) * (size_t)RC);
+    while (t != start && t >= 0 && n < RC) { if (T[t].d) stats[7]++; tmp[n++] = t; t = par[t]; }
+    if (t != start) { stats[2] = 6; ret = 0; }
+    else { tmp[n++] = start; for (int64_t i = 0; i < n; ++i) out[i] = tmp[n - 1 - i]; ret = n; }
+    free(tmp);
+  }
+  /* labels of the nodes outside the run are not the sequential ones: blank them for the comparison */
+  if (!giveup) for (int li = 0; li < nl; ++li) { int x = list[li]; if (x != target && x != start && !t_lt(&T[x], &T[target])) g[x] = INFINITY; }
+  free(T); free(par); free(list);
+  stats[6] = 0;
+  return ret;
+}

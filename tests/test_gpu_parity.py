@@ -27,7 +27,7 @@ def closed_set_engine(request):
     SEQ = request.param == "sequential"
     e.set_option("astar_settle", 0 if SEQ else 1)
     yield
-    e.set_option("astar_settle", 0)
+    e.set_option("astar_settle", -1)
     SEQ = True
 
 
