@@ -436,6 +436,34 @@ def cap_e2e(G):
     np.savez_compressed(os.path.join(OUT, "e2e.npz"), **d, **{"meta_" + k: v for k, v in META.items()})
 
 
+def serpentine(n=12):
+    """A one-cell-wide serpentine corridor: random waypoints almost never decode (pso.py:126-143 fallback fixture)."""
+    g = np.ones((n, n), int)
+    for r in range(0, n, 2):
+        g[r, :] = 0
+    for i, r in enumerate(range(1, n, 2)):
+        g[r, n - 1 if i % 2 == 0 else 0] = 0
+    g[0, 0] = 2
+    last = n - 1 if (n - 1) % 2 == 0 else n - 2
+    g[last, n - 1 if ((last // 2) % 2 == 0) else 0] = 3
+    return g
+
+
+def cap_e2e_pso_fallback():
+    """PSOSolver whose 20 N random particles all fail to decode: the reference falls back to the direct A* path as its
+    one particle, clones it and keeps iterating (pso.py:126-143)."""
+    import ref_e2e
+    g = serpentine(12)
+    pk = dict(num_iterations=4, num_particles=4, num_waypoints_per_particle=5, w=0.7, c1=1.5, c2=1.5, **MAIN_W)
+    r = ref_e2e.pso_solve(g, 21, **pk)
+    assert r["attempts"] == 80, r["attempts"]                      # every attempt was used up: the fallback fired
+    d = dict(grid=g.astype(np.int8), attempts=np.array(r["attempts"]))
+    for k in ("path", "stats", "curve", "pos", "pbest_fit"):
+        d[k] = np.asarray(r[k])
+    print("e2e pso fallback: fitness", r["stats"][4], "path cells", len(r["path"]), "curve", r["curve"])
+    np.savez_compressed(os.path.join(OUT, "e2e_pso_fallback.npz"), **d, **{"meta_" + k: v for k, v in META.items()})
+
+
 if __name__ == "__main__":
     assert rh.available(), "needs /root/reference"
     os.makedirs(OUT, exist_ok=True)
@@ -451,4 +479,5 @@ if __name__ == "__main__":
     if "pso" in which: cap_pso_update(G)
     if "dijkstra" in which: cap_dijkstra(G)
     if "e2e" in which: cap_e2e(G)
+    if "e2e" in which or "pso_fallback" in which: cap_e2e_pso_fallback()
     print("golden fixtures written to", OUT)

@@ -106,3 +106,20 @@ def test_gpu_facades_match_reference_solve_loops():
     assert [r * 20 + c for r, c in res[0]] == list(z["pso0_path"]) and np.array_equal(np.array(res[1:], float), z["pso0_stats"])
     assert np.array_equal(np.array(ps.convergence_curve), z["pso0_curve"])
     assert np.array_equal(ps._pos, z["pso0_pos"]) and np.array_equal(ps._pbest_fit, z["pso0_pbest_fit"])
+
+
+@pytest.mark.gpu
+def test_gpu_pso_init_fallback_matches_reference():
+    """pso.py:126-143: when none of the 20 N random particles decodes (a serpentine corridor map), the reference takes the
+    direct A* path as its one particle, clones it and iterates; the facade must do the same."""
+    import pathfit
+    z = gio.load("e2e_pso_fallback")
+    g = z["grid"].astype(np.int64)
+    ps = pathfit.PSOSolver(g, num_iterations=4, num_particles=4, num_waypoints_per_particle=5, w=0.7, c1=1.5, c2=1.5,
+                           turn_penalty_factor=0.3, safety_penalty_factor=0.8, min_safe_distance=1.8,
+                           diagonal_obstacle_penalty_value=100.0, seed=21)
+    res = ps.solve()
+    C = g.shape[1]
+    assert [r * C + c for r, c in res[0]] == list(z["path"]) and np.array_equal(np.array(res[1:], float), z["stats"])
+    assert np.array_equal(np.array(ps.convergence_curve), z["curve"])
+    assert np.array_equal(ps._pos, z["pos"]) and np.array_equal(ps._pbest_fit, z["pbest_fit"])
