@@ -106,7 +106,9 @@ class HostBuf:
 class Comm:
     """rank / world and the four collectives the solvers use, on buffer objects (DevBuf or HostBuf) + element ranges."""
 
-    def __init__(self, dist=None, device=None, engine=None, transport=None):
+    def __init__(self, dist=None, device=None, engine=None, transport=None, loopback=False):
+        self.loopback = bool(loopback)   # world == 1 only: still issue every collective (a one-rank RCCL communicator) -- lets a
+                                         # single GPU exercise the rccl transport's pointers, sizes and stream ordering
         self.dist = dist
         self.device = device
         self.rank = dist.get_rank() if dist is not None else int(os.environ.get("PF_COMM_RANK", "0")) if transport == "rccl" else 0
@@ -171,7 +173,7 @@ class Comm:
         rank order of per-rank blocks of counts[r] rows."""
         mine = counts[self.rank] * row_elems
         offs = np.concatenate([[0], np.cumsum(counts)]) * row_elems
-        if self.world == 1:
+        if self.world == 1 and not (self.loopback and self.transport == "rccl"):
             dst.copy_from(0, src, src_off, mine)
             return
         isz = np.dtype(dst.dtype).itemsize
@@ -199,7 +201,7 @@ class Comm:
             dst.write(int(offs[r]), self._n(outs[r])[: counts[r] * row_elems])
 
     def broadcast(self, buf, off, count, root):
-        if self.world == 1 or count == 0:
+        if (self.world == 1 and not (self.loopback and self.transport == "rccl")) or count == 0:
             return
         isz = np.dtype(buf.dtype).itemsize
         self._acct(count * isz)
@@ -232,7 +234,7 @@ class Comm:
         buf.write(off, self._n(t))
 
     def all_reduce_sum_f64(self, buf, off, count):
-        if self.world == 1:
+        if self.world == 1 and not (self.loopback and self.transport == "rccl"):
             return
         self._acct(2 * count * 8)
         if self.transport == "rccl":
@@ -246,7 +248,7 @@ class Comm:
     def all_gather_host(self, arr):
         """A few host scalars per rank (e.g. PSO's per-round (first improver, fitness)) -> [world][k] float64."""
         a = np.ascontiguousarray(arr, np.float64).reshape(-1)
-        if self.world == 1:
+        if self.world == 1 and not (self.loopback and self.transport == "rccl"):
             return a[None, :]
         if self.transport == "rccl":
             e = self.engine

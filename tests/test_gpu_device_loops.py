@@ -263,3 +263,36 @@ def test_wide_safety_windows_and_dynamic_maps():
     sc = e.score_host(p2, score_params(0, True, 0.3, 0.8, 9.25, 100.0))
     for p, row in zip(p2, sc):
         assert np.array_equal(row, o2.score(p, 0, 0.3, 0.8, 9.25, True, 100.0))
+
+
+def test_sharded_solvers_over_rccl_loopback():
+    """The rccl transport of pathfit.dist (device pointers, byte counts, stream ordering) on the one GPU of the box: a
+    one-rank communicator in loopback mode still issues every all_gather / broadcast / all_reduce through pf_comm_*.  Results
+    must equal the plain single-process solvers.  (Multi-rank RCCL itself needs one GPU per rank.)"""
+    import pathfit
+    from pathfit.dist import Comm, ShardedMAACO, ShardedMPA, ShardedPSO, ShardedGA
+    g, s, t = gio.grid("fig7")
+
+    def comm_for(eng):
+        return Comm(None, None, engine=eng, transport="rccl", loopback=True)
+    # MAACO: gathers, best scan, best-path broadcast, chunked deposit (+ the non-strict all_reduce variant)
+    for strict in (True, False):
+        e1 = pathfit.Engine(g)
+        c1 = comm_for(e1)
+        sm = ShardedMAACO(c1, lambda: pathfit.MAACO(g, 21, 5, engine=e1, seed=7, **MK), 21, strict=strict, chunks=3)
+        got = sm.solve_path_planning()
+        m = pathfit.MAACO(g, 21, 5, seed=7, **MK)
+        want = m.solve_path_planning()
+        assert got == want and np.array_equal(sm.local.pheromone_matrix, m.pheromone_matrix), strict
+        assert c1.calls > 0 and c1.bytes_moved > 0
+    e2 = pathfit.Engine(g)
+    sm = ShardedMPA(comm_for(e2), lambda n: pathfit.MPA(g, 30, 9, engine=e2, seed=3, n_local=n), 30)
+    m = pathfit.MPA(g, 30, 9, seed=3)
+    assert sm.solve_path_planning() == m.solve_path_planning()
+    assert sm.local.convergence_curve_data == m.convergence_curve_data
+    e3 = pathfit.Engine(g)
+    ps, ps0 = ShardedPSO(comm_for(e3), g, engine=e3, seed=6, **PSO_KW), pathfit.PSOSolver(g, seed=6, **PSO_KW)
+    assert ps.solve() == ps0.solve() and ps.convergence_curve == ps0.convergence_curve
+    e4 = pathfit.Engine(g)
+    ga, ga0 = ShardedGA(comm_for(e4), g, engine=e4, seed=4, **GA_KW), pathfit.GASolver(g, seed=4, **GA_KW)
+    assert ga.solve() == ga0.solve() and ga.convergence_curve == ga0.convergence_curve
