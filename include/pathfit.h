@@ -237,7 +237,7 @@ int pf_mpa_memory(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_sl
                   double* d_pop_stats);
 
 /* Tuning knobs (results never change): "maaco_pack8_min" ants per batch from which eight ants share a wavefront
- * (default 2048); "maaco_window" 0/1 tabu set of those walks as HBM epoch stamps (default 0) or an LDS bitmap window (1: slower);
+ * (default 2048);
  * "mpa_prune" 0/1 exact bound pruning of MPA rebuilds (default 1); "astar_settle" 0/1 closed-set searches (AStarSolver
  * / Dijkstra / GA / PSO decodes) try the parallel label-settling engine first: -1 (default) the Dijkstra variant only,
  * which it always certifies; 1 the A* variant too (exact -- certified or handed back to the sequential loop -- but no

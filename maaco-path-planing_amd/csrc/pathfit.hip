@@ -411,8 +411,9 @@ struct MaacoArgs {
   const double* eta;      // [RC][2]  eta'^beta for (no turn, turn)
   const double* tep;      // [RC][3]  (eta'^beta no turn, tau, eta'^beta turn): ONE 16-byte load at offset 8*turn gives tau and
                           // eta'[turn] (k_maaco_walk8; refreshed by k_pack_tep before every walk)
-  unsigned* visit;        // [nslots][RC] tabu epoch stamps
+  unsigned* visit;        // [nslots][vstride] packed tabu sets (Tabu below)
   unsigned* slot_epoch;   // [nslots]
+  int wpr, vstride;       // tabu words per grid row, words per slot (= R * wpr)
   int* work; DevCounters* cnt;
   int start, target, iter, num_iterations; double q0;
   unsigned long long seed; int ant0, n, path_cap;
@@ -425,12 +426,55 @@ __global__ void k_pack_tep(int RC, const double* tau, const double* eta, double*
 }
 typedef double pf_d2u __attribute__((ext_vector_type(2), aligned(8)));
 
+// The tabu set of one resident ant (MAACO.py:281 `visited`), packed: one 32-bit word covers 16 cells of a grid row, its
+// upper half is the epoch (the ant's number in this slot) the 16 bits belong to, so a new ant needs no clearing and a word
+// of an older ant reads as empty.  2 bits per cell instead of a 4-byte stamp: a 64-B sector holds 256 cells of a row, so the
+// three rows a step probes stay in L2 for hundreds of steps (with stamps nearly every step missed to HBM), and a slot is
+// R * C / 4 bytes (64 KB at 512^2).  Epochs wrap at 0xFFF0 -> the slot is wiped.
+#define PF_TABU_WRAP 0xFFF0u
+PF_DEV bool tabu_test(unsigned w, unsigned epoch, int c) { return (w >> 16) == epoch && ((w >> (c & 15)) & 1u); }
+PF_DEV unsigned tabu_set(unsigned w, unsigned epoch, int c) { return ((w >> 16) == epoch ? w : epoch << 16) | (1u << (c & 15)); }
+// The last two words an ant stored, kept in registers: a probe of one of them takes the register copy, so a step never
+// depends on reading back a store the same wave issued one or two instructions ago.
+struct TabuLast {
+  int i0, i1; unsigned v0, v1;
+  PF_DEV void reset() { i0 = i1 = -1; v0 = v1 = 0; }
+  PF_DEV unsigned patch(int idx, unsigned w) const { return idx == i0 ? v0 : idx == i1 ? v1 : w; }
+  PF_DEV void stored(int idx, unsigned v) { i1 = i0; v1 = v0; i0 = idx; v0 = v; }
+};
+
+// ---- 8-lane group arithmetic without LDS round trips (DPP only) ----
+// max over the group, in every lane (quad swaps, then the half-row mirror)
+PF_DEV double gmax8(double v) {
+  v = fmax(v, dpp_d<0xB1, 0xF>(v));    // quad_perm:[1,0,3,2]
+  v = fmax(v, dpp_d<0x4E, 0xF>(v));    // quad_perm:[2,3,0,1]
+  v = fmax(v, dpp_d<0x141, 0xF>(v));   // row_half_mirror
+  return v;
+}
+// lane j of each group: ((a0 + a1) + a2 ... ) + aj, added in exactly that order (a sequential Python sum / numpy cumsum)
+PF_DEV double gscan8(double a, int k) {
+  double x = a;
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    double y = dpp_d<0x111, 0xF>(x);   // row_shr:1
+    y = k == 0 ? 0.0 : y;              // (lane 8 of a row would read the other group's lane 7)
+    x = y + a;
+  }
+  return x;
+}
+// the value of the group's lane 7 in every lane
+PF_DEV double glast8(double v) {
+  const double lo = dpp_d<0x157, 0xF>(v), hi = dpp_d<0x15F, 0xF>(v);   // row_newbcast:7 / :15
+  return (lane_id() & 8) ? hi : lo;
+}
 __global__ __launch_bounds__(64) void k_maaco_walk(MaacoArgs p) {
   const int lane = lane_id();
   const Grid& G = p.G;
   const int R = G.R, C = G.C, RC = R * C;
-  unsigned* visit = p.visit + (size_t)blockIdx.x * RC;
+  unsigned* visit = p.visit + (size_t)blockIdx.x * p.vstride;
   unsigned epoch = p.slot_epoch[blockIdx.x];
+  const int WPR = p.wpr;
+  TabuLast tl;
   const int k = lane & 7;
   const int mdr = AM_DR[k], mdc = AM_DC[k];
   const unsigned hbit = 1u << AM_TO_HM[k];
@@ -446,8 +490,8 @@ __global__ __launch_bounds__(64) void k_maaco_walk(MaacoArgs p) {
     const int a = next_work(p.work, lane);
     if (a >= p.n) break;
     epoch += 1;
-    if (epoch >= 0xFFFFFFF0u) {
-      for (int i = lane; i < RC; i += 64) visit[i] = 0;
+    if (epoch >= PF_TABU_WRAP) {
+      for (int i = lane; i < p.vstride; i += 64) visit[i] = 0;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       epoch = 1;
     }
@@ -455,7 +499,12 @@ __global__ __launch_bounds__(64) void k_maaco_walk(MaacoArgs p) {
     int* out = p.cells + (size_t)a * p.path_cap;
     int cr = sr, cc = sc, n = 1, prev_k = -1, nturn = 0, rc = 0;
     double plen = 0.0;
-    if (lane == 0) { out[0] = p.start; visit[p.start] = epoch; }
+    tl.reset();
+    {
+      const int wi = sr * WPR + (sc >> 4); const unsigned wv = tabu_set(0u, epoch, sc);
+      if (lane == 0) { out[0] = p.start; visit[wi] = wv; }
+      tl.stored(wi, wv);
+    }
     const long long max_steps = (long long)RC * 2;                 // MAACO.py:283
     long long steps = 0;
     while (!(cr == tr && cc == tc) && steps < max_steps) {
@@ -464,11 +513,12 @@ __global__ __launch_bounds__(64) void k_maaco_walk(MaacoArgs p) {
       const bool inb = lane < 8 && nr >= 0 && nr < R && nc >= 0 && nc < C;
       const int nidx = nr * C + nc;
       const int turn = (prev_k >= 0 && k != prev_k) ? 1 : 0;     // MAACO.py:184-195
-      unsigned vst = 0, mmask = 0; double tv = 0.0, ev = 0.0;
-      if (inb) { vst = visit[nidx]; tv = p.tau[nidx]; ev = p.eta[(size_t)nidx * 2 + turn]; }
+      unsigned vw = 0, mmask = 0; double tv = 0.0, ev = 0.0;
+      const int widx = nr * WPR + (nc >> 4);
+      if (inb) { vw = tl.patch(widx, visit[widx]); tv = p.tau[nidx]; ev = p.eta[(size_t)nidx * 2 + turn]; }
       else if (lane == 9) mmask = G.mm[cur];
       const unsigned M = (unsigned)bcast_i((int)mmask, 9);
-      const bool ok = inb && (M & hbit) && vst != epoch;         // valid, not tabu, no corner cut (:93-95,:100-120)
+      const bool ok = inb && (M & hbit) && !tabu_test(vw, epoch, nc);   // valid, not tabu, no corner cut (:93-95,:100-120)
       const unsigned mall = (unsigned)(__ballot(ok) & 0xFF);
       // strategy 2 orientation: current -> target (:152-157)
       const int vr = tr - cr, vc = tc - cc;
@@ -480,40 +530,31 @@ __global__ __launch_bounds__(64) void k_maaco_walk(MaacoArgs p) {
       if (!cand) { rc = 1; break; }                               // :287-288
       const int ncand = __builtin_popcount(cand);
       cand_tot += ncand;
+      const bool cmine = lane < 8 && ((cand >> k) & 1u);
       const double q = g.random();                                // :232 (drawn even for one candidate)
-      const double attr = tv * ev;                                // :238 tau^alpha * eta'^beta
+      const double attr = cmine ? tv * ev : 0.0;                  // :238 tau^alpha * eta'^beta; the other lanes add exact zeros
       int pick;
-      if (q <= p.q0) {                                            // :241-250 running max with absolute tolerance
-        double mx = -1.0; unsigned bm = 0;
-        for (unsigned c2 = cand; c2; c2 &= c2 - 1) {
-          const int j = __builtin_ctz(c2);
-          const double aj = bcast_d(attr, j);
-          if (aj > mx) { mx = aj; bm = 1u << j; }
-          else if (fabs(aj - mx) < 1e-9) bm |= 1u << j;
-        }
-        if (!bm) { rc = 1; break; }
+      if (q <= p.q0) {                                            // :241-250 running max with absolute tolerance, closed form (k_maaco_walk8)
+        const double M = gmax8(cmine ? attr : -1.0);
+        const unsigned eq = (unsigned)__ballot(cmine && attr == M) & 0xFFu;
+        if (!eq) { rc = 1; break; }
+        const unsigned bm = (unsigned)__ballot(cmine && k >= __builtin_ctz(eq) && fabs(attr - M) < 1e-9) & 0xFFu;
         pick = nth_set_bit(bm, (int)g.randbelow((unsigned long long)__builtin_popcount(bm)));   // random.choice
       } else {
-        double sum = 0.0;                                         // :252 sum() in candidate order
-        for (unsigned c2 = cand; c2; c2 &= c2 - 1) sum = sum + bcast_d(attr, __builtin_ctz(c2));
+        const double sum = bcast_d(gscan8(attr, k), 7);           // :252 sum() in candidate order (ordered 8-lane scan)
         if (sum < 1e-9) pick = nth_set_bit(cand, (int)g.randbelow((unsigned long long)ncand));   // :253-254
         else {
-          double ps = 0.0;                                        // :255-258
-          for (unsigned c2 = cand; c2; c2 &= c2 - 1) ps = ps + bcast_d(attr, __builtin_ctz(c2)) / sum;
-          const bool renorm = fabs(ps - 1.0) > 1e-6;
+          const double p0 = attr / sum;                           // :255
+          double pj = p0;
+          if (!(sum < 1.0e300)) {                                 // :256-258 cannot renormalise for a finite sum (see k_maaco_walk8)
+            const double ps = bcast_d(gscan8(p0, k), 7);
+            if (fabs(ps - 1.0) > 1e-6) pj = p0 / ps;
+          }
           const double u = g.random();                            // :259 np.random.choice -> one random_sample
-          double last = 0.0; bool first = true;                   // cdf = cumsum(p); cdf /= cdf[-1]
-          for (unsigned c2 = cand; c2; c2 &= c2 - 1) {
-            double pj = bcast_d(attr, __builtin_ctz(c2)) / sum; if (renorm) pj = pj / ps;
-            last = first ? pj : last + pj; first = false;
-          }
-          double acc = 0.0; first = true; int idx = 0, seen = 0;
-          for (unsigned c2 = cand; c2; c2 &= c2 - 1) {            // searchsorted(cdf, u, side='right')
-            double pj = bcast_d(attr, __builtin_ctz(c2)) / sum; if (renorm) pj = pj / ps;
-            acc = first ? pj : acc + pj; first = false;
-            seen += 1;
-            if (acc / last <= u) idx = seen;
-          }
+          const double mine = gscan8(pj, k);                      // cdf = cumsum(p); cdf /= cdf[-1]
+          const double last = bcast_d(mine, 7);
+          const unsigned tm = (unsigned)__ballot(cmine && mine / last <= u) & 0xFFu;   // searchsorted(cdf, u, side='right')
+          int idx = tm ? __builtin_popcount(cand & ((2u << (31 - __builtin_clz(tm))) - 1u)) : 0;
           if (idx > ncand - 1) idx = ncand - 1;
           pick = nth_set_bit(cand, idx);
         }
@@ -523,7 +564,12 @@ __global__ __launch_bounds__(64) void k_maaco_walk(MaacoArgs p) {
       prev_k = pick;
       cr += bcast_i(mdr, pick); cc += bcast_i(mdc, pick);
       if (n >= p.path_cap) { rc = 3; break; }
-      if (lane == 0) { out[n] = cr * C + cc; visit[cr * C + cc] = epoch; }
+      {
+        const int wi = cr * WPR + (cc >> 4);                        // = lane `pick`'s word, which it holds up to date
+        const unsigned wv = tabu_set((unsigned)bcast_i((int)vw, pick), epoch, cc);
+        if (lane == 0) { out[n] = cr * C + cc; visit[wi] = wv; }
+        tl.stored(wi, wv);
+      }
       n += 1; steps += 1;
     }
     if (rc == 0 && !(cr == tr && cc == tc)) rc = 2;               // :301-302 step cap
@@ -552,29 +598,26 @@ __global__ __launch_bounds__(64) void k_maaco_walk(MaacoArgs p) {
 // ---------------------------------------------------------------------------
 PF_DEV unsigned gballot8(bool p) { return (unsigned)(__ballot(p) >> (lane_id() & 56)) & 0xFFu; }
 PF_DEV int gbcast8_i(int v, int k) { return __builtin_amdgcn_ds_bpermute(((lane_id() & 56) + k) << 2, v); }
+// index of the idx-th set bit of an 8-bit mask (lane k tests bit k)
+PF_DEV int gnth8(unsigned m, int idx, int k) {
+  return __builtin_ctz(gballot8(((m >> k) & 1u) && __builtin_popcount(m & ((1u << k) - 1u)) == idx) | 0x100u);
+}
 PF_DEV double gbcast8_d(double v, int k) {
   const int lo = gbcast8_i(__double2loint(v), k), hi = gbcast8_i(__double2hiint(v), k);
   return __hiloint2double(hi, lo);
 }
 
-// WIN: the tabu set of an ant is an exact visited BITMAP of a 64 x 64-cell window around it, in LDS (512 B per ant),
-// instead of 4-byte epoch stamps in HBM (1 MB per resident ant at 512^2): candidates are always adjacent cells, so a step
-// only ever probes the 3 x 3 neighbourhood.  That takes one of the three divergent loads and one of the two stores off
-// every step (the walk is bound by the number of divergent vector-memory instructions).  When the ant comes
-// within one cell of the window's edge the window is recentred on it and rebuilt from the ant's own path (the cells it
-// has visited ARE its path): all 64 lanes scan the path with coalesced loads, ~n/64 iterations, every ~31 steps.
-#define PF_WIN 64
-template <bool WIN>
+// eight ants per wavefront: the 8 lanes of a group hold the 8 moves of one ant
 __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
-  __shared__ unsigned long long win[8][PF_WIN];                    // [ant of the wave][window row] -> 64 column bits
   const Grid& G = p.G;
   const int R = G.R, C = G.C, RC = R * C;
   const int lane = lane_id();
   const int k = lane & 7, grp = lane >> 3;
   const int slot = blockIdx.x * 8 + grp;
-  unsigned* visit = WIN ? nullptr : p.visit + (size_t)slot * RC;
-  unsigned epoch = WIN ? 0u : p.slot_epoch[slot];
-  int wr0 = 0, wc0 = 0;                                            // top-left cell of this ant's window (may lie outside the grid)
+  unsigned* visit = p.visit + (size_t)slot * p.vstride;
+  unsigned epoch = p.slot_epoch[slot];
+  const int WPR = p.wpr;
+  TabuLast tl; tl.reset();
   const int mdr = AM_DR[k], mdc = AM_DC[k];
   const unsigned hbit = 1u << AM_TO_HM[k];
   const int sr = row_of(G, p.start), sc = p.start - sr * C;
@@ -582,7 +625,6 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
   const int vrS = tr - sr, vcS = tc - sc;
   const bool o1 = !((vcS > 0 && mdc < 0) || (vcS < 0 && mdc > 0) || (vrS > 0 && mdr < 0) || (vrS < 0 && mdr > 0));
   const unsigned O1 = gballot8(o1);
-  const double mcost = (mdr != 0 && mdc != 0) ? PF_SQRT2 : 1.0;
   const long long max_steps = (long long)RC * 2;                   // MAACO.py:283
   unsigned long long steps_tot = 0, cand_tot = 0, cells_tot = 0, ovf_tot = 0;
   // per-ant state (replicated in the 8 lanes of the group)
@@ -600,29 +642,24 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
       if (w >= p.n) alive = false;
       else {
         a = w;
-        if (!WIN) {
-          epoch += 1;
-          if (epoch >= 0xFFFFFFF0u) {
-            for (int i = k; i < RC; i += 8) visit[i] = 0;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            epoch = 1;
-          }
+        epoch += 1;
+        if (epoch >= PF_TABU_WRAP) {
+          for (int i = k; i < p.vstride; i += 8) visit[i] = 0;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          epoch = 1;
         }
         g.init(p.seed, DOM_MAACO, (unsigned long long)p.iter, (unsigned long long)(p.ant0 + a));
         out = p.cells + (size_t)a * p.path_cap;
         cr = sr; cc = sc; n = 1; prev_k = -1; nturn = 0; rc = 0; plen = 0.0; steps = 0;
-        if (k == 0) { out[0] = p.start; if (!WIN) visit[p.start] = epoch; }
-        if (WIN) {                                                 // fresh window centred on the start, only the start marked
-          wr0 = sr - PF_WIN / 2; wc0 = sc - PF_WIN / 2;
-          for (int i = k; i < PF_WIN; i += 8) win[grp][i] = 0ull;
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          if (k == 0) win[grp][sr - wr0] = 1ull << (sc - wc0);
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        tl.reset();
+        {
+          const int wi = sr * WPR + (sc >> 4); const unsigned wv = tabu_set(0u, epoch, sc);
+          if (k == 0) { out[0] = p.start; visit[wi] = wv; }
+          tl.stored(wi, wv);
         }
         need = false;
       }
     }
-    // (a group that has run out of ants stays in the loop, inert: the window rebuild below is a 64-lane job)
     bool done = alive && ((cr == tr && cc == tc) || steps >= max_steps);
     if (alive && !done) {
       const int cur = cr * C + cc;
@@ -630,16 +667,20 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
       const bool inb = nr >= 0 && nr < R && nc >= 0 && nc < C;
       const int nidx = nr * C + nc;
       const int turn = (prev_k >= 0 && k != prev_k) ? 1 : 0;       // MAACO.py:184-195
-      unsigned vst = 0; double tv = 0.0, ev = 0.0;
+      unsigned vw = 0; double tv = 0.0, ev = 0.0;
       const unsigned M = G.mm[cur];
+      const int widx = nr * WPR + (nc >> 4);
+      // Every step that finds a candidate draws q (:232) and then at least one more 64-bit word (random.choice's first
+      // getrandbits at :250 / :254, or numpy's random_sample at :259): both words are mixed here, before the loads below
+      // are waited for, and the counter advances only when the step gets that far.
+      const uint64_t w1 = g.peek64(1), w2 = g.peek64(2);
       if (inb) {
-        if (WIN) vst = (unsigned)((win[grp][nr - wr0] >> (nc - wc0)) & 1ull);   // (the neighbourhood is inside the window: see the recentring below)
-        else vst = visit[nidx];
+        vw = tl.patch(widx, visit[widx]);
         // the step is bound by the number of divergent vector loads: tau and eta'[turn] in one
         const pf_d2u te = *(const pf_d2u*)(p.tep + (size_t)nidx * 3 + turn);
         tv = turn ? te.x : te.y; ev = turn ? te.y : te.x;
       }
-      const bool ok = inb && (M & hbit) && (WIN ? vst == 0u : vst != epoch);
+      const bool ok = inb && (M & hbit) && !tabu_test(vw, epoch, nc);
       const unsigned mall = gballot8(ok);
       const int vr = tr - cr, vc = tc - cc;
       const bool o2 = !((vc > 0 && mdc < 0) || (vc < 0 && mdc > 0) || (vr > 0 && mdr < 0) || (vr < 0 && mdr > 0));
@@ -651,83 +692,62 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
       else {
         const int ncand = __builtin_popcount(cand);
         cand_tot += ncand;
-        const double q = g.random();                                // :232
-        const double attr = tv * ev;                                // :238
+        const bool cmine = (cand >> k) & 1u;
+        g.ctr += 2;
+        const double q = Rng::to_unit(w1);                          // :232
+        const double attr = cmine ? tv * ev : 0.0;                  // :238; the other lanes add an exact zero to the ordered sums below
         int pick = 0;
-        if (q <= p.q0) {                                            // :241-250
-          double mx = -1.0; unsigned bm = 0;
-          for (unsigned c2 = cand; c2; c2 &= c2 - 1) {
-            const int j = __builtin_ctz(c2);
-            const double aj = gbcast8_d(attr, j);
-            if (aj > mx) { mx = aj; bm = 1u << j; }
-            else if (fabs(aj - mx) < 1e-9) bm |= 1u << j;
-          }
-          if (!bm) { rc = 1; done = true; }
-          else pick = nth_set_bit(bm, (int)g.randbelow((unsigned long long)__builtin_popcount(bm)));
-        } else {
-          double sum = 0.0;                                         // :252
-          for (unsigned c2 = cand; c2; c2 &= c2 - 1) sum = sum + gbcast8_d(attr, __builtin_ctz(c2));
-          if (sum < 1e-9) pick = nth_set_bit(cand, (int)g.randbelow((unsigned long long)ncand));   // :253-254
+        if (q <= p.q0) {
+          // :241-250, the running maximum with its absolute tolerance, in closed form: the tie set restarts at the FIRST
+          // occurrence of the maximum M (`attr > max` drops every earlier member there) and from then on collects the
+          // candidates within 1e-9 of M (none can exceed it).  NaN neither restarts nor joins, as in the loop.
+          const double M = gmax8(cmine ? attr : -1.0);
+          const unsigned eq = gballot8(cmine && attr == M);
+          if (!eq) { rc = 1; done = true; }
           else {
-            // Every quotient of :255-259 belongs to one candidate, and candidate j's values live in lane j: each lane
-            // divides for its own move (three fp64 divisions a step for the whole group instead of ~4 per candidate,
-            // one after the other); only the sums run over the candidates, in candidate order, as the reference's do.
+            const unsigned bm = gballot8(cmine && k >= __builtin_ctz(eq) && fabs(attr - M) < 1e-9);
+            pick = gnth8(bm, (int)g.randbelow_from(w2, (unsigned long long)__builtin_popcount(bm)), k);   // random.choice
+          }
+        } else {
+          // The sums of :252-259 run over the candidates in candidate order.  Candidate j lives in lane j, so each is one
+          // ordered 8-lane scan (7 dependent DPP steps, no LDS round trip per candidate); every quotient belongs to one
+          // candidate and is computed in its lane.
+          const double sum = glast8(gscan8(attr, k));               // :252
+          if (sum < 1e-9) pick = gnth8(cand, (int)g.randbelow_from(w2, (unsigned long long)ncand), k);   // :253-254
+          else {
             const double p0 = attr / sum;                           // :255 probabilities[j]
-            double ps = 0.0;
-            for (unsigned c2 = cand; c2; c2 &= c2 - 1) ps = ps + gbcast8_d(p0, __builtin_ctz(c2));   // :256 sum(probabilities)
-            const bool renorm = fabs(ps - 1.0) > 1e-6;
-            const double pj = renorm ? p0 / ps : p0;                // :257-258
-            const double u = g.random();                            // :259 numpy.random.choice: cdf = cumsum(p); cdf /= cdf[-1]
-            double acc = 0.0, mine = 0.0; bool first = true;
-            for (unsigned c2 = cand; c2; c2 &= c2 - 1) {
-              const int j = __builtin_ctz(c2);
-              const double pjj = gbcast8_d(pj, j);
-              acc = first ? pjj : acc + pjj; first = false;
-              mine = k == j ? acc : mine;                           // cdf[position of my move]
+            // :256-258 renormalise when |sum(probabilities) - 1| > 1e-6.  For a finite sum of at most 8 non-negative terms
+            // that never happens: sum = S(1 + e), |e| <= 7u (u = 2^-53), every quotient is a_j / sum (1 + d_j), |d_j| <= u
+            // (an underflowing quotient errs by < 2^-1074), and adding them in order costs another 7u, so
+            // |sum(probabilities) - 1| < 16u ~ 2e-15.  Only an overflowed sum takes the general route.
+            double pj = p0;
+            if (!(sum < 1.0e300)) {
+              const double ps = glast8(gscan8(p0, k));              // :256 sum(probabilities)
+              if (fabs(ps - 1.0) > 1e-6) pj = p0 / ps;              // :257-258
             }
-            const double last = acc;
-            const unsigned tm = gballot8(((cand >> k) & 1u) && mine / last <= u);   // searchsorted(cdf, u, side="right")
+            const double u = Rng::to_unit(w2);                      // :259 numpy.random.choice: cdf = cumsum(p); cdf /= cdf[-1]
+            const double mine = gscan8(pj, k);                      // cdf[position of my move]
+            const double last = glast8(mine);
+            const unsigned tm = gballot8(cmine && mine / last <= u);   // searchsorted(cdf, u, side="right")
             int idx = tm ? __builtin_popcount(cand & ((2u << (31 - __builtin_clz(tm))) - 1u)) : 0;
             if (idx > ncand - 1) idx = ncand - 1;
-            pick = nth_set_bit(cand, idx);
+            pick = gnth8(cand, idx, k);
           }
         }
         if (!done) {
-          plen += gbcast8_d(mcost, pick);                           // :293
+          plen += ((0xA5u >> pick) & 1u) ? PF_SQRT2 : 1.0;         // :293 (moves 0, 2, 5, 7 are the diagonals)
           if (prev_k >= 0 && pick != prev_k) nturn += 1;
           prev_k = pick;
-          cr += gbcast8_i(mdr, pick); cc += gbcast8_i(mdc, pick);
+          cr += (int)((0xA940u >> (2 * pick)) & 3u) - 1;            // AM_DR[pick] + 1, two bits a move
+          cc += (int)((0x9224u >> (2 * pick)) & 3u) - 1;            // AM_DC[pick] + 1
           if (n >= p.path_cap) { rc = 3; done = true; }
           else {
-            if (k == 0) { out[n] = cr * C + cc; if (WIN) win[grp][cr - wr0] |= 1ull << (cc - wc0); else visit[cr * C + cc] = epoch; }
+            const int wi = cr * WPR + (cc >> 4);                   // = lane `pick`'s word, which it holds up to date
+            const unsigned wv = tabu_set((unsigned)gbcast8_i((int)vw, pick), epoch, cc);
+            if (k == 0) { out[n] = cr * C + cc; visit[wi] = wv; }
+            tl.stored(wi, wv);
             n += 1; steps += 1;
           }
-        }
-      }
-    }
-    if (WIN) {
-      // ---- recentre + rebuild the windows of the ants that came within a cell of their window's edge ----
-      const bool edge = alive && !need && !done && (cr - wr0 < 1 || cr - wr0 > PF_WIN - 2 || cc - wc0 < 1 || cc - wc0 > PF_WIN - 2);
-      unsigned long long em = __ballot(edge && k == 0);
-      if (em) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");           // the path cells written so far are in L2 before they are read back
-        while (em) {
-          const int l0 = __builtin_ctzll(em); em &= em - 1;          // lane 8 * g of the ant to serve (uniform)
-          const int g_ = l0 >> 3;
-          const int ar = bcast_i(cr, l0), ac = bcast_i(cc, l0), an = bcast_i(n, l0);
-          const int* apath = (const int*)(((uint64_t)(unsigned)bcast_i((int)(unsigned)((uint64_t)out & 0xFFFFFFFFull), l0)) |
-                                          ((uint64_t)(unsigned)bcast_i((int)(unsigned)((uint64_t)out >> 32), l0) << 32));   // (both halves zero-extended)
-          const int nr0 = ar - PF_WIN / 2, nc0 = ac - PF_WIN / 2;
-          win[g_][lane] = 0ull;                                       // 64 lanes, 64 rows
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          for (int i = lane; i < an; i += 64) {                       // coalesced; agent scope: never a stale L1 line
-            const int cell = __hip_atomic_load(apath + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int r_ = row_of(G, cell), c_ = cell - r_ * C;
-            const unsigned rr_ = (unsigned)(r_ - nr0), cc_ = (unsigned)(c_ - nc0);
-            if (rr_ < (unsigned)PF_WIN && cc_ < (unsigned)PF_WIN) atomicOr(&win[g_][rr_], 1ull << cc_);
-          }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          if (grp == g_) { wr0 = nr0; wc0 = nc0; }
         }
       }
     }
@@ -745,7 +765,7 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
     }
   }
   if (k == 0) {
-    if (!WIN) p.slot_epoch[slot] = epoch;
+    p.slot_epoch[slot] = epoch;
     atomicAdd(&p.cnt->steps, steps_tot); atomicAdd(&p.cnt->candidates, cand_tot); atomicAdd(&p.cnt->path_cells, cells_tot);
     if (ovf_tot) atomicAdd(&p.cnt->overflow, ovf_tot);
   }
@@ -1875,8 +1895,7 @@ static int g_settle = env_int("PF_SETTLE", -1);  // closed-set searches try the 
 static double g_doubt_log = 1.0 / 8589934592.0;   // 2^-33 relative margin on normalvariate's accept test (pf_set_option "mpa_doubt_log_e15" overrides, in 1e-15)
 static double g_doubt_round = 1e-7;                // absolute margin on the fraction fed to round()   ("mpa_doubt_round_e15")
 static int g_maaco_pack8_min = env_int("PF_MAACO_PACK8_MIN", 2048);   // ants per batch from which 8 ants share a wavefront
-static int g_maaco_window = env_int("PF_MAACO_WINDOW", 0);           // 8-ants-per-wave walk: tabu set = HBM epoch stamps (0, shipped) or an LDS bitmap window (1: exact, but measured
-                                                                      // 2.6x SLOWER on maaco512 -- 5.94 vs 2.28 ms -- because every recentring rebuilds the window from the path: DESIGN.md 5)
+static int g_tabu_epoch = -1;                      // test hook ("maaco_tabu_epoch"): >= 0 -> the next walk batch starts its tabu slots from this epoch (wrap coverage)
 static const int kLdsS = 16;
 static int ensure_slots(pf_handle* h, int allow_diag = 1, int restrict_corner = 1) {
   CK(hipSetDevice(h->device));
@@ -2173,10 +2192,10 @@ int pf_set_option(pf_handle* h, const char* name, int64_t value) {
   if (!name) return failmsg(h, "pf_set_option: bad arguments");
   if (!strcmp(name, "astar_step_cap")) { g_step_cap = value > 0 ? (long long)value : 0; return 0; }
   if (!strcmp(name, "maaco_pack8_min")) { g_maaco_pack8_min = (int)value; return 0; }
-  if (!strcmp(name, "maaco_window")) { g_maaco_window = value != 0; return 0; }
   if (!strcmp(name, "mpa_prune")) { g_mpa_prune = value != 0; return 0; }
   if (!strcmp(name, "astar_settle")) { g_settle = value < 0 ? -1 : (value != 0); return 0; }
   if (!strcmp(name, "plateau_kernels")) { g_plateau_mode = (int)value; return 0; }
+  if (!strcmp(name, "maaco_tabu_epoch")) { g_tabu_epoch = (int)value; return 0; }
   if (!strcmp(name, "mpa_doubt_log_e15")) { g_doubt_log = value < 0 ? 1.0 / 8589934592.0 : (double)value * 1e-15; return 0; }
   if (!strcmp(name, "mpa_doubt_round_e15")) { g_doubt_round = value < 0 ? 1e-7 : (double)value * 1e-15; return 0; }
   return failmsg(h, std::string("pf_set_option: unknown option ") + name);
@@ -2253,12 +2272,13 @@ int pf_maaco_setup(pf_handle* h, const pf_maaco_params* p) {
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, h->device));
     const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (!h->nslots) h->nslots = cus * kSlotsPerCU;
-    // one tabu-stamp array per resident ant: up to 128 ants per CU (16 waves x 8 ants), within 32 GiB
+    // one packed tabu set (Tabu, R * ceil(C / 16) words) per resident ant: up to 128 ants per CU (16 waves x 8 ants), within 32 GiB
+    const size_t vwords = (size_t)h->R * (size_t)((h->C + 15) >> 4);
     int vs = cus * 128;
-    while ((size_t)vs * RC * sizeof(unsigned) > (32ull << 30) && vs > cus * 32) vs /= 2;
+    while ((size_t)vs * vwords * sizeof(unsigned) > (32ull << 30) && vs > cus * 32) vs /= 2;
     h->maaco_slots = vs;
-    CK(hipMalloc(&h->d_visit, sizeof(unsigned) * (size_t)vs * RC));
-    CK(hipMemsetAsync(h->d_visit, 0, sizeof(unsigned) * (size_t)vs * RC, h->stream));
+    CK(hipMalloc(&h->d_visit, sizeof(unsigned) * (size_t)vs * vwords));
+    CK(hipMemsetAsync(h->d_visit, 0, sizeof(unsigned) * (size_t)vs * vwords, h->stream));
     CK(hipMalloc(&h->d_visit_epoch, sizeof(unsigned) * vs));
     CK(hipMemsetAsync(h->d_visit_epoch, 0, sizeof(unsigned) * vs, h->stream));
     CK(hipStreamSynchronize(h->stream));
@@ -2290,6 +2310,7 @@ int pf_maaco_walk_batch(pf_handle* h, int32_t iter, uint64_t seed, int32_t ant0,
   if (!h->d_tep) CK(hipMalloc(&h->d_tep, sizeof(double) * 3 * (size_t)h->RC));
   a.tep = h->d_tep;
   a.visit = h->d_visit; a.slot_epoch = h->d_visit_epoch; a.work = h->d_work; a.cnt = h->d_cnt;
+  a.wpr = (h->C + 15) >> 4; a.vstride = h->R * a.wpr;
   a.start = h->mp.start; a.target = h->mp.target; a.iter = iter; a.num_iterations = h->mp.num_iterations;
   a.q0 = maaco_q0(iter, h->mp.num_iterations, h->mp.q0_initial);
   a.seed = seed; a.ant0 = ant0; a.n = n; a.path_cap = path_cap;
@@ -2300,10 +2321,13 @@ int pf_maaco_walk_batch(pf_handle* h, int32_t iter, uint64_t seed, int32_t ant0,
   const int need = pack8 ? (n + 7) / 8 : n; if (grid > need) grid = need;
   CK(hipMemsetAsync(h->d_work, 0, sizeof(int), h->stream));
   CK(hipMemsetAsync(h->d_cnt, 0, sizeof(DevCounters), h->stream));
+  if (g_tabu_epoch >= 0) {                                          // one-shot: later batches carry on from there
+    CK(hipMemsetD32Async((hipDeviceptr_t)h->d_visit_epoch, g_tabu_epoch, (size_t)h->maaco_slots, h->stream));
+    g_tabu_epoch = -1;
+  }
   if (pack8) hipLaunchKernelGGL(k_pack_tep, dim3((h->RC + 255) / 256), dim3(256), 0, h->stream, h->RC, a.tau, a.eta, h->d_tep);
   CK(hipEventRecord(h->ev0, h->stream));
-  if (pack8 && g_maaco_window) hipLaunchKernelGGL(k_maaco_walk8<true>, dim3(grid), dim3(64), 0, h->stream, a);
-  else if (pack8) hipLaunchKernelGGL(k_maaco_walk8<false>, dim3(grid), dim3(64), 0, h->stream, a);
+  if (pack8) hipLaunchKernelGGL(k_maaco_walk8, dim3(grid), dim3(64), 0, h->stream, a);
   else hipLaunchKernelGGL(k_maaco_walk, dim3(grid), dim3(64), 0, h->stream, a);
   CK(hipGetLastError());
   CK(hipEventRecord(h->ev1, h->stream));

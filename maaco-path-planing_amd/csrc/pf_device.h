@@ -134,11 +134,21 @@ struct Rng {
     key = k; ctr = 0;
   }
   PF_DEV uint64_t next64() { ctr += 1; return mix64(key + ctr * 0x9E3779B97F4A7C15ULL); }
-  PF_DEV double random() { return (double)(next64() >> 11) * (1.0 / 9007199254740992.0); }
+  // the word `ahead` draws from now, without consuming it (callers that mix ahead of a decision advance ctr themselves)
+  PF_DEV uint64_t peek64(uint64_t ahead) const { return mix64(key + (ctr + ahead) * 0x9E3779B97F4A7C15ULL); }
+  static PF_DEV double to_unit(uint64_t w) { return (double)(w >> 11) * (1.0 / 9007199254740992.0); }
+  PF_DEV double random() { return to_unit(next64()); }
   // random.py _randbelow_with_getrandbits (n >= 1): draws even when n == 1
   PF_DEV uint64_t randbelow(uint64_t n) {
     int k = 64 - __builtin_clzll(n);
     uint64_t r = next64() >> (64 - k);
+    while (r >= n) r = next64() >> (64 - k);
+    return r;
+  }
+  // the same, the first word already drawn
+  PF_DEV uint64_t randbelow_from(uint64_t first, uint64_t n) {
+    int k = 64 - __builtin_clzll(n);
+    uint64_t r = first >> (64 - k);
     while (r >= n) r = next64() >> (64 - k);
     return r;
   }

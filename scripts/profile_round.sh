@@ -12,7 +12,8 @@ ROOT=$(pwd)
 export TMPDIR=/tmp
 cd /tmp
 for W in $WL; do
-  case $W in mpa512) ST="--steps 20 --warmup 5";;   # the driver's protocol: the traffic figure is keyed to this kernel time ga512|astar1024) ST="--steps 2 --warmup 1";; pso512) ST="--steps 2 --warmup 1";; *) ST="--steps 6 --warmup 2";; esac
+  # mpa512 runs the driver's protocol: the traffic figure is keyed to this kernel time
+  case $W in mpa512) ST="--steps 20 --warmup 5";; ga512|astar1024|pso512) ST="--steps 2 --warmup 1";; *) ST="--steps 6 --warmup 2";; esac
   timeout -k 10 200 python3 "$ROOT/bench.py" --workload $W --no-cpu --no-extra $ST > "$OUT/${W}_bench.json" 2> "$OUT/${W}_bench.err" || { echo "$W bench failed"; exit 1; }
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${W}_stats" -- python3 "$ROOT/bench.py" --workload $W --no-cpu --no-extra $ST > "$OUT/${W}_stats.log" 2>&1 || { echo "$W stats failed"; exit 1; }
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/${W}_fetch" -- python3 "$ROOT/bench.py" --workload $W --no-cpu --no-extra $ST > "$OUT/${W}_fetch.log" 2>&1 || { echo "$W fetch failed"; exit 1; }
@@ -26,7 +27,7 @@ for W in $WL; do
     python3 - "$f" "$OUT/${W}_dominant_trace.csv" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-keep = [r for r in rows if any(k in r["Kernel_Name"] for k in ("k_mpa_sweep", "k_maaco_walk", "k_decode_batch", "k_astar_batch<0>", "k_astar_batch<2>"))]
+keep = [r for r in rows if any(k in r["Kernel_Name"] for k in ("k_mpa_sweep", "k_maaco_walk", "k_decode_batch", "k_astar_batch<"))]
 w = csv.writer(open(sys.argv[2], "w"))
 w.writerow(["Kernel_Name", "Start_Timestamp", "End_Timestamp"])
 for r in keep:

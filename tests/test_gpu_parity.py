@@ -379,38 +379,52 @@ def test_mpa_rebuild_golden():
                     assert np.array_equal(stats[j], z["stats"][i]), (gname, beta, i)
 
 
-@pytest.mark.parametrize("window", [1, 0])
-def test_maaco_eight_ants_per_wave_path_matches(window):
-    """k_maaco_walk8 (8 ants per wavefront, in-loop refetch) == goldens: force it on for tiny batches too, with the
-    tabu set as HBM epoch stamps (shipped) and as an LDS bitmap window (kept as an option: exact, measured slower)."""
+def test_maaco_eight_ants_per_wave_path_matches():
+    """k_maaco_walk8 (8 ants per wavefront, in-loop refetch) == goldens: force it on for tiny batches too."""
     e, _, _, _, _ = eng("fig7")
     e.set_option("maaco_pack8_min", 1)
-    e.set_option("maaco_window", window)
     try:
         test_maaco_golden_walks_and_pheromone()
     finally:
         e.set_option("maaco_pack8_min", 2048)
-        e.set_option("maaco_window", 0)
 
 
-def test_maaco_window_walks_equal_stamp_walks_1024():
-    """Long walks on G1024 (~1700 steps, dozens of window recentrings per ant, ants that wander back into cells they
-    left many windows ago): the LDS-window kernel and the HBM-stamp kernel must emit identical walks."""
+@pytest.mark.parametrize("pack8", [1, 0])
+def test_maaco_tabu_epoch_wrap(pack8):
+    """The packed tabu sets carry a 16-bit epoch per word: start every slot just below the wrap so that the ants of one
+    batch cross it (slot wipe + epoch restart) and compare with the goldens again."""
+    e, _, _, _, _ = eng("fig7")
+    e.set_option("maaco_pack8_min", 1 if pack8 else 1 << 30)
+    try:
+        for ep in (0xFFF0 - 1, 0xFFF0 - 2):     # (descending: a slot never revisits an epoch between two wipes)
+            e.set_option("maaco_tabu_epoch", ep)
+            test_maaco_golden_walks_and_pheromone()
+    finally:
+        e.set_option("maaco_pack8_min", 2048)
+        e.set_option("maaco_tabu_epoch", -1)
+
+
+def test_maaco_packed_and_single_ant_kernels_agree_1024():
+    """Long walks on G1024 (~1700 steps, ants that wander back into cells they left long ago): the 8-ants-per-wave kernel
+    and the one-ant-per-wave kernel must emit identical walks, also across an epoch wrap in the middle of the batch."""
     import pathfit
     from pathfit import env
     g = env.bench_grid(1024)
     m = pathfit.MAACO(g, 4096, 100, 1.0, 7.0, 0.1, 2.5, 1.0, 0.9, 0.2, 0.9, 0.5, 0.1, seed=11)
     res = []
-    for window in (1, 0):
-        m.engine.set_option("maaco_window", window)
+    for pack8_min, ep in ((1, -1), (1 << 30, -1), (1, 0xFFF0 - 1), (1, 0xFFF0 - 2)):
+        m.engine.set_option("maaco_pack8_min", pack8_min)
+        m.engine.set_option("maaco_tabu_epoch", ep)
         m.walk_iteration_dev(3)
         dc, dl, dp, dt, ds = m.walk_bufs()
         res.append((dc.download(), dl.download(), dp.download(), dt.download(), ds.download()))
-    m.engine.set_option("maaco_window", 0)
-    a, b = res
-    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
-    for i in range(4096):
-        assert np.array_equal(a[0][i, :a[1][i]], b[0][i, :b[1][i]]), i
+    m.engine.set_option("maaco_pack8_min", 2048)
+    m.engine.set_option("maaco_tabu_epoch", -1)
+    a = res[0]
+    for b in res[1:]:
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+        for i in range(4096):
+            assert np.array_equal(a[0][i, :a[1][i]], b[0][i, :b[1][i]]), i
     assert (a[1] > 0).mean() > 0.3
 
 
