@@ -42,7 +42,7 @@ class Study:
         self.free = np.flatnonzero(self.occ.reshape(-1) != 1)
 
     def one(self, s, t, avoid=None, hzero=0):
-        st_a = np.zeros(8, np.int64); st_b = np.zeros(6, np.int64)
+        st_a = np.zeros(10, np.int64); st_b = np.zeros(6, np.int64)
         av = avoid.ctypes.data if avoid is not None else None
         na = L.settle_v0(self.occ.ctypes.data, self.R, self.Cc, 1, 1, int(s), int(t), av, hzero, self.out_a.ctypes.data, self.RC,
                          st_a.ctypes.data, self.ga.ctypes.data)
@@ -65,11 +65,11 @@ class Study:
                 t_ok = t_ok and int(st_t[0]) + 1 == int(st_b[0])      # expanded nodes + start == the reference's pops
         return dict(n=int(nb), region=int(st_a[0]), delayed=int(st_a[1]), unsafe=int(st_a[2]), expansions=int(st_a[3]),
                     multi=int(st_a[4]), viol=int(st_a[5]), pops=int(st_b[0]), same_path=bool(same_path), same_lab=same_lab,
-                    path_delayed=int(st_a[7]), path=self.out_b[:max(nb, 0)].copy(), t_cert=t_cert, t_ok=bool(t_ok), t_why=int(st_t[2]),
+                    path_delayed=int(st_a[7]), first_delayed_rank=int(st_a[8]), path=self.out_b[:max(nb, 0)].copy(), t_cert=t_cert, t_ok=bool(t_ok), t_why=int(st_t[2]),
                     t_delayed=int(st_t[1]))
 
     def v1_vs_model(self, s, t):
-        st_a = np.zeros(8, np.int64); st_b = np.zeros(6, np.int64)
+        st_a = np.zeros(10, np.int64); st_b = np.zeros(6, np.int64)
         na = L.settle_v0(self.occ.ctypes.data, self.R, self.Cc, 1, 1, int(s), int(t), None, 0, self.out_a.ctypes.data, self.RC,
                          st_a.ctypes.data, self.ga.ctypes.data)
         nb = L.ref_v1(self.ws, self.occ.ctypes.data, self.R, self.Cc, 1, 1, int(s), int(t), None, self.out_b.ctypes.data, self.RC,
@@ -94,6 +94,12 @@ def summarize(name, rows):
     for r in rows:
         if not r["t_cert"]:
             why[r["t_why"]] = why.get(r["t_why"], 0) + 1
+    fb = [r for r in rows if r["delayed"] > 0 and r["region"] > 0]
+    if fb:
+        fr = np.array([r["first_delayed_rank"] / r["region"] for r in fb])
+        wt = np.array([r["pops"] for r in fb], float)
+        print(f"{name:28s} searches with delayed nodes: {len(fb)}; share of the region (in key order) before the first one: "
+              f"mean {fr.mean():.2f}, pop-weighted {np.average(fr, weights=wt):.2f}, quartiles {np.percentile(fr, [25, 50, 75]).round(2)}", flush=True)
     print(f"{name:28s} T-order certificate: certified {tc}/{n}, certified-but-different {tbad}, give-up reasons {why}", flush=True)
     print(f"{name:28s} cases {n:5d} | all-regular {reg:5d} | certified (no unsafe delayed) {safe:5d} | path== {okp:5d} labels== {okl:5d} | "
           f"certified-but-different {bad_safe} | fixpoint violations {viol} | delayed/search {dl / n:.2f} | expansions/pops {exp / max(pops, 1):.3f}",

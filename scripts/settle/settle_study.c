@@ -49,7 +49,7 @@ static int cmp_sk(const void* a, const void* b) {
 ORC_API int64_t settle_v0(const uint8_t* occ, int R, int C, int allow_diag, int restrict_corner, int start, int target,
                           const uint8_t* avoid, int hzero, int32_t* out, int64_t cap, int64_t* stats, double* g_out) {
   const int RC = R * C;
-  memset(stats, 0, sizeof(int64_t) * 8);
+  memset(stats, 0, sizeof(int64_t) * 10);            /* [8] = key rank of the first delayed node (region size if none), [9] = 0 */
   int sr = start / C, sc = start % C, tr = target / C, tc = target % C;
   stats[6] = 1;
   if (!orc_free(occ, R, C, sr, sc) || !orc_free(occ, R, C, tr, tc)) return 0;
@@ -120,7 +120,7 @@ ORC_API int64_t settle_v0(const uint8_t* occ, int R, int C, int allow_diag, int 
     if (best_any < 0) { stats[2]++; stats[1]++; delayed[x] = 2; continue; }   /* its label came from a node outside the final region */
     if (best_reg >= 0) pbest[x] = best_reg; else { pbest[x] = best_any; delayed[x] = 1; stats[1]++; }
   }
-  stats[0] = nreg;
+  stats[0] = nreg; stats[8] = nreg;
   /* chain rule for delayed nodes: in key order the nodes strictly between x and its parent must all be delayed nodes
    * whose parent chain leads to that same parent (x, x', ... pop right after it, in reverse), and no worse offer may
    * let x be popped before its parent is (S3). */
@@ -128,6 +128,7 @@ ORC_API int64_t settle_v0(const uint8_t* occ, int R, int C, int allow_diag, int 
     qsort(srt, nreg, sizeof(sk), cmp_sk);
     int32_t* rank = (int32_t*)malloc(sizeof(int32_t) * (size_t)RC);
     for (int i = 0; i < nreg; ++i) rank[srt[i].cell] = i;
+    for (int i = 0; i < nreg; ++i) if (delayed[srt[i].cell]) { stats[8] = i; break; }
     for (int i = 0; i < nreg; ++i) {
       int x = srt[i].cell;
       if (delayed[x] != 1) continue;
