@@ -301,7 +301,9 @@ def main():
 
     # N > 1: RCCL over xGMI bound directly (pf_comm_*, device pointers on the engine's stream); torch.distributed only ships the
     # 128-byte unique id and, below, reduces the wall time.  PF_BENCH_TRANSPORT=torch keeps the host-staged torch collectives.
-    use_rccl = dist is not None and a.backend == "nccl" and os.environ.get("PF_BENCH_TRANSPORT", "rccl") == "rccl"
+    # ("rccl!" tries the direct binding whatever the torch backend is: the rehearsal of its failure path on one shared GPU)
+    tr_env = os.environ.get("PF_BENCH_TRANSPORT", "rccl")
+    use_rccl = dist is not None and ((a.backend == "nccl" and tr_env == "rccl") or tr_env == "rccl!")
     comm = Comm(dist, torch.device("cuda", local_rank) if (dist is not None and a.backend == "nccl") else None,
                 transport="rccl" if use_rccl else None)
     K, W = a.steps, a.warmup
@@ -310,11 +312,11 @@ def main():
         grid = env.bench_grid(gsize_of(name))
         eng = pathfit.Engine(grid, device=local_rank)
         if comm.transport == "rccl" and comm.engine is None:
-            try:
-                comm.attach(eng)
-            except Exception as ex:             # the direct binding could not start: host-staged torch collectives instead
-                print(f"[bench] pf_comm (RCCL direct) unavailable on rank {rank}: {ex!r}; falling back to torch.distributed", file=sys.stderr)
-                comm.transport = "torch"
+            # the direct binding is checked with one collective, under a timeout, and the verdict is agreed by all ranks:
+            # if it cannot start everywhere, every rank uses the host-staged torch collectives instead
+            if not comm.attach_checked(eng, timeout=float(os.environ.get("PF_COMM_TIMEOUT", "120"))):
+                print(f"[bench] pf_comm (RCCL direct) unavailable (rank {rank}: {comm.attach_error!r}); all ranks fall back to "
+                      "torch.distributed", file=sys.stderr)
 
         def sync_all():
             if torch is not None and torch.cuda.is_available():
@@ -378,6 +380,9 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if getattr(comm, "attach_stuck", False):         # a bootstrap thread that never returned must not hold the exit up
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
 
 
 def _mpa_cpu_slice(grid, seed, lo, hi, budget_s):

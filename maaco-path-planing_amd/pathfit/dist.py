@@ -153,6 +153,46 @@ class Comm:
         engine._ck(engine.L.pf_comm_init(engine.h, self.rank, self.world, idb))
         return self
 
+    def attach_checked(self, engine, timeout=120.0):
+        """attach() plus one all_gather of the rank numbers through the new communicator, run in a helper thread so that a
+        bootstrap that never returns cannot take the caller with it; every rank then learns, through torch.distributed,
+        whether ALL ranks made it.  Returns True when the rccl transport is usable everywhere; otherwise this rank's
+        transport falls back to the host-staged torch collectives (and so does every other rank's: same verdict)."""
+        import threading
+        ok = [False]
+        err = [None]
+
+        def work():
+            try:
+                self.attach(engine)
+                if self.world > 1:
+                    mine = engine.put(np.array([self.rank], np.int32), np.int32)
+                    allr = engine.buf(self.world, np.int32)
+                    engine._ck(engine.L.pf_comm_all_gather(engine.h, mine.ptr, allr.ptr, 4))
+                    got = allr.download()
+                    if not np.array_equal(got, np.arange(self.world, dtype=np.int32)):
+                        raise RuntimeError(f"pf_comm_all_gather returned {got.tolist()}")
+                ok[0] = True
+            except Exception as ex:            # noqa: BLE001 -- any failure means "use the other transport"
+                err[0] = ex
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        th.join(timeout)
+        good = ok[0] and not th.is_alive()
+        self.attach_stuck = th.is_alive()
+        self.attach_error = err[0] if err[0] is not None else ("timed out" if th.is_alive() else None)
+        if self.dist is not None and self.world > 1:
+            import torch
+            t = torch.tensor([1 if good else 0], dtype=torch.int32)
+            if self.device is not None:
+                t = t.to(self.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+            good = bool(int(t.cpu()[0]))
+        if not good:
+            self.transport = "torch"
+            self.engine = engine
+        return good
+
     def _acct(self, nbytes):
         self.bytes_moved += int(nbytes)
         self.calls += 1

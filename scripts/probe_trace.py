@@ -42,6 +42,7 @@ for it in range(1, 4):
                     q = np.percentile(pp[m], [50, 90, 99, 100]).astype(int)
                     print(f"  {nm} A*#{seg + 1} result {res}: n {m.sum()}, pops sum {pp[m].sum()}, p50/p90/p99/max {q.tolist()}")
     # concurrency over time
-    for T in (10, 25, 50, 75, 100, 125, 150, 175, 200):
+    print('   duration histogram (ms): ' + ', '.join(f'>{b}: {int((dur[act] > b).sum())}' for b in (2, 5, 8, 10, 12, 14, 16, 20, 24)))
+    for T in (2, 5, 8, 10, 12, 14, 16, 20, 24, 28):
         print(f"   t={T} ms: running items {(act & (st <= T) & (en > T)).sum()}", end=";")
     print()
