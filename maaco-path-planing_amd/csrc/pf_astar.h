@@ -15,8 +15,8 @@
 
 namespace pf {
 
-// LDS of one search wave (bytes): [0, 1028) bucket counts; [0, 10240) doubles as the pocket flood's scratch before the
-// search starts; [2048, 3328) staging area of the pivot selection; [PF_GEO_OFF, +2496) replay source-lane table;
+// LDS of one search wave (bytes): [0, 4 * (PF_SW_NBK + 1)) bucket counts; [0, 10240) doubles as the pocket flood's scratch before the
+// search starts; [6144, 8192) staging area of the refill's run sort (and, in the plateau kernels, of the pivot selection); [PF_GEO_OFF, +2496) replay source-lane table;
 // [PF_SX_OFF, +256) prefix-sum marks of the refill
 #define PF_SX_OFF 14848
 #define PF_LDS_BYTES (PF_SX_OFF + 256)

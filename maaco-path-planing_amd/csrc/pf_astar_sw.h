@@ -3,12 +3,13 @@
 // The open list is a monotone bucket queue with a sorted window (the round-1 designs it replaced -- lane-owned LDS
 // bins with an argmin + rescan per pop, and four speculative pops over those bins -- are in the history):
 //
-//   pool    entries live unsorted in HBM buckets keyed by floor(f * Q) (Q = 64, 256 circular buckets: a push is at
-//           most 2*sqrt(2) above the pop that made it, 182 buckets); an append is one LDS atomic for the slot
+//   pool    entries live unsorted in HBM buckets keyed by floor(f * Q) (Q = 128, 512 circular buckets: a push is at
+//           most 2*sqrt(2) above the pop that made it, 363 buckets); an append is one LDS atomic for the slot
 //           index and three fire-and-forget stores -- nothing waits for it;
 //   window  when the window runs dry the next non-empty buckets (<= 64 entries) are loaded one entry per lane and
-//           sorted on the full key (f, g, cell) by a bitonic network over the lanes; lane k then holds the k-th
-//           next pop.  A pop is five v_readlane; no reduction, no rescan;
+//           sorted on the full key (f, g, cell): the buckets already are in key order, so each entry only has to be
+//           ranked inside its own bucket (sort_runs; a bitonic network over the lanes is kept for buckets larger than
+//           the window); lane k then holds the k-th next pop.  A pop is five v_readlane; no reduction, no rescan;
 //   limit   every pool entry is >= every window entry.  A push whose key is below the window's limit is
 //           inserted in place (one ballot for the position, one wave shift); when the window is full its largest
 //           entry goes back to the pool and becomes the limit;
@@ -27,15 +28,21 @@ namespace pf {
 #define PF_LDS_ORDER() asm volatile("" ::: "memory")
 PF_DEV unsigned long long dbits(double x) { return (unsigned long long)__double_as_longlong(x); }
 
-#define PF_SW_Q 64.0
+#ifndef PF_SW_Q
+#define PF_SW_Q 128.0     /* buckets per unit of f; PF_SW_NBK must cover 2*sqrt(2)*Q + 1 buckets.  r02: 64 -> 128 halves the runs the
+                             refill has to order (A/B on one box: mpa512 160.1 -> 166.4 k evals/s, ga512 16.4 -> 17.1 k; 256: no further gain) */
+#endif
 #ifndef PF_EARLY_REFILL
 #define PF_EARLY_REFILL 1   /* 0: refill only when the window is empty (A/B builds: 123-127 k against 131.5 k evals/s) */
 #endif
+#ifndef PF_RUN_SORT
+#define PF_RUN_SORT 1       /* 0: the bitonic network for every refill (A/B builds) */
+#endif
 #ifndef PF_SW_NBK
-#define PF_SW_NBK 256     /* circular buckets, a power of two (a stress build with 64 sends far keys through the spill list) */
+#define PF_SW_NBK 512     /* circular buckets, a power of two (a stress build with a quarter of it sends far keys through the spill list) */
 #endif
 #ifndef PF_SW_CAP
-#define PF_SW_CAP 1024   /* entries per bucket (a stress build with -DPF_SW_CAP=8 drives everything through the spill list) */
+#define PF_SW_CAP 512    /* entries per bucket (a stress build with -DPF_SW_CAP=8 drives everything through the spill list) */
 #endif
 
 PF_DEV bool key_lt(double f1, double g1, int c1, double f2, double g2, int c2) {   // branch-free (f, g, cell) order
@@ -101,6 +108,68 @@ PF_DEV void sort_lanes(double& f, double& g, int& c, int lane, int n2) {
 // 64 lanes holding a bitonic sequence -> ascending
 PF_DEV void merge_lanes(double& f, double& g, int& c, int lane) { merge_block<64>(f, g, c, lane); }
 
+// Sort <= 64 entries that already come as RUNS in key order (one run per f bucket, the buckets ascending): an entry's
+// place is the number of live entries in the earlier runs plus the number of smaller keys in its own run.  The entries are
+// staged in LDS and every lane walks its own run (the lanes of a run read the same address: a broadcast) -- as many rounds
+// as the longest run holds entries (3.5 buckets a refill, the longest 26 entries on average on G512), each two LDS reads
+// and one key compare, against the 21 compare-exchange stages of the bitonic network, which move five dwords across the
+// lanes each (measured: ~4 950 clocks per 64-lane sort, ~630 clocks per trip).  `start` = first lane of my run, `m` = its
+// length (0 for a lane without an entry); lanes without a live entry (f = +inf: none, or dropped as superseded) end up
+// behind the live ones, as the network leaves them.
+// acc + ((f1, g1, c1) < (f2, g2, c2) in the lanes of `en`), for keys of real entries: f, g >= 0 or +inf and c >= 0, so the
+// doubles order like their bit patterns and the key is one 160-bit unsigned number -- "<" is the borrow of a subtraction:
+// five 32-bit subtracts instead of four fp64 compares, an integer compare and their mask logic.
+PF_DEV int count_key_lt(int acc, double f1, double g1, int c1, double f2, double g2, int c2, unsigned long long en) {
+  int t;
+  asm volatile("v_sub_co_u32 %[t], vcc, %[c1], %[c2]\n\t"
+               "v_subb_co_u32 %[t], vcc, %[gl1], %[gl2], vcc\n\t"
+               "v_subb_co_u32 %[t], vcc, %[gh1], %[gh2], vcc\n\t"
+               "v_subb_co_u32 %[t], vcc, %[fl1], %[fl2], vcc\n\t"
+               "v_subb_co_u32 %[t], vcc, %[fh1], %[fh2], vcc\n\t"
+               "s_and_b64 vcc, vcc, %[en]\n\t"
+               "v_addc_co_u32 %[acc], vcc, 0, %[acc], vcc"
+               : [t] "=&v"(t), [acc] "+v"(acc)
+               : [c1] "v"(c1), [c2] "v"(c2), [gl1] "v"(__double2loint(g1)), [gl2] "v"(__double2loint(g2)), [gh1] "v"(__double2hiint(g1)),
+                 [gh2] "v"(__double2hiint(g2)), [fl1] "v"(__double2loint(f1)), [fl2] "v"(__double2loint(f2)), [fh1] "v"(__double2hiint(f1)),
+                 [fh2] "v"(__double2hiint(f2)), [en] "s"(en)
+               : "vcc");
+  return acc;
+}
+#ifndef PF_SORT_UNROLL
+#define PF_SORT_UNROLL 8
+#endif
+#define PF_SORT_LDS 6144    /* staging: 64 x 32 B in the wave's LDS, [6144, 8192): free while the pop loop runs (pf_astar.h) */
+struct __attribute__((aligned(16))) SortFG { double f, g; };
+PF_DEV void sort_runs(char* lds, double& f, double& g, int& c, int start, int m, int lane) {
+  char* base = lds + PF_SORT_LDS;
+  PF_LDS_ORDER();
+  { SortFG v; v.f = f; v.g = g; *(SortFG*)(base + lane * 32) = v; *(int*)(base + lane * 32 + 16) = c; }
+  PF_LDS_ORDER();
+  int below = 0;
+  const char* run = base + start * 32;
+  // PF_SORT_UNROLL entries a round, read unconditionally (their LDS reads go out back to back; past my run's end they return
+  // other runs' entries or bytes behind the staging area -- inside the wave's LDS, ignored by the t + u < m test)
+  for (int t = 0; __ballot(t < m) != 0ull; t += PF_SORT_UNROLL) {
+    SortFG e[PF_SORT_UNROLL]; int ec[PF_SORT_UNROLL];
+#pragma unroll
+    for (int u = 0; u < PF_SORT_UNROLL; ++u) { e[u] = *(const SortFG*)(run + (t + u) * 32); ec[u] = *(const int*)(run + (t + u) * 32 + 16); }
+#pragma unroll
+    for (int u = 0; u < PF_SORT_UNROLL; ++u) below = count_key_lt(below, e[u].f, e[u].g, ec[u], f, g, c, __ballot(t + u < m));
+  }
+  PF_LDS_ORDER();
+  const bool live = f != PF_INF;
+  const unsigned long long lm = __ballot(live);
+  const int nlive = __builtin_popcountll(lm);
+  const int pos = live ? __builtin_popcountll(lm & ((1ull << start) - 1ull)) + below
+                       : nlive + __builtin_popcountll(~lm & ((1ull << lane) - 1ull));
+  // every lane sends its entry to lane `pos` (a permutation of the 64 lanes)
+  const int a = pos << 2;
+  const int flo = __builtin_amdgcn_ds_permute(a, __double2loint(f)), fhi = __builtin_amdgcn_ds_permute(a, __double2hiint(f));
+  const int glo = __builtin_amdgcn_ds_permute(a, __double2loint(g)), ghi = __builtin_amdgcn_ds_permute(a, __double2hiint(g));
+  c = __builtin_amdgcn_ds_permute(a, c);
+  f = __hiloint2double(fhi, flo); g = __hiloint2double(ghi, glo);
+}
+
 // inclusive prefix sum / running maximum over the lanes (row scan by row_shr, then row_bcast:15 / :31)
 PF_DEV int wave_incl_sum(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
@@ -151,6 +220,9 @@ PF_DEV void geo_to_lds(char* smem, int lane) {
 }
 
 #define PF_SW_SPILL 16384
+static_assert((double)PF_SW_NBK >= 2.8285 * PF_SW_Q + 1.0, "a push lies at most 2*sqrt(2) above the pop that made it: the circular range must cover that");
+static_assert(4 * (PF_SW_NBK + 1) <= PF_SORT_LDS, "bucket counts and the sort's staging area share the wave's LDS");
+static_assert(((size_t)(PF_SW_NBK + 1) * PF_SW_CAP + PF_SW_SPILL) * 16 <= (size_t)PF_POOL_STRIDE, "bucket pool + spill list fit the slot's HBM scratch");
 // A pool entry is 16 bytes: (g, packed cell).  Its f is not stored: f = g + h(cell) is the very fp64 operation that
 // produced it when the entry was pushed (astar.py:90 / MPA.py:140), so reading an entry back recomputes it bit for bit
 // -- one 16-byte store per push and one 16-byte load per refilled entry instead of three scattered ones each
@@ -283,7 +355,7 @@ PF_DEV bool respill(const SwPool& P, SwWin& W, int lane) {
 #ifndef PF_SELECT_MIN
 #define PF_SELECT_MIN 256   /* bucket size from which the pivot selection replaces the sort-and-merge pass */
 #endif
-#define PF_SEL_LDS 2048     /* byte offset of the staging area (64 x 20 B) in the wave's LDS, between the bucket counts and the replay table */
+#define PF_SEL_LDS 6144     /* byte offset of the staging area (64 x 20 B) in the wave's LDS, between the bucket counts and the replay table */
 PF_DEV int take_smallest_select(const SwPool& P, char* lds, int bi, int c0, double& wf, double& wg, int& wc, int lane) {
   constexpr int CAP = PF_SW_CAP;
   double* sf = (double*)(lds + PF_SEL_LDS); double* sg = sf + 64; int* sc = (int*)(sg + 64);
@@ -447,8 +519,30 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
           if (lane < k) P.cnt[(b0 + lane) & (NBK - 1)] = 0;
           int live = total;
           if (SEM == 0) live = drop_superseded(rec, C, nf, ng, nc);
+#if !PF_RUN_SORT
           int n2 = 1; while (n2 < total) n2 <<= 1;
+#endif
+#ifdef PF_STAMPS
+          sw_cnt[0] += 1; sw_cnt[1] += total; sw_cnt[2] += ~wave_min_u32(~(lane < k ? (unsigned)cb : 0u)); sw_cnt[3] += k;
+          const unsigned long long ts0_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+          { unsigned tmp_ = (unsigned)nc; asm volatile("" : "+v"(tmp_)); }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          const unsigned long long ts1_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+          sw_cnt[4] += ts1_ - ts0_;
+#endif
+#if PF_RUN_SORT
+          {
+            const int msz = bperm_i(kk, cb);                      // (every lane takes part: a masked-off source lane would read as 0)
+            sort_runs((char*)O.lf, nf, ng, nc, lane < total ? lane - j : 0, lane < total ? msz : 0, lane);
+          }
+#else
           sort_lanes(nf, ng, nc, lane, n2);
+#endif
+#ifdef PF_STAMPS
+          { unsigned tmp_ = (unsigned)nc; asm volatile("" : "+v"(tmp_)); }
+          const unsigned long long ts2_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+          sw_cnt[5] += ts2_ - ts1_;
+#endif
           // lanes 0..rem-1 <- the old window, then the new entries
           const int so = W.wp + lane < 64 ? W.wp + lane : 63, sn = lane >= rem ? lane - rem : 0;
           const double of_ = bperm_d(so, W.wf), og_ = bperm_d(so, W.wg); const int oc_ = bperm_i(so, W.wc);
@@ -472,8 +566,12 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
           if (lane == 0) P.cnt[NBK] = 0;
           int live = cF;
           if (SEM == 0) live = drop_superseded(rec, C, W.wf, W.wg, W.wc);
+#if PF_RUN_SORT
+          sort_runs((char*)O.lf, W.wf, W.wg, W.wc, 0, lane < cF ? cF : 0, lane);      // one run: the front bucket
+#else
           int n2 = 1; while (n2 < cF) n2 <<= 1;
           sort_lanes(W.wf, W.wg, W.wc, lane, n2);
+#endif
 #ifdef PF_STAMPS
           sw_cnt[0] += 1; sw_cnt[1] += cF;
 #endif
@@ -529,8 +627,15 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
           if (lane < k) P.cnt[(b0 + lane) & (NBK - 1)] = 0;
           int live = total;
           if (SEM == 0) live = drop_superseded(rec, C, W.wf, W.wg, W.wc);
+#if PF_RUN_SORT
+          {
+            const int msz = bperm_i(kk, cb);                      // (every lane takes part: a masked-off source lane would read as 0)
+            sort_runs((char*)O.lf, W.wf, W.wg, W.wc, lane < total ? lane - j : 0, lane < total ? msz : 0, lane);
+          }
+#else
           int n2 = 1; while (n2 < total) n2 <<= 1;
           sort_lanes(W.wf, W.wg, W.wc, lane, n2);
+#endif
 #ifdef PF_STAMPS
           sw_cnt[6] += 1; sw_cnt[7] += total;
 #endif

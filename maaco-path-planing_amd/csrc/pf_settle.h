@@ -27,6 +27,9 @@ namespace pf {
 
 #define PF_ST_SEQ 5                 /* internal: not certified -> the caller runs the sequential engine */
 #define PF_SETTLE_CAP 1024          /* entries per bucket (16 B each) */
+// the band structure of this engine is its own (the pop loop's bucket width is tuned separately, pf_astar_sw.h)
+#define PF_ST_Q 64.0
+#define PF_ST_NBK 256
 #define PF_LAB_KEYMASK ((1ull << 57) - 1ull)
 
 PF_DEV unsigned long long lab_enc(double g, unsigned code) {
@@ -42,7 +45,7 @@ PF_DEV int opposite_move(int m) { return m < 4 ? (m ^ 1) : 11 - m; }   // helper
 template <int VARIANT>
 __device__ __forceinline__ int settle(const Grid& G, const Open& O, const SettleMem& M, int start, int target, int tr, int tc,
                                       const int* av_list, int av_n, int* out, int out_cap, int& out_n, AStat& st, int lane) {
-  constexpr int NBK = PF_SW_NBK, CAP = PF_SETTLE_CAP;
+  constexpr int NBK = PF_ST_NBK, CAP = PF_SETTLE_CAP;
   const int C = G.C, RC = G.R * G.C;
   int* cnt = (int*)O.lf;                                            // LDS [NBK] entries per bucket
   double* eg = O.of;                                                // HBM [NBK][CAP] label of the entry
@@ -65,7 +68,7 @@ __device__ __forceinline__ int settle(const Grid& G, const Open& O, const Settle
   const int sr = row_of(G, start), sc = start - sr * C;
   long dr0 = sr - tr, dc0 = sc - tc;
   const double h0 = VARIANT == 2 ? 0.0 : __builtin_sqrt((double)(dr0 * dr0 + dc0 * dc0));
-  int bcur = (int)(h0 * PF_SW_Q);                                    // first bucket (absolute) that may hold entries
+  int bcur = (int)(h0 * PF_ST_Q);                                    // first bucket (absolute) that may hold entries
   if (lane == 0) { eg[(size_t)(bcur & (NBK - 1)) * CAP] = 0.0; ec[(size_t)(bcur & (NBK - 1)) * CAP] = start; cnt[bcur & (NBK - 1)] = 1; }
   PF_LDS_ORDER();
   int nt = 0;                                                        // touched entries
@@ -90,12 +93,12 @@ __device__ __forceinline__ int settle(const Grid& G, const Open& O, const Settle
       if (b0 < 0) break;                                             // open list exhausted
       bcur = b0;
     }
-    if (F != PF_INF && (double)bcur > F * PF_SW_Q) break;            // every remaining entry has f above the goal's
+    if (F != PF_INF && (double)bcur > F * PF_ST_Q) break;            // every remaining entry has f above the goal's
     // ---- one entry per lane: the whole buckets from bcur on that fit 64 lanes (a fixpoint does not care about the order,
     // and one 1/64-wide band alone rarely holds 64 nodes), or 64 entries of the first one when it is larger ----
     int eidx = -1;                                                   // my entry's index in the pool
     {
-      const int lim = F == PF_INF ? 0x7FFFFFFF : (int)(F * PF_SW_Q);  // last band that can hold a node of the region
+      const int lim = F == PF_INF ? 0x7FFFFFFF : (int)(F * PF_ST_Q);  // last band that can hold a node of the region
       const int cb = bcur + lane <= lim ? cnt[(bcur + lane) & (NBK - 1)] : 0;   // lane k: size of the k-th band from bcur
       const int c0 = bcast_i(cb, 0);
       if (c0 > 64) {
@@ -163,7 +166,7 @@ __device__ __forceinline__ int settle(const Grid& G, const Open& O, const Settle
         const int nr = r + move_dr(k), nc = c + move_dc(k);
         long dr_ = nr - tr, dc_ = nc - tc;
         const double fn = VARIANT == 2 ? t : t + __builtin_sqrt((double)(dr_ * dr_ + dc_ * dc_));   // :90
-        int ba = (int)(fn * PF_SW_Q); ba = ba < bcur ? bcur : ba;     // (an ulp below the current band: it is processed with it)
+        int ba = (int)(fn * PF_ST_Q); ba = ba < bcur ? bcur : ba;     // (an ulp below the current band: it is processed with it)
         if (won) {
           push_l += 1;
           const int at = __hip_atomic_fetch_add(&cnt[ba & (NBK - 1)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
