@@ -2183,8 +2183,8 @@ extern "C" int pf_debug_trace(pf_handle* h, uint64_t* out) {
 #ifdef PF_STAMPS
 extern "C" int pf_debug_stamps(pf_handle* h, uint64_t* out, int reset) {
   CK(hipSetDevice(h->device));
-  CK(hipMemcpyFromSymbol(out, HIP_SYMBOL(pf::g_stamps), sizeof(uint64_t) * 16));
-  if (reset) { uint64_t z[16] = {0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(pf::g_stamps), z, sizeof(z))); }
+  CK(hipMemcpyFromSymbol(out, HIP_SYMBOL(pf::g_stamps), sizeof(uint64_t) * 24));
+  if (reset) { uint64_t z[24] = {0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(pf::g_stamps), z, sizeof(z))); }
   return 0;
 }
 #endif

@@ -50,7 +50,7 @@ struct AStat {
 };
 // diagnostic build only (-DPF_STAMPS): shader-clock time per section of the pop loop, never in the product .so
 #ifdef PF_STAMPS
-__device__ unsigned long long g_stamps[16];
+__device__ unsigned long long g_stamps[24];
 #endif
 
 // Mark cells[0..n) of a path as "avoid" for this slot's current eval epoch.

@@ -487,6 +487,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
 
 #ifdef PF_STAMPS
   unsigned long long sw_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sw_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long sw_er[6] = {0, 0, 0, 0, 0, 0};           // early refills: count, entries, largest run, buckets, clocks waiting for the entries, clocks sorting
 #endif
   for (;;) {
     SW_T(t0)
@@ -523,12 +524,12 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
           int n2 = 1; while (n2 < total) n2 <<= 1;
 #endif
 #ifdef PF_STAMPS
-          sw_cnt[0] += 1; sw_cnt[1] += total; sw_cnt[2] += ~wave_min_u32(~(lane < k ? (unsigned)cb : 0u)); sw_cnt[3] += k;
+          sw_er[0] += 1; sw_er[1] += total; sw_er[2] += ~wave_min_u32(~(lane < k ? (unsigned)cb : 0u)); sw_er[3] += k;
           const unsigned long long ts0_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
           { unsigned tmp_ = (unsigned)nc; asm volatile("" : "+v"(tmp_)); }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           const unsigned long long ts1_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
-          sw_cnt[4] += ts1_ - ts0_;
+          sw_er[4] += ts1_ - ts0_;
 #endif
 #if PF_RUN_SORT
           {
@@ -541,7 +542,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
 #ifdef PF_STAMPS
           { unsigned tmp_ = (unsigned)nc; asm volatile("" : "+v"(tmp_)); }
           const unsigned long long ts2_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
-          sw_cnt[5] += ts2_ - ts1_;
+          sw_er[5] += ts2_ - ts1_;
 #endif
           // lanes 0..rem-1 <- the old window, then the new entries
           const int so = W.wp + lane < 64 ? W.wp + lane : 63, sn = lane >= rem ? lane - rem : 0;
@@ -929,7 +930,10 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
 #endif
   }
 #ifdef PF_STAMPS
-  if (lane == 0) for (int i = 0; i < 8; ++i) { atomicAdd(&g_stamps[i], sw_acc[i]); atomicAdd(&g_stamps[8 + i], sw_cnt[i]); }
+  if (lane == 0) {
+    for (int i = 0; i < 8; ++i) { atomicAdd(&g_stamps[i], sw_acc[i]); atomicAdd(&g_stamps[8 + i], sw_cnt[i]); }
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_stamps[16 + i], sw_er[i]);
+  }
 #endif
   if (n_max > st.max_open) st.max_open = n_max;
   st.pops += (unsigned long long)steps; st.pushes += 1u + (unsigned)wave_sum_i((int)push_l);

@@ -19,7 +19,7 @@ for n in ((int(sys.argv[1]),) if len(sys.argv) > 1 else (1,)):
     if os.environ.get("PF_SAME"):      # n copies of the corner-to-corner search (shader clocks per trip under load)
         starts[:] = 0; targets[:] = g.size - 1
     for v in (1, 0):
-        out = np.zeros(16, np.uint64)
+        out = np.zeros(24, np.uint64)
         e.L.pf_debug_stamps(e.h, out.ctypes.data, 1)
         paths, st, cnt = e.astar_host(v, starts, targets, None, path_cap=8192, want_counters=True)
         e.L.pf_debug_stamps(e.h, out.ctypes.data, 1)
@@ -27,9 +27,9 @@ for n in ((int(sys.argv[1]),) if len(sys.argv) > 1 else (1,)):
         print(f"us per trip (kernel time / trips of one search) {1e3 * e.last_kernel_ms() / (trips / n):.3f}")
         print(f"n={n} v{v}: {e.last_kernel_ms():.1f} ms pops {pops} trips {trips} pops/trip {pops / trips:.2f} clocks/trip {out[:7].sum() / trips:.0f}: " +
               "; ".join(f"{names[i]} {out[i] / trips:.0f}" for i in range(7)))
-        c = out[8:].astype(float)
-        if c[0] > 10:
-            print(f"      early refills: {int(c[0])} (every {trips / c[0]:.1f} trips), entries avg {c[1] / c[0]:.1f}, buckets avg {c[3] / c[0]:.1f}, largest bucket avg {c[2] / c[0]:.1f}; "
-                  f"clocks per early refill: waiting for the pool entries {c[4] / c[0]:.0f}, sort {c[5] / c[0]:.0f}")
+        c = out[8:16].astype(float); er = out[16:].astype(float)
+        if er[0] > 0:
+            print(f"      early refills: {int(er[0])} (every {trips / er[0]:.1f} trips), entries avg {er[1] / er[0]:.1f}, buckets avg {er[3] / er[0]:.1f}, largest bucket avg {er[2] / er[0]:.1f}; "
+                  f"clocks per early refill: waiting for the pool entries {er[4] / er[0]:.0f}, sort {er[5] / er[0]:.0f}")
         print(f"      refills: front small {int(c[0])} (avg {c[1] / max(c[0], 1):.1f}), front big {int(c[2])} (avg size {c[3] / max(c[2], 1):.1f}), "
               f"regular {int(c[6])} (avg {c[7] / max(c[6], 1):.1f}), regular big {int(c[4])} (avg size {c[5] / max(c[4], 1):.1f})")
