@@ -87,3 +87,33 @@ def test_shard_helpers():
     # sequential scan semantics MAACO.py:343-349: a later near-tie with fewer turns takes the path, not the length
     L, T, i = maaco_best_scan_host(np.array([10.0, 10.0 - 5e-10, 10.0 + 4e-10]), np.array([5, 6, 2]))
     assert (L, T, i) == (10.0 - 5e-10, 2.0, 2)
+
+
+def test_attach_checked_falls_back_when_the_binding_cannot_start():
+    """Comm.attach_checked: a direct (RCCL) binding that fails, or never returns, must leave the communicator on the host-staged
+    transport instead of raising or hanging (bench.py's N > 1 start-up).  No GPU: the engine is a stub."""
+    import time
+    from pathfit.dist import Comm
+
+    class _L:
+        def __init__(self, mode):
+            self.mode = mode
+
+        def pf_comm_unique_id(self, buf):
+            if self.mode == "hang":
+                time.sleep(30)
+            return 1                                   # "failed"
+
+        def pf_last_error(self, h):
+            return b"stub: no rccl here"
+
+    class _Eng:
+        def __init__(self, mode):
+            self.L, self.h = _L(mode), None
+
+    for mode, timeout in (("fail", 5.0), ("hang", 0.3)):
+        c = Comm(None, None, transport="rccl")
+        t0 = time.time()
+        ok = c.attach_checked(_Eng(mode), timeout=timeout)
+        assert ok is False and c.transport == "torch" and time.time() - t0 < 5.0
+        assert c.attach_error is not None and c.attach_stuck == (mode == "hang")
