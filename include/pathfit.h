@@ -239,9 +239,11 @@ int pf_mpa_memory(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_sl
 /* Tuning knobs (results never change): "maaco_pack8_min" ants per batch from which eight ants share a wavefront
  * (default 2048);
  * "mpa_prune" 0/1 exact bound pruning of MPA rebuilds (default 1); "astar_settle" 0/1 closed-set searches (AStarSolver
- * / Dijkstra / GA / PSO decodes) try the parallel label-settling engine first: -1 (default) the Dijkstra variant only,
- * which it always certifies; 1 the A* variant too (exact -- certified or handed back to the sequential loop -- but no
- * faster on tail-bound batches); 0 never (the sequential loop's pop / push counters are the reference's).  Test hook: "astar_step_cap" > 0
+ * / Dijkstra / GA / PSO decodes) try the parallel label-settling engine first: -1 (default) the Dijkstra variant
+ * always (it is always certified) and the A* searches of the decodes at the head of a batch's longest-first queue
+ * ("astar_settle_top", per mille of the batch, default 60: the agents the batch ends on; a decode is a chain of W + 1 searches,
+ * so a fallback costs one link); 1 every A* search too (exact -- certified or handed back to the sequential loop -- but slower
+ * on batches of single searches); 0 never (the sequential loop's pop / push counters are the reference's).  Test hook: "astar_step_cap" > 0
  * lowers the connectors' step cap below the reference's 3RC / 2RC (astar.py:58, MPA.py:118) so that the cap path
  * (PF_ST_STEP_CAP) can be exercised; 0 restores the reference's value.  "mpa_doubt_log_e15" / "mpa_doubt_round_e15":
  * margins (in 1e-15; < 0 = default) inside which an MPA proposal is handed to the host's libm (tests widen them to

@@ -47,6 +47,8 @@ struct Common {
   // parallel closed-set engine (pf_settle.h): per-slot label / touched / parent arrays, or null (off)
   unsigned long long* st_lab; int* st_touched; unsigned char* st_par; unsigned* st_epoch;
   bool st_astar;         // also for the A* variant (else Dijkstra only)
+  int st_top;            // ... or only for the items at queue positions below this (the longest-expected ones: the batch ends on
+                         // them, and the engine shortens a search's chain at the price of more traffic per node)
 };
 
 PF_DEV Open make_open(char* smem, int /*S*/, char* tier2) {
@@ -92,9 +94,10 @@ PF_DEV int next_work(int* work, int lane) {
 }
 // dynamic work distribution in longest-expected-first order (the batch finishes when its longest search
 // does, so long searches must start first); returns -1 when the queue is drained
-PF_DEV int next_agent(const Common& c, int n, int lane) {
+PF_DEV int next_agent(const Common& c, int n, int lane, int* pos = nullptr) {
   const int w = next_work(c.work, lane);
   if (w >= n) return -1;
+  if (pos) *pos = w;
   return c.queue ? c.queue[w] : w;
 }
 PF_DEV void flush_counters(DevCounters* c, const AStat& st, unsigned long long cells, unsigned long long ovf, int lane) {
@@ -197,9 +200,11 @@ __global__ __launch_bounds__(64) void k_astar_batch(AstarArgs p) {
   AStat tot = {0, 0, 0, 0, 0, 0};
   unsigned long long cells = 0, ovf = 0;
   for (;;) {
-    const int a = next_agent(p.c, p.n, lane);
+    int qpos = 0;
+    const int a = next_agent(p.c, p.n, lane, &qpos);
     if (a < 0) break;
     if (p.c.retry && p.status[a] != 3) continue;
+    s.sm.astar_too = p.c.st_astar || (p.c.queue && qpos < p.c.st_top);
     slot_begin_eval(s, RC, lane);
     if (p.avoid_off) {
       const long long b = p.avoid_off[a], e = p.avoid_off[a + 1];
@@ -266,9 +271,11 @@ __global__ __launch_bounds__(64) void k_decode_batch(DecodeArgs p) {
   AStat tot = {0, 0, 0, 0, 0, 0};
   unsigned long long cells = 0, ovf = 0;
   for (;;) {
-    const int a = next_agent(p.c, p.n, lane);
+    int qpos = 0;
+    const int a = next_agent(p.c, p.n, lane, &qpos);
     if (a < 0) break;
     if (p.c.retry && p.status[a] != 3) continue;
+    s.sm.astar_too = p.c.st_astar || (p.c.queue && qpos < p.c.st_top);
     slot_begin_eval(s, RC, lane);
     int* out = p.cells + (size_t)a * p.path_cap;
     int n = 1, cur = p.start, rc = 0;
@@ -1888,6 +1895,8 @@ static int env_int(const char* name, int dflt) { const char* v = getenv(name); r
 static const int kSlotsPerCU = 8;                       // resident one-agent waves per CU at most
 static const int kWavesPerCU = env_int("PF_WAVES_PER_CU", 8);   // resident one-agent waves per CU (LDS permitting)
 static int g_mpa_prune = 1;   // exact bound pruning of MPA rebuilds (pf_set_option "mpa_prune")
+static int g_settle_top = env_int("PF_SETTLE_TOP", 60);  // auto mode ("astar_settle" -1): per mille of a DECODE batch, from the head of the longest-first queue, whose A* searches
+                                                         // also try the engine (pf_set_option "astar_settle_top")
 static int g_settle = env_int("PF_SETTLE", -1);  // closed-set searches try the 64-nodes-per-trip engine first (pf_settle.h; pf_set_option "astar_settle"):
                                                   // -1 (default) Dijkstra only -- h == 0 makes every node regular, so it is never handed back, and it measures
                                                   // 1.6x (2048 concurrent searches) to 3.5x (one search) faster; 1 also A* (exact too -- certified or handed back --
@@ -1949,7 +1958,7 @@ static Common make_common(pf_handle* h, int allow_diag, int restrict_corner, int
   c.G = make_grid(h, allow_diag, restrict_corner);
   c.rec = h->d_rec; c.tier2 = h->d_tier2; c.slot_state = h->d_slot_state; c.work = h->d_work; c.queue = nullptr; c.cnt = h->d_cnt; c.S = S; c.retry = retry;
   const bool st_on = g_settle != 0 && h->d_st_lab;
-  c.st_lab = st_on ? h->d_st_lab : nullptr; c.st_astar = g_settle > 0; c.st_touched = h->d_st_touched; c.st_par = h->d_st_par; c.st_epoch = h->d_st_epoch;
+  c.st_lab = st_on ? h->d_st_lab : nullptr; c.st_astar = g_settle > 0; c.st_top = 0; c.st_touched = h->d_st_touched; c.st_par = h->d_st_par; c.st_epoch = h->d_st_epoch;
   return c;
 }
 static int begin_batch(pf_handle* h) {
@@ -2057,6 +2066,8 @@ int pf_astar_batch(pf_handle* h, int32_t variant, int32_t allow_diag, int32_t re
   if (n > 64) {
     if (make_queue(h, n, [&](float* est) { hipLaunchKernelGGL(k_plan_astar, dim3((n + 255) / 256), dim3(256), 0, h->stream, a.c.G, n, d_start, d_target, est); })) return -1;
     a.c.queue = h->d_queue;
+    // (no head-of-queue settling here: a batch of single searches ends on its longest search, and the longest searches are the
+    // ones that meet an anomaly and fall back -- astar1024: 182 -> 237 ms with 3 % of the items settled)
   }
   // sparse maps (plateaus of equal f along open runs) go to the separately compiled kernels with the plateau refills
   const bool plat = plateau_map(h);
@@ -2104,6 +2115,10 @@ int pf_decode_batch(pf_handle* h, int32_t allow_diag, int32_t restrict_corner, i
   if (n > 64) {
     if (make_queue(h, n, [&](float* est) { hipLaunchKernelGGL(k_plan_decode, dim3((n + 255) / 256), dim3(256), 0, h->stream, a.c.G, n, W, d_wp_cells, d_wp_pos, start, target, est); })) return -1;
     a.c.queue = h->d_queue;
+    // A decode is a chain of W + 1 closed-set searches, so a fallback costs one link, not the chain: the agents at the head of
+    // the longest-first queue (the ones the batch ends on) try the parallel settling engine, which shortens their chains
+    // 1.6x; the others stay sequential, which costs less traffic per node.  ga512 121 -> 108 ms, pso512 60.4 -> 55.9 ms at 6 %.
+    if (g_settle < 0) a.c.st_top = (int)((long long)n * g_settle_top / 1000);
   }
   return plateau_map(h) ? launch_with_retry(h, k_decode_batch<true>, a, n) : launch_with_retry(h, k_decode_batch<false>, a, n);
 }
@@ -2194,6 +2209,7 @@ int pf_set_option(pf_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "maaco_pack8_min")) { g_maaco_pack8_min = (int)value; return 0; }
   if (!strcmp(name, "mpa_prune")) { g_mpa_prune = value != 0; return 0; }
   if (!strcmp(name, "astar_settle")) { g_settle = value < 0 ? -1 : (value != 0); return 0; }
+  if (!strcmp(name, "astar_settle_top")) { g_settle_top = value < 0 ? 0 : (value > 1000 ? 1000 : (int)value); return 0; }
   if (!strcmp(name, "plateau_kernels")) { g_plateau_mode = (int)value; return 0; }
   if (!strcmp(name, "maaco_tabu_epoch")) { g_tabu_epoch = (int)value; return 0; }
   if (!strcmp(name, "mpa_doubt_log_e15")) { g_doubt_log = value < 0 ? 1.0 / 8589934592.0 : (double)value * 1e-15; return 0; }

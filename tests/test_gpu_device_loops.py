@@ -296,3 +296,36 @@ def test_sharded_solvers_over_rccl_loopback():
     e4 = pathfit.Engine(g)
     ga, ga0 = ShardedGA(comm_for(e4), g, engine=e4, seed=4, **GA_KW), pathfit.GASolver(g, seed=4, **GA_KW)
     assert ga.solve() == ga0.solve() and ga.convergence_curve == ga0.convergence_curve
+
+
+def test_head_of_queue_settling_leaves_decodes_unchanged():
+    """Default mode (`astar_settle` -1): the decodes at the head of a batch's longest-first queue try the parallel settling
+    engine (`astar_settle_top` per mille of the batch), the others the sequential loop.  Whatever the share, paths, statuses
+    and scores are those of the all-sequential batch."""
+    import pathfit
+    g = gio.grid("g256")[0]
+    e = pathfit.Engine(g)
+    n, W, cap = 300, 4, 8 * 256 + 64
+    rng = np.random.default_rng(5)
+    free = np.flatnonzero(g.reshape(-1) != 1)
+    d_wp = e.put(rng.choice(free, (n, W)).astype(np.int32).reshape(-1))
+    sp = pathfit.score_params(0, True, 0.3, 0.8, 1.8, 100.0)
+    outs = []
+    try:
+        for mode, top in ((0, 0), (-1, 0), (-1, 60), (-1, 500), (-1, 1000), (1, 0)):
+            e.set_option("astar_settle", mode); e.set_option("astar_settle_top", top)
+            dc, dl, ds, dst = e.buf((n, cap), np.int32), e.buf(n, np.int32), e.buf(n, np.int32), e.buf((n, 5), np.float64)
+            e.decode_batch(n, W, 0, g.size - 1, cap, dc, dl, ds, d_wp, None, sp, dst)
+            c = e.counters()
+            outs.append((dc.download(), dl.download(), ds.download(), dst.download(), c["settled_searches"] + c["sequential_searches"]))
+    finally:
+        e.set_option("astar_settle", -1); e.set_option("astar_settle_top", 60)
+    ref = outs[0]
+    assert ref[4] == 0 and outs[1][4] == 0                    # nothing tries the engine with a share of 0
+    tried = [o[4] for o in outs]
+    assert 0 < tried[2] < tried[3] < tried[4] == tried[5]     # 6 % < 50 % < everything == `astar_settle` 1
+    for o in outs[1:]:
+        assert np.array_equal(ref[1], o[1]) and np.array_equal(ref[2], o[2]) and np.array_equal(ref[3], o[3])
+        for i in range(n):
+            assert np.array_equal(ref[0][i, :ref[1][i]], o[0][i, :o[1][i]]), i
+    assert (ref[1] > 0).sum() > n // 2
