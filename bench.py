@@ -153,7 +153,7 @@ class Run:
             def step():
                 eng.decode_batch(per_gpu, 5, 0, 512 * 512 - 1, cap, d_cells, d_len, d_st, d_wp, None, sp, d_stats)
                 if world > 1:       # C3: the tournament needs the whole fitness column
-                    comm.all_gather_concat(d_stats.download()[:, 4], [per_gpu] * world)
+                    comm.all_gather_host(d_stats.download()[:, 4])
             self.step = self.warm = step
             self.cfg = {"workload": f"GA chained-waypoint decode+score of one generation's children, W=5, {per_gpu} agents/GPU, G512 "
                                     "(BASELINE.json configs[3] per-GPU share)", "agents_per_gpu": per_gpu,
