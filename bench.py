@@ -166,9 +166,10 @@ class Run:
                                     "(BASELINE.json configs[3] per-GPU share)", "agents_per_gpu": per_gpu,
                         "grid_sha256": env.grid_hash(grid)[:16]}
 
-            def make(iters):
-                return pathfit.PSOSolver(grid, num_iterations=iters, num_particles=per_gpu, num_waypoints_per_particle=5, w=0.7,
-                                         c1=1.5, c2=1.5, engine=eng, seed=a.seed, asynchronous=not a.pso_sync, **W_MAIN)
+            def make(iters):       # N > 1: one swarm of per_gpu x world particles, sharded in blocks (the asynchronous gbest is repaired across ranks)
+                return pathfit.PSOSolver(grid, num_iterations=iters, num_particles=per_gpu * world, num_waypoints_per_particle=5, w=0.7,
+                                         c1=1.5, c2=1.5, engine=eng, seed=a.seed, asynchronous=not a.pso_sync,
+                                         comm=comm if world > 1 else None, **W_MAIN)
             st = {"ps": None}
 
             def warm():
