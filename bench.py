@@ -150,10 +150,13 @@ class Run:
                                              eng.buf((per_gpu, 5), np.float64))
             d_wp = eng.put(rng.choice(free, (per_gpu, 5)).astype(np.int32).reshape(-1))
 
+            d_fit_loc, d_fit_all = eng.buf(per_gpu, np.float64), eng.buf(per_gpu * world, np.float64)
+
             def step():
                 eng.decode_batch(per_gpu, 5, 0, 512 * 512 - 1, cap, d_cells, d_len, d_st, d_wp, None, sp, d_stats)
-                if world > 1:       # C3: the tournament needs the whole fitness column
-                    comm.all_gather_host(d_stats.download()[:, 4])
+                if world > 1:       # C3: the tournament needs the whole fitness column -- device column to device column
+                    eng.gather_col(per_gpu, d_stats, 5, 4, d_fit_loc)
+                    comm.all_gather(d_fit_loc, 0, d_fit_all, [per_gpu] * world)
             self.step = self.warm = step
             self.cfg = {"workload": f"GA chained-waypoint decode+score of one generation's children, W=5, {per_gpu} agents/GPU, G512 "
                                     "(BASELINE.json configs[3] per-GPU share)", "agents_per_gpu": per_gpu,
@@ -250,6 +253,74 @@ def traffic_note(roof, workload):
         return
 
 
+RC_RCCL_STUCK = 75      # a rank whose direct-RCCL bootstrap never returned: the process is abandoned, a fresh one retries host-staged
+
+
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(n, argv, worker=None, env_extra=None, timeout=None):
+    """`python bench.py --gpus N` without torchrun: start N rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as
+    torch.distributed.run would), relay rank 0's JSON line, and fail loudly if any rank fails or the line does not report
+    N ranks.  Runs BEFORE anything in this process has touched the GPU (no torch / pathfit import above this point), and
+    never re-execs: the ranks are ordinary child processes.  `worker` replaces [python, bench.py] (the CPU test's stub).
+    Returns (exit code, the JSON line or None)."""
+    import subprocess
+    cmd = list(worker) if worker else [sys.executable, os.path.abspath(__file__)]
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.update(env_extra or {})
+        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    line, rcs = None, []
+    t_end = None if timeout is None else time.monotonic() + timeout
+    try:
+        out0, _ = procs[0].communicate(timeout=timeout)
+        for ln in out0.splitlines():
+            if ln.startswith("{") and '"metric"' in ln:
+                line = ln
+        for pr in procs:
+            rcs.append(pr.wait(timeout=None if t_end is None else max(1.0, t_end - time.monotonic())))
+    except subprocess.TimeoutExpired:
+        rcs = [124]
+    finally:
+        for pr in procs:                      # exactly the processes started here, by pid
+            if pr.poll() is None:
+                pr.kill()
+    if any(rc != 0 for rc in rcs):
+        print(f"[bench launcher] rank exit codes {rcs}", file=sys.stderr)
+        return (next(rc for rc in rcs if rc != 0) or 1), line
+    if line is None:
+        print("[bench launcher] rank 0 printed no JSON line", file=sys.stderr)
+        return 1, None
+    try:
+        got = json.loads(line).get("n_gpus")
+    except Exception:
+        got = None
+    if got != n:
+        print(f"[bench launcher] the line reports n_gpus={got!r}, {n} ranks were started", file=sys.stderr)
+        return 1, line
+    return 0, line
+
+
+def _retry_host_staged(a):
+    """This rank's direct-RCCL bootstrap thread is stuck inside the library: the handle it shares with this thread must not
+    be used again.  Every rank reached the same verdict (attach_checked all-reduces it), so every rank starts ONE fresh child
+    process of itself with PF_BENCH_TRANSPORT=torch on the next port, relays its output and exits with its code."""
+    import subprocess
+    env = dict(os.environ, PF_BENCH_TRANSPORT="torch", PF_BENCH_RETRIED="1",
+               MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 1))
+    rc = subprocess.call([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env)
+    sys.stdout.flush(); sys.stderr.flush()
+    os._exit(rc)              # (the stuck thread would hold a normal interpreter exit up)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -272,6 +343,11 @@ def main():
         from pathfit import env as env_
         print(json.dumps(_mpa_cpu_slice(env_.bench_grid(512), a.seed, lo, hi, a.cpu_seconds)), flush=True)
         return
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:                      # not under torchrun: start the N ranks ourselves
+        rc, line = launch_ranks(a.gpus, sys.argv[1:])
+        if line is not None:
+            print(line, flush=True)
+        sys.exit(rc)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -303,7 +379,7 @@ def main():
     # N > 1: RCCL over xGMI bound directly (pf_comm_*, device pointers on the engine's stream); torch.distributed only ships the
     # 128-byte unique id and, below, reduces the wall time.  PF_BENCH_TRANSPORT=torch keeps the host-staged torch collectives.
     # ("rccl!" tries the direct binding whatever the torch backend is: the rehearsal of its failure path on one shared GPU)
-    tr_env = os.environ.get("PF_BENCH_TRANSPORT", "rccl")
+    tr_env = os.environ.get("PF_BENCH_TRANSPORT", "rccl")       # (a retry after a stuck bootstrap sets "torch")
     use_rccl = dist is not None and ((a.backend == "nccl" and tr_env == "rccl") or tr_env == "rccl!")
     comm = Comm(dist, torch.device("cuda", local_rank) if (dist is not None and a.backend == "nccl") else None,
                 transport="rccl" if use_rccl else None)
@@ -317,7 +393,12 @@ def main():
             # if it cannot start everywhere, every rank uses the host-staged torch collectives instead
             if not comm.attach_checked(eng, timeout=float(os.environ.get("PF_COMM_TIMEOUT", "120"))):
                 print(f"[bench] pf_comm (RCCL direct) unavailable (rank {rank}: {comm.attach_error!r}); all ranks fall back to "
-                      "torch.distributed", file=sys.stderr)
+                      "torch.distributed" + (" in fresh processes (a bootstrap thread is stuck)" if comm.attach_stuck else ""), file=sys.stderr)
+                if comm.attach_stuck:
+                    if os.environ.get("PF_BENCH_RETRIED"):
+                        sys.stdout.flush(); sys.stderr.flush()
+                        os._exit(RC_RCCL_STUCK)
+                    _retry_host_staged(a)       # does not return
 
         def sync_all():
             if torch is not None and torch.cuda.is_available():
@@ -381,9 +462,6 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
-    if getattr(comm, "attach_stuck", False):         # a bootstrap thread that never returned must not hold the exit up
-        sys.stdout.flush(); sys.stderr.flush()
-        os._exit(0)
 
 
 def _mpa_cpu_slice(grid, seed, lo, hi, budget_s):

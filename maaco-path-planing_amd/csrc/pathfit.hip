@@ -2318,7 +2318,7 @@ int pf_maaco_walk_batch(pf_handle* h, int32_t iter, uint64_t seed, int32_t ant0,
   if (!h) return -2;
   if (!h->maaco_ready) return failmsg(h, "pf_maaco_walk_batch: call pf_maaco_setup first");
   if (n < 0 || path_cap < 2 || !d_cells || !d_len || !d_plen || !d_turns || !d_status) return failmsg(h, "pf_maaco_walk_batch: bad arguments");
-  if (n == 0) return 0;
+  if (n == 0) { memset(&h->last, 0, sizeof(h->last)); return 0; }   // an empty batch has empty counters (not the previous batch's overflow)
   CK(hipSetDevice(h->device));
   MaacoArgs a;
   a.G = make_grid(h, 1, 1);
@@ -3083,11 +3083,20 @@ int pf_comm_recv(pf_handle* h, void* d_buf, int64_t bytes, int32_t peer) {
 // one step of a ring: send to `to` and receive from `from` as ONE group (both directions progress together)
 int pf_comm_sendrecv(pf_handle* h, const void* d_send, int64_t send_bytes, int32_t to, void* d_recv, int64_t recv_bytes, int32_t from) {
   NEED_COMM(h);
-  if (send_bytes < 0 || recv_bytes < 0) return failmsg(h, "pf_comm_sendrecv: bad arguments");
+  const bool snd = send_bytes > 0 && to >= 0, rcv = recv_bytes > 0 && from >= 0;
+  if (send_bytes < 0 || recv_bytes < 0 || (snd && (!d_send || to >= h->comm_world || to == h->comm_rank)) ||
+      (rcv && (!d_recv || from >= h->comm_world || from == h->comm_rank)))
+    return failmsg(h, "pf_comm_sendrecv: bad arguments");
   NK(g_rccl.GroupStart());
-  if (send_bytes && to >= 0) NK(g_rccl.Send(d_send, (size_t)send_bytes, ncclInt8, to, h->comm, h->stream));
-  if (recv_bytes && from >= 0) NK(g_rccl.Recv(d_recv, (size_t)recv_bytes, ncclInt8, from, h->comm, h->stream));
-  NK(g_rccl.GroupEnd());
+  // an error between GroupStart and GroupEnd must still close the group: an open group would silently swallow every later
+  // collective of this thread
+  ncclResult_t r1 = ncclSuccess, r2 = ncclSuccess;
+  if (snd) r1 = g_rccl.Send(d_send, (size_t)send_bytes, ncclInt8, to, h->comm, h->stream);
+  if (rcv && r1 == ncclSuccess) r2 = g_rccl.Recv(d_recv, (size_t)recv_bytes, ncclInt8, from, h->comm, h->stream);
+  const ncclResult_t r3 = g_rccl.GroupEnd();
+  if (r1 != ncclSuccess) return nccl_fail(h, "ncclSend (pf_comm_sendrecv)", r1);
+  if (r2 != ncclSuccess) return nccl_fail(h, "ncclRecv (pf_comm_sendrecv)", r2);
+  if (r3 != ncclSuccess) return nccl_fail(h, "ncclGroupEnd (pf_comm_sendrecv)", r3);
   return 0;
 }
 int pf_comm_rank(pf_handle* h) { return h ? h->comm_rank : 0; }

@@ -5,7 +5,7 @@
 //
 //   pool    entries live unsorted in HBM buckets keyed by floor(f * Q) (Q = 128, 512 circular buckets: a push is at
 //           most 2*sqrt(2) above the pop that made it, 363 buckets); an append is one LDS atomic for the slot
-//           index and three fire-and-forget stores -- nothing waits for it;
+//           index and ONE fire-and-forget 16-byte store of (g, cell) -- nothing waits for it;
 //   window  when the window runs dry the next non-empty buckets (<= 64 entries) are loaded one entry per lane and
 //           sorted on the full key (f, g, cell): the buckets already are in key order, so each entry only has to be
 //           ranked inside its own bucket (sort_runs; a bitonic network over the lanes is kept for buckets larger than

@@ -156,15 +156,26 @@ class Comm:
     def attach_checked(self, engine, timeout=120.0):
         """attach() plus one all_gather of the rank numbers through the new communicator, run in a helper thread so that a
         bootstrap that never returns cannot take the caller with it; every rank then learns, through torch.distributed,
-        whether ALL ranks made it.  Returns True when the rccl transport is usable everywhere; otherwise this rank's
-        transport falls back to the host-staged torch collectives (and so does every other rank's: same verdict)."""
+        whether ALL ranks made it.  Returns True when the rccl transport is usable everywhere.
+
+        Otherwise there are two cases.  (a) Every helper thread came back (librccl missing, an error code): this rank's
+        transport falls back to the host-staged torch collectives -- and so does every other rank's (same verdict).
+        (b) Some rank's helper is still inside the library at the deadline (`attach_stuck`, the same on every rank): that
+        thread shares the engine handle and its stream with the caller, so the handle must not be used again -- the caller
+        has to abandon this process for GPU work (bench.py starts a fresh one with PF_BENCH_TRANSPORT=torch).  A helper that
+        wakes up after the deadline sees `cancelled`, destroys the communicator it may have made and touches neither the
+        engine nor its stream."""
         import threading
         ok = [False]
         err = [None]
+        cancelled = threading.Event()
 
         def work():
             try:
                 self.attach(engine)
+                if cancelled.is_set():                 # too late: the verdict is out.  No probe collective, no engine calls.
+                    engine.L.pf_comm_destroy(engine.h)
+                    return
                 if self.world > 1:
                     mine = engine.put(np.array([self.rank], np.int32), np.int32)
                     allr = engine.buf(self.world, np.int32)
@@ -178,16 +189,20 @@ class Comm:
         th = threading.Thread(target=work, daemon=True)
         th.start()
         th.join(timeout)
-        good = ok[0] and not th.is_alive()
-        self.attach_stuck = th.is_alive()
-        self.attach_error = err[0] if err[0] is not None else ("timed out" if th.is_alive() else None)
+        stuck = th.is_alive()
+        if stuck:
+            cancelled.set()
+        good = ok[0] and not stuck
+        self.attach_error = err[0] if err[0] is not None else ("timed out" if stuck else None)
         if self.dist is not None and self.world > 1:
             import torch
-            t = torch.tensor([1 if good else 0], dtype=torch.int32)
+            t = torch.tensor([1 if good else 0, 0 if stuck else 1], dtype=torch.int32)
             if self.device is not None:
                 t = t.to(self.device)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
-            good = bool(int(t.cpu()[0]))
+            t = t.cpu()
+            good, stuck = bool(int(t[0])), not bool(int(t[1]))
+        self.attach_stuck = stuck              # on ANY rank: a peer that did initialise would wait for it in the first collective
         if not good:
             self.transport = "torch"
             self.engine = engine
@@ -348,18 +363,25 @@ class ShardedMAACO:
             (abs(ib_len - m.best_path_length_overall) < 1e-9 and ib_turns < m.best_path_turns_overall)
         if take and ib_idx >= 0:
             r, li = owner_of(ib_idx, self.counts)
-            # the winner's path row travels only now, when the overall best changes: [len, cells...] from its owner
-            if getattr(self, "_row", None) is None:
-                self._row = _mkbuf(e, m.path_cap + 1, np.int32)
+            # the winner's path row travels only now, when the overall best changes: its length first, then exactly that many
+            # cells.  (Never `path_cap` cells: a rank whose ant overflowed has grown ITS path_cap in walk_iteration_dev, so
+            # the ranks need not agree on it -- the count of a collective must not depend on it.)
+            if getattr(self, "_hdr", None) is None:
+                self._hdr = _mkbuf(e, 1, np.int32)
             if r == c.rank:
-                self._row.copy_from(0, dl, li, 1)
-                self._row.copy_from(1, dc, li * m.path_cap, m.path_cap)
-            c.broadcast(self._row, 0, m.path_cap + 1, r)
-            L = int(self._row.read(0, 1)[0])
+                self._hdr.copy_from(0, dl, li, 1)
+            c.broadcast(self._hdr, 0, 1, r)
+            L = int(self._hdr.read(0, 1)[0])
+            if getattr(self, "_row", None) is None or self._row_cap < L:
+                self._row_cap = max(L, m.path_cap)
+                self._row = _mkbuf(e, self._row_cap, np.int32)
+            if r == c.rank:
+                self._row.copy_from(0, dc, li * m.path_cap, L)
+            c.broadcast(self._row, 0, L, r)
             from .paths import CellPath
             if ib_len < m.best_path_length_overall:
                 m.best_path_length_overall = ib_len
-            m.best_path_overall = CellPath(self._row.read(1, L), m.cols).tolist()
+            m.best_path_overall = CellPath(self._row.read(0, L), m.cols).tolist()
             m.best_path_turns_overall = int(ib_turns) if ib_turns != INF else INF
         self._update_pheromone(n)
         m.convergence_curve_data.append(m.best_path_length_overall if m.best_path_length_overall != INF else None)

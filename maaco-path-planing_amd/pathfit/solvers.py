@@ -602,20 +602,34 @@ class PSOSolver(_WaypointSolver):
 
     # gbest_particle_data / particles are the reference's public attributes (pso.py:37-38); while a solve is running
     # they live in HBM and are materialised only when somebody reads them
+    def fetch_gbest(self):
+        """Sharded runs: bring the gbest's stats and path row from the rank that owns them to every rank.  A COLLECTIVE --
+        every rank must call it (finish() does); reading `gbest_particle_data` never communicates."""
+        d = getattr(self, "_gbest_dev", None)
+        c = self.comm
+        if d is None or c is None or c.world == 1 or self._gowner < 0:
+            return
+        e = self.engine
+        hdr = self._d.setdefault("ghdr", e.buf(8, np.float64))
+        if c.rank == self._gowner:
+            hdr.write(0, d["stats"])
+        c.broadcast(hdr, 0, 5, self._gowner)
+        c.broadcast(self._d["gpath"], 0, 1, self._gowner)               # the length, then exactly that many cells
+        L = int(self._d["gpath"].read(0, 1)[0])
+        c.broadcast(self._d["gpath"], 1, L, self._gowner)
+        self._gbest_dev = dict(d, stats=hdr.read(0, 5), len=L)
+        self._gowner = c.rank                                            # every rank holds the row now
+
     @property
     def gbest_particle_data(self):
         if getattr(self, "_gbest_dev", None) is not None:
             d = self._gbest_dev
             e, c = self.engine, self.comm
-            if c is not None and c.world > 1:             # the path row and the stats live on the owner: fetch them (collective!)
-                hdr = self._d.setdefault("ghdr", e.buf(8, np.float64))
-                if c.rank == self._gowner:
-                    hdr.write(0, d["stats"])
-                c.broadcast(hdr, 0, 5, self._gowner)
-                c.broadcast(self._d["gpath"], 0, self._cap + 1, self._gowner)
-                d = dict(d, stats=hdr.read(0, 5), len=int(self._d["gpath"].read(0, 1)[0]))
+            pos = e.read(self._d["gb"].ptr, self.num_waypoints * 2, np.float64).reshape(-1, 2)   # (every rank holds the position)
+            if c is not None and c.world > 1 and c.rank != self._gowner:
+                # purely local view: the path row and the stats live on the owner until fetch_gbest() (a collective) is called
+                return {"fitness": float(d["fitness"]), "position": pos.tolist(), "path": None, "index": d["idx"], "owner_rank": self._gowner}
             cells = self._d["gpath"].read(1, d["len"])
-            pos = e.read(self._d["gb"].ptr, self.num_waypoints * 2, np.float64).reshape(-1, 2)
             self._set_gbest(d["idx"], pos, CellPath(cells, self.cols), d["stats"])
         return self._gbest
 
@@ -798,6 +812,7 @@ class PSOSolver(_WaypointSolver):
         self._download_state()
         self._sync_particles()
         self._particles_stale = False
+        self.fetch_gbest()
         res = self.gbest_particle_data
         path = res["path"].tolist() if isinstance(res["path"], CellPath) else res["path"]
         res["path"] = path

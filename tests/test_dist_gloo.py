@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KW = dict(alpha=1.0, beta=2.0, rho=0.1, Q=2.5, a_turn_coef=1.0, wh_max=0.9, wh_min=0.2, k_h_adaptive=0.9, q0_initial=0.5)
 
 
-def _worker(rank, world, port, out_dir, strict, ants=21, chunks=8):
+def _worker(rank, world, port, out_dir, strict, ants=21, chunks=8, cap_factor=None):
     for p in (os.path.join(ROOT, "maaco-path-planing_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
     import torch.distributed as dist
@@ -24,6 +24,8 @@ def _worker(rank, world, port, out_dir, strict, ants=21, chunks=8):
     g, s, t = gio.grid("fig7")
     comm = Comm(dist, None)           # transport: gloo (host staged) -- the exchange logic is transport independent
     sm = ShardedMAACO(comm, lambda: FakeMAACO(g, s, t, ants, 5, 7, **KW), ants, strict=strict, chunks=chunks)
+    if cap_factor:                    # this rank's walk "overflowed and grew its path rows" (MAACO.walk_iteration_dev): path_cap differs per rank
+        sm.local.path_cap *= cap_factor[rank]
     path, length, turns = sm.solve_path_planning()
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), path=np.array(path), length=length, turns=turns,
              tau=sm.local.engine.maaco_get_pheromone(), curve=np.array(sm.local.convergence_curve_data, float))
@@ -70,6 +72,18 @@ def test_sharded_maaco_three_ranks_uneven_blocks_pipelined_fold(tmp_path):
         assert np.array_equal(z["curve"], ref[4]) and np.array_equal(z["tau"], ref[3])
 
 
+def test_sharded_maaco_ranks_with_different_path_cap(tmp_path):
+    """One rank has grown its path rows (an ant overflowed there, only there): the exchange must not depend on path_cap being
+    the same everywhere -- the best row travels as (length, exactly that many cells)."""
+    import torch.multiprocessing as mp
+    port = 25100 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), True, 21, 8, (1, 4)), nprocs=2, join=True)
+    ref = _single(True)
+    for r in (0, 1):
+        z = np.load(tmp_path / f"r{r}.npz")
+        assert np.array_equal(z["path"], ref[0]) and float(z["length"]) == ref[1] and np.array_equal(z["tau"], ref[3])
+
+
 def test_single_rank_sharded_equals_oracle_loop():
     import pf_loops, pf_oracle as po, golden_io as gio
     g, s, t = gio.grid("fig7")
@@ -110,6 +124,42 @@ def test_attach_checked_falls_back_when_the_binding_cannot_start():
     class _Eng:
         def __init__(self, mode):
             self.L, self.h = _L(mode), None
+
+    calls = []
+
+    class _Late:                                       # pf_comm_init returns AFTER the deadline: the helper must not touch the engine
+        def pf_comm_unique_id(self, buf):
+            time.sleep(0.6)
+            return 0
+
+        def pf_comm_init(self, h, rank, world, idb):
+            calls.append("init")
+            return 0
+
+        def pf_comm_destroy(self, h):
+            calls.append("destroy")
+            return 0
+
+        def pf_comm_all_gather(self, *a):
+            calls.append("probe")
+            return 0
+
+    class _LateEng:
+        L, h = _Late(), None
+
+        def _ck(self, rc):
+            assert rc == 0
+
+        def put(self, *a):
+            calls.append("put")
+
+        def buf(self, *a):
+            calls.append("buf")
+
+    c = Comm(None, None, transport="rccl")
+    assert c.attach_checked(_LateEng(), timeout=0.2) is False and c.attach_stuck
+    time.sleep(1.0)
+    assert calls == ["init", "destroy"], calls
 
     for mode, timeout in (("fail", 5.0), ("hang", 0.3)):
         c = Comm(None, None, transport="rccl")
