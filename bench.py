@@ -38,7 +38,7 @@ MAACO_MAIN = dict(alpha=1.0, beta=7.0, rho=0.1, Q=2.5, a_turn_coef=1.0, wh_max=0
 W_MAIN = dict(turn_penalty_factor=0.3, safety_penalty_factor=0.8, min_safe_distance=1.8,
               diagonal_obstacle_penalty_value=100.0)                                 # main.py:21-24
 WORKLOADS = ["mpa512", "maaco512", "pso512", "ga512", "maaco128", "maaco1024", "astar1024"]
-DOMINANT = {"mpa512": ("mpa_sweep", "k_mpa_sweep"), "ga512": ("decode", "k_decode_batch"), "pso512": ("decode", "k_decode_batch"),
+DOMINANT = {"mpa512": ("mpa_sweep", "k_mpa_search"), "ga512": ("decode", "k_decode_batch"), "pso512": ("decode", "k_decode_batch"),
             "astar1024": ("astar", "k_astar_batch"), "maaco128": ("maaco_walk", "k_maaco_walk"),
             "maaco512": ("maaco_walk", "k_maaco_walk8"), "maaco1024": ("maaco_walk", "k_maaco_walk8")}
 

@@ -1264,101 +1264,123 @@ __global__ __launch_bounds__(64) void k_mpa_fads(MpaFadsArgs p) {
   flush_counters(p.c.cnt, tot, cells, ovf, lane);
 }
 
-// Fused sweep: phase items [0,n) and FADs candidate items [n,2n) share one longest-first work queue, so an
-// iteration pays ONE tail instead of two (the FADs candidates are population independent).
+// The sweep of one iteration: phase items [0,n) and FADs candidate items [n,2n) share one longest-first work queue, so an
+// iteration pays ONE tail instead of two (the FADs candidates are population independent).  Three passes:
+//   k_mpa_plan    one wave per item: which searches, if any (MpaPlan, the gate's verdict from k_mpa_propose, the exact
+//                 pruning bound, the FADs gating draws) -> a 32-byte job;
+//   k_mpa_search  persistent waves over the queue: nothing but the (up to) two chained MPA._a_star calls of a job, through
+//                 ONE astar<1> call site -- the pop loop is the kernel's hot code, and everything else that used to live in
+//                 the fused kernel (plans, gates, scoring, the FADs branch) cost it registers: 160 VGPR / 241 SGPR spills
+//                 against 118 / 97 for the bare connector;
+//   k_mpa_finish  one wave per item: endpoint check, score_path, the fall-back to the unmodified path, FADs candidates.
 struct MpaSweepArgs { MpaPhaseArgs ph; MpaFadsArgs fd; };
+struct __attribute__((aligned(16))) MpaJob {
+  const int* src;     // phase items: the path whose prefix [0, n0) starts the rebuilt path (and whose [0, n0 - 1) is the avoid set)
+  int n0;             // cells of src to copy (phase: idx + 1; FADs: 0 -- the first search writes the start itself)
+  int astart, g0, g1; // searches astart -> g0 (skipped when g0 < 0) then -> g1
+  int kind;           // 0: nothing to search, 1: phase item, 2: FADs detour
+  int aux;            // kind 0: phase -> status for k_mpa_finish (4 unmodified, 3 overflow); FADs -> 1 copy the memoised initial path, 3 overflow, 0 none
+};
+struct MpaRes { int n, rc; };   // cells in the item's buffer after the searches; rc 0 done, 1 FADs detour failed, 3 scratch / path overflow
 
-// One item of the fused sweep: phase item (item < n) or FADs candidate item.  Same arithmetic as mpa_phase_item /
-// mpa_fads_item (candidate mode), restated so that both kinds run their (up to) two chained searches through ONE
-// astar<1> call site: the pop loop is the kernel's hot code, and three inlined copies of it (one per call site)
-// did not fit the instruction cache shared by the waves of two CUs.
-__device__ __forceinline__ void mpa_sweep_item(const MpaSweepArgs& q, int item, Slot& s, const Open& O, AStat& tot,
-                               unsigned long long& cells, unsigned long long& ovf, int lane) {
+__global__ __launch_bounds__(64) void k_mpa_plan(MpaSweepArgs q, MpaJob* jobs, MpaRes* res) {
   const MpaPhaseArgs& p = q.ph;
   const MpaFadsArgs& f = q.fd;
   const Grid& G = p.c.G;
-  const int RC = G.R * G.C;
+  const int lane = lane_id();
+  const int item = blockIdx.x;
+  if (item >= 2 * p.n) return;
   const bool isph = item < p.n;
   const int a = isph ? item : item - p.n;
-  // ---- the plan: searches astart -> g0 (skipped when g0 < 0) then -> g1, appended at buf[n-1..] ----
-  bool search = false;
-  int astart = 0, g0 = -1, g1 = p.m.target, n = 0, rc = 4;
-  int* buf = nullptr;
-  // phase state
-  const int* mod = nullptr; int modL = 0; const double* mod_stats = nullptr;
-  int* out = nullptr;
-  // FADs state
-  int slot = 0; bool have = false, have_stats = false;
+  MpaJob j; j.src = nullptr; j.n0 = 0; j.astart = 0; j.g0 = -1; j.g1 = p.m.target; j.kind = 0; j.aux = isph ? 4 : 0;
+  unsigned long long pruned_n = 0;
   if (isph) {
-    const MpaPlan q = mpa_plan(p, a);
-    slot = q.slot;
-    const int* prey = q.prey;
-    const double* prey_stats = q.prey_stats;
-    out = p.out_cells + (size_t)a * p.path_cap;
-    mod = q.mod; modL = q.modL; mod_stats = q.mod_stats;
-    n = modL;                                                     // default: the unmodified path + its stats
-    {
-      const int2 pr = p.prop[a];                                  // k_mpa_propose: {idx or -1, target cell}
-      const int idx = first_i(pr.x);
-      if (idx >= 0) {
-        // ---- _reconstruct_path_segment(mod, ref, idx, is_levy, scale) ----
-        slot_begin_eval(s, RC, lane);
-        const int cur = mod[idx];
-        mark_avoid(s, mod, idx, lane);                            // set(prefix[:-1]) :290
-        const int inter = first_i(pr.y);
-        bool pruned = false;                                      // exact pruning: see mpa_phase_item
-        if (p.m.dt) {
-          double pre = 0.0;
-          for (int i = lane; i < idx; i += 64) {
-            const int dd = mod[i + 1] - mod[i];
-            pre += (dd == 1 || dd == -1 || dd == G.C || dd == -G.C) ? 1.0 : PF_SQRT2;
-          }
-          pre = wave_sum_d(pre);
-          double lb = p.m.dt[cur];
-          if (G.occ[inter] != 1 && inter != cur) {
-            const int r0 = row_of(G, cur), r1 = row_of(G, inter);
-            const long dr_ = r1 - r0, dc_ = (inter - r1 * G.C) - (cur - r0 * G.C);
-            lb = fmin(lb, __builtin_sqrt((double)(dr_ * dr_ + dc_ * dc_)) + p.m.dt[inter]);
-          }
-          lb = (pre + lb) * (1.0 - 1e-9);
-          const double prey_fit = prey_stats[4];
-          pruned = lb >= prey_fit && (mod == prey || mod_stats[4] >= prey_fit);
+    const MpaPlan pl = mpa_plan(p, a);
+    const int2 pr = p.prop[a];                                    // k_mpa_propose: {idx or -1, target cell}
+    const int idx = first_i(pr.x);
+    if (idx >= 0) {
+      // ---- _reconstruct_path_segment(mod, ref, idx, is_levy, scale): (idx <= modL-2 so the :286 early return cannot trigger)
+      const int* mod = pl.mod;
+      const int cur = mod[idx];
+      const int inter = first_i(pr.y);
+      bool pruned = false;                                        // exact pruning: see mpa_phase_item
+      if (p.m.dt) {
+        double pre = 0.0;
+        for (int i = lane; i < idx; i += 64) {
+          const int dd = mod[i + 1] - mod[i];
+          pre += (dd == 1 || dd == -1 || dd == G.C || dd == -G.C) ? 1.0 : PF_SQRT2;
         }
-        if (pruned) ovf += 1ull << 32;
-        else if (idx + 1 > p.path_cap) rc = 3;
-        else {
-          copy_path(out, mod, idx + 1, lane);                     // :296
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          search = true; buf = out; n = idx + 1; astart = cur; rc = 0;
-          g0 = (G.occ[inter] != 1 && inter != cur) ? inter : -1;  // :298
+        pre = wave_sum_d(pre);
+        double lb = p.m.dt[cur];
+        if (G.occ[inter] != 1 && inter != cur) {
+          const int r0 = row_of(G, cur), r1 = row_of(G, inter);
+          const long dr_ = r1 - r0, dc_ = (inter - r1 * G.C) - (cur - r0 * G.C);
+          lb = fmin(lb, __builtin_sqrt((double)(dr_ * dr_ + dc_ * dc_)) + p.m.dt[inter]);
         }
+        lb = (pre + lb) * (1.0 - 1e-9);
+        const double prey_fit = pl.prey_stats[4];
+        pruned = lb >= prey_fit && (mod == pl.prey || pl.mod_stats[4] >= prey_fit);
+      }
+      if (pruned) pruned_n = 1;
+      else if (idx + 1 > p.path_cap) j.aux = 3;
+      else {
+        j.kind = 1; j.src = mod; j.n0 = idx + 1; j.astart = cur;
+        j.g0 = (G.occ[inter] != 1 && inter != cur) ? inter : -1;  // :298
       }
     }
   } else {
-    buf = f.cand_cells + (size_t)a * f.path_cap;
-    const int gi = f.gidx[a];
-    slot = f.slot[a];
-    Rng g; g.init(f.seed, DOM_MPA_FADS, (unsigned long long)f.iter, (unsigned long long)gi);
+    Rng g; g.init(f.seed, DOM_MPA_FADS, (unsigned long long)f.iter, (unsigned long long)f.gidx[a]);
     if (g.random() < f.m.fads) {                                   // :389
-      slot_begin_eval(s, RC, lane);
       if (g.random() < f.CF) {                                     // :390
         const int rr_ = (int)g.randint(0, G.R - 1);                // :391
         const int rc_ = (int)g.randint(0, G.C - 1);
         const int node = rr_ * G.C + rc_;
         bool pruned = false;                                       // exact pruning: see mpa_fads_item
         if (f.m.dt && G.occ[node] != 1) {
-          pruned = (f.m.ds[node] + f.m.dt[node]) * (1.0 - 1e-9) >= f.pop_stats[(size_t)slot * 5 + 4];
-          if (pruned) ovf += 1ull << 32;
+          pruned = (f.m.ds[node] + f.m.dt[node]) * (1.0 - 1e-9) >= f.pop_stats[(size_t)f.slot[a] * 5 + 4];
+          if (pruned) pruned_n = 1;
         }
-        if (G.occ[node] != 1 && !pruned) { search = true; n = 1; astart = f.m.start; g0 = node; }   // :393-394
-      } else if (f.init_len > 0) {                                 // :405 re-init path (memoised)
-        if (f.init_len > f.path_cap) rc = 3;
-        else { copy_path(buf, f.init_cells, f.init_len, lane); n = f.init_len; have = true; have_stats = true; }
-      }
+        if (G.occ[node] != 1 && !pruned) { j.kind = 2; j.n0 = 0; j.astart = f.m.start; j.g0 = node; }   // :393-394
+      } else if (f.init_len > 0) j.aux = f.init_len > f.path_cap ? 3 : 1;   // :405 re-init path (memoised)
     }
   }
-  // ---- the searches (the one astar<1> call site of the kernel) ----
-  if (search) {
+  if (lane == 0) {
+    jobs[item] = j;
+    MpaRes r; r.n = 0; r.rc = 1; res[item] = r;
+    if (pruned_n) atomicAdd(&p.c.cnt->pruned, pruned_n);
+  }
+}
+
+struct MpaSearchArgs { Common c; const MpaJob* jobs; MpaRes* res; int n_items, path_cap; int* ph_cells; int* fd_cells; int n; };
+
+__global__ __launch_bounds__(64) void k_mpa_search(MpaSearchArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = lane_id();
+  const Grid& G = p.c.G;
+  const int RC = G.R * G.C;
+  Open O = make_open(smem, p.c.S, p.c.tier2);
+  Slot s = slot_load(p.c, RC);
+  AStat tot = {0, 0, 0, 0, 0, 0};
+  unsigned long long ovf = 0;
+  for (;;) {
+    const int item = next_agent(p.c, p.n_items, lane);
+    if (item < 0) break;
+    const MpaJob j = p.jobs[item];
+    if (first_i(j.kind) == 0) continue;
+#ifdef PF_TRACE
+    const unsigned long long tr0 = wall_clock64(), pp0 = tot.pops;
+#endif
+    const bool isph = first_i(j.kind) == 1;
+    int* buf = isph ? p.ph_cells + (size_t)item * p.path_cap : p.fd_cells + (size_t)(item - p.n) * p.path_cap;
+    slot_begin_eval(s, RC, lane);
+    int n = 1, astart = first_i(j.astart), rc = 0;
+    const int g0 = first_i(j.g0), g1 = first_i(j.g1);
+    if (isph) {
+      n = first_i(j.n0);
+      mark_avoid(s, j.src, n - 1, lane);                          // set(prefix[:-1]) :290
+      copy_path(buf, j.src, n, lane);                             // :296
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    }
     const int cap = p.path_cap;
 #pragma unroll 1                                                  // one inlined copy of the pop loop, not two
     for (int seg = 0; seg < 2; ++seg) {
@@ -1366,7 +1388,7 @@ __device__ __forceinline__ void mpa_sweep_item(const MpaSweepArgs& q, int item, 
       int mlen = 0;
 #ifdef PF_TRACE
       const unsigned long long pq0 = tot.pops;
-      if (!isph && seg == 0 && lane == 0 && a < 8192) { g_trace3[4 * (p.n + a)] = 1; g_trace3[4 * (p.n + a) + 1] = g0; }
+      if (!isph && seg == 0 && lane == 0 && item < 16384) { g_trace3[4 * item] = 1; g_trace3[4 * item + 1] = g0; }
 #endif
       const int r2 = astar<1>(G, s, O, astart, seg == 0 ? g0 : g1, buf + n - 1, cap - (n - 1), mlen, tot, lane);
 #ifdef PF_TRACE
@@ -1379,64 +1401,73 @@ __device__ __forceinline__ void mpa_sweep_item(const MpaSweepArgs& q, int item, 
           n += mlen - 1;
         }
       } else {
-        if (!(r2 == 0 && mlen > 0)) break;                        // :395 / :397
+        if (!(r2 == 0 && mlen > 0)) { rc = 1; break; }            // :395 / :397
         if (seg == 0) { mark_avoid(s, buf, mlen - 1, lane); astart = g0; n = mlen; }   // set(p1[:-1]) :396
-        else { n += mlen - 1; have = true; }                      // :398-400 (last is the target by construction)
+        else n += mlen - 1;                                       // :398-400 (last is the target by construction)
       }
     }
-  }
-  // ---- score and hand over ----
-  if (isph) {
-    bool rebuilt = false;
-    if (search && rc != 3) {
-      // :310-315 dedup is a no-op (see k_decode_batch); :316-317 endpoint check
-      const int first = out[0], last = out[n - 1];
-      if (first != p.m.start || last != p.m.target) rc = 4; else { rc = 0; rebuilt = true; }
-    }
-    double sc[5];
-    if (rebuilt) score_path(G, p.sp, out, n, lane, sc);
-    else if (rc != 3) {
-      n = modL;
-      copy_path(out, mod, modL, lane);
-      for (int i = 0; i < 5; ++i) sc[i] = mod_stats[i];
-      if (modL == 0) { sc[0] = PF_INF; sc[1] = 0; sc[2] = 0; sc[3] = 0; sc[4] = PF_INF; }
-    } else n = 0;
-    if (lane == 0) { p.out_len[a] = n; p.status[a] = rc; }
-    if (rc != 3 && lane < 5) p.out_stats[(size_t)a * 5 + lane] = sc[lane];
-  } else {
-    if (!have) n = 0;
-    if (have) {
-      double sc[5];
-      if (have_stats) { for (int i = 0; i < 5; ++i) sc[i] = f.init_stats[i]; }
-      else score_path(G, f.sp, buf, n, lane, sc);
-      if (lane < 5) f.cand_stats[(size_t)a * 5 + lane] = sc[lane];
-    }
-    if (lane == 0) f.cand_len[a] = have ? n : 0;
-  }
-  cells += n; ovf += rc == 3;
-}
-__global__ __launch_bounds__(64) void k_mpa_sweep(MpaSweepArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = lane_id();
-  Open O = make_open(smem, p.ph.c.S, p.ph.c.tier2);
-  Slot s = slot_load(p.ph.c, p.ph.c.G.R * p.ph.c.G.C);
-  AStat tot = {0, 0, 0, 0, 0, 0};
-  unsigned long long cells = 0, ovf = 0;
-  for (;;) {
-    const int item = next_agent(p.ph.c, 2 * p.ph.n, lane);
-    if (item < 0) break;
-#ifdef PF_TRACE
-    const unsigned long long tr0 = wall_clock64(), pp0 = tot.pops;
-#endif
-    mpa_sweep_item(p, item, s, O, tot, cells, ovf, lane);
+    if (lane == 0) { MpaRes r; r.n = n; r.rc = rc; p.res[item] = r; }
+    ovf += rc == 3;
 #ifdef PF_TRACE
     if (lane == 0 && item < 16384) {
       g_trace[4 * item] = tr0; g_trace[4 * item + 1] = wall_clock64(); g_trace[4 * item + 2] = tot.pops - pp0; g_trace[4 * item + 3] = blockIdx.x;
     }
 #endif
   }
-  slot_store(p.ph.c, s, lane);
-  flush_counters(p.ph.c.cnt, tot, cells, ovf, lane);
+  slot_store(p.c, s, lane);
+  flush_counters(p.c.cnt, tot, 0, ovf, lane);
+}
+
+__global__ __launch_bounds__(64) void k_mpa_finish(MpaSweepArgs q, const MpaJob* jobs, const MpaRes* res) {
+  const MpaPhaseArgs& p = q.ph;
+  const MpaFadsArgs& f = q.fd;
+  const Grid& G = p.c.G;
+  const int lane = lane_id();
+  const int item = blockIdx.x;
+  if (item >= 2 * p.n) return;
+  const bool isph = item < p.n;
+  const int a = isph ? item : item - p.n;
+  const MpaJob j = jobs[item];
+  const MpaRes r = res[item];
+  int n = 0;
+  if (isph) {
+    const MpaPlan pl = mpa_plan(p, a);
+    int* out = p.out_cells + (size_t)a * p.path_cap;
+    int rc = j.kind == 1 ? r.rc : j.aux;
+    bool rebuilt = false;
+    if (j.kind == 1 && rc != 3) {
+      // :310-315 dedup is a no-op (see k_decode_batch); :316-317 endpoint check
+      n = r.n;
+      const int first = out[0], last = out[n - 1];
+      if (first != p.m.start || last != p.m.target) rc = 4; else { rc = 0; rebuilt = true; }
+    }
+    double sc[5];
+    if (rebuilt) score_path(G, p.sp, out, n, lane, sc);
+    else if (rc != 3) {
+      // no move: phase 1 keeps the prey (:342,:347); phases 2/3 re-score path_to_modify (:356,:363,:369,:376),
+      // whose stats are the stored ones (same function, same path)
+      n = pl.modL;
+      copy_path(out, pl.mod, pl.modL, lane);
+      for (int i = 0; i < 5; ++i) sc[i] = pl.mod_stats[i];
+      if (pl.modL == 0) { sc[0] = PF_INF; sc[1] = 0; sc[2] = 0; sc[3] = 0; sc[4] = PF_INF; }
+    } else n = 0;
+    if (lane == 0) { p.out_len[a] = n; p.status[a] = rc; }
+    if (rc != 3 && lane < 5) p.out_stats[(size_t)a * 5 + lane] = sc[lane];
+    if (rc == 3 && j.kind != 1 && lane == 0) atomicAdd(&p.c.cnt->overflow, 1ull);
+  } else {
+    int* buf = f.cand_cells + (size_t)a * f.path_cap;
+    bool have = false;
+    double sc[5];
+    if (j.kind == 2 && r.rc == 0) { n = r.n; have = true; score_path(G, f.sp, buf, n, lane, sc); }
+    else if (j.kind == 0 && j.aux == 1) {                          // :405 re-init path (memoised, see MpaFadsArgs)
+      n = f.init_len; have = true;
+      copy_path(buf, f.init_cells, n, lane);
+      for (int i = 0; i < 5; ++i) sc[i] = f.init_stats[i];
+    } else if (j.kind == 0 && j.aux == 3 && lane == 0) atomicAdd(&p.c.cnt->overflow, 1ull);
+    if (have && lane < 5) f.cand_stats[(size_t)a * 5 + lane] = sc[lane];
+    if (lane == 0) f.cand_len[a] = have ? n : 0;
+  }
+  if (lane == 0 && n) atomicAdd(&p.c.cnt->path_cells, (unsigned long long)n);
 }
 // memory step (MPA.py:381-384) then FADs acceptance (:402 / :408) for predator a
 __global__ __launch_bounds__(64) void k_mpa_apply(int n, int path_cap, const int* slots, const int* c1_cells, const int* c1_len,
@@ -1693,6 +1724,7 @@ struct pf_handle {
   double* d_ds = nullptr; double* d_dt = nullptr;   // static shortest distances from the start / to the target (pruning bounds)
   float* d_est = nullptr; float* d_est2 = nullptr; int* d_iota = nullptr; int* d_queue = nullptr; int est_cap = 0;
   void* d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
+  void* d_jobs = nullptr; void* d_jres = nullptr; int job_cap = 0;   // the sweep's search jobs / results (k_mpa_plan -> k_mpa_search -> k_mpa_finish)
   int2* d_prop = nullptr; int* d_doubt = nullptr; int prop_cap = 0;   // MPA proposals {idx, target cell}; doubt list [0] = count, [1..] = predators
   long long doubts_resolved = 0;
   void* d_scan = nullptr; void* d_scan3 = nullptr;   // results of the small device scans
@@ -1844,7 +1876,7 @@ void pf_destroy(pf_handle* h) {
   if (h->comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(h->stream); g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
   void* ptrs[] = {h->d_occ, h->d_mm_r1, h->d_mm_r0, h->d_mm_r1_nd, h->d_mm_r0_nd, h->d_d2near, h->d_rec, h->d_slot_state,
                   h->d_work, h->d_cnt, h->d_pen, h->d_tier2, h->d_tau, h->d_taua, h->d_eta, h->d_dep, h->d_tep, h->d_visit, h->d_visit_epoch,
-                  h->d_bits, h->d_tmp, h->d_elite_stats, h->d_init_cells, h->d_init_stats, h->d_est, h->d_est2, h->d_iota, h->d_queue, h->d_sort_tmp, h->d_prop, h->d_doubt, h->d_scan, h->d_scan3, h->d_okey, h->d_okey2, h->d_oval2, h->d_elite_cells, h->d_elite_len, h->d_ga_pool, h->d_st_lab, h->d_st_touched, h->d_st_par, h->d_st_epoch,
+                  h->d_bits, h->d_tmp, h->d_elite_stats, h->d_init_cells, h->d_init_stats, h->d_est, h->d_est2, h->d_iota, h->d_queue, h->d_sort_tmp, h->d_jobs, h->d_jres, h->d_prop, h->d_doubt, h->d_scan, h->d_scan3, h->d_okey, h->d_okey2, h->d_oval2, h->d_elite_cells, h->d_elite_len, h->d_ga_pool, h->d_st_lab, h->d_st_touched, h->d_st_par, h->d_st_epoch,
                   h->d_comp[0], h->d_comp[1], h->d_comp[2], h->d_comp[3], h->d_ds, h->d_dt};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -2848,16 +2880,29 @@ int pf_mpa_iter_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uint
   a.ph.c.queue = h->d_queue; a.fd.c.queue = h->d_queue;
   const int S = kLdsS;
   a.ph.c.S = S; a.fd.c.S = S; a.ph.c.retry = 0; a.fd.c.retry = 0;
+  if (2 * n > h->job_cap) {
+    if (h->d_jobs) CK(hipFree(h->d_jobs));
+    if (h->d_jres) CK(hipFree(h->d_jres));
+    CK(hipMalloc(&h->d_jobs, sizeof(MpaJob) * 2 * (size_t)n)); CK(hipMalloc(&h->d_jres, sizeof(MpaRes) * 2 * (size_t)n));
+    h->job_cap = 2 * n;
+  }
+  MpaJob* jobs = (MpaJob*)h->d_jobs; MpaRes* jres = (MpaRes*)h->d_jres;
+  MpaSearchArgs sa;
+  sa.c = a.ph.c; sa.jobs = jobs; sa.res = jres; sa.n_items = 2 * n; sa.path_cap = path_cap; sa.ph_cells = d_c1_cells; sa.fd_cells = d_c2_cells; sa.n = n;
   const size_t lds = open_bytes(S);
-  CK(hipFuncSetAttribute((const void*)k_mpa_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  CK(hipFuncSetAttribute((const void*)k_mpa_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = (int)((160 * 1024) / lds); if (per_cu > kWavesPerCU) per_cu = kWavesPerCU; if (per_cu < 1) per_cu = 1;
   int grid = (h->nslots / kSlotsPerCU) * per_cu; if (grid > 2 * n) grid = 2 * n; if (grid > h->nslots) grid = h->nslots;
   CK(hipMemsetAsync(h->d_work, 0, sizeof(int), h->stream));
   CK(hipMemsetAsync(h->d_cnt, 0, sizeof(DevCounters), h->stream));
+  hipLaunchKernelGGL(k_mpa_plan, dim3(2 * n), dim3(64), 0, h->stream, a, jobs, jres);
+  CK(hipGetLastError());
   CK(hipEventRecord(h->ev0, h->stream));
-  hipLaunchKernelGGL(k_mpa_sweep, dim3(grid), dim3(64), lds, h->stream, a);
+  hipLaunchKernelGGL(k_mpa_search, dim3(grid), dim3(64), lds, h->stream, sa);
   CK(hipGetLastError());
   CK(hipEventRecord(h->ev1, h->stream));
+  hipLaunchKernelGGL(k_mpa_finish, dim3(2 * n), dim3(64), 0, h->stream, a, (const MpaJob*)jobs, (const MpaRes*)jres);
+  CK(hipGetLastError());
   hipLaunchKernelGGL(k_mpa_apply, dim3(n), dim3(64), 0, h->stream, n, path_cap, d_slot, d_c1_cells, d_c1_len, d_c1_stats,
                      d_c2_cells, d_c2_len, d_c2_stats, d_pop_cells, d_pop_len, d_pop_stats);
   CK(hipGetLastError());
@@ -3084,8 +3129,7 @@ int pf_comm_recv(pf_handle* h, void* d_buf, int64_t bytes, int32_t peer) {
 int pf_comm_sendrecv(pf_handle* h, const void* d_send, int64_t send_bytes, int32_t to, void* d_recv, int64_t recv_bytes, int32_t from) {
   NEED_COMM(h);
   const bool snd = send_bytes > 0 && to >= 0, rcv = recv_bytes > 0 && from >= 0;
-  if (send_bytes < 0 || recv_bytes < 0 || (snd && (!d_send || to >= h->comm_world || to == h->comm_rank)) ||
-      (rcv && (!d_recv || from >= h->comm_world || from == h->comm_rank)))
+  if (send_bytes < 0 || recv_bytes < 0 || (snd && (!d_send || to >= h->comm_world)) || (rcv && (!d_recv || from >= h->comm_world)))   // (a ring step onto itself is legal inside a group)
     return failmsg(h, "pf_comm_sendrecv: bad arguments");
   NK(g_rccl.GroupStart());
   // an error between GroupStart and GroupEnd must still close the group: an open group would silently swallow every later

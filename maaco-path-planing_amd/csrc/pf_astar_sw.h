@@ -450,6 +450,161 @@ PF_DEV int drop_superseded(const Rec* rec, int C, double& wf, double wg, int wc)
   return __builtin_popcountll(__ballot(live));
 }
 
+// ---- early refill: fewer than `below` entries left in the window.  With the front bucket and the spill list empty, every pool
+// entry lies in a regular bucket at or above the limit, so the next whole buckets, sorted, simply continue the
+// window (its remaining keys are below the limit): the trips keep seven heads instead of running the window dry.
+template <int SEM>
+PF_DEV void sw_early_refill(const SwPool& P, SwWin& W, const Open& O, const Rec* rec, int C, int lane, int below) {
+  constexpr int NBK = PF_SW_NBK, CAP = PF_SW_CAP;
+  if (W.wn - W.wp > 0 && W.wn - W.wp < below && W.n_pool > 0 && W.n_spill == 0) {
+    const int rem = W.wn - W.wp;
+    const int c_ = P.cnt[(W.bcur + lane) & (NBK - 1)];
+    const unsigned long long nz = __ballot(c_ > 0);
+    if (nz && P.cnt[NBK] == 0) {
+      const int b0 = W.bcur + __builtin_ctzll(nz);
+      const int cb = P.cnt[(b0 + lane) & (NBK - 1)];
+      const int incl = wave_incl_sum(cb);
+      const int k = __builtin_popcountll(__ballot(incl <= 64 - rem));
+      if (k > 0) {
+        const int total = bcast_i(incl, k - 1);
+        int* mark = (int*)O.sx;
+        mark[lane] = 0;
+        PF_LDS_ORDER();
+        if (lane < k && cb > 0) mark[incl - cb] = lane;
+        PF_LDS_ORDER();
+        const int kk = wave_incl_max(mark[lane]);
+        const int j = lane - bperm_i(kk, incl - cb);
+        double nf = PF_INF, ng = 0.0; int nc = 0;
+        if (lane < total) {
+          const int bi = (b0 + kk) & (NBK - 1);
+          ent_get(P, P.be + bi * CAP + j, nf, ng, nc);
+        }
+        if (lane < k) P.cnt[(b0 + lane) & (NBK - 1)] = 0;
+        int live = total;
+        if (SEM == 0) live = drop_superseded(rec, C, nf, ng, nc);
+#if !PF_RUN_SORT
+        int n2 = 1; while (n2 < total) n2 <<= 1;
+#endif
+#if PF_RUN_SORT
+        {
+          const int msz = bperm_i(kk, cb);                      // (every lane takes part: a masked-off source lane would read as 0)
+          sort_runs((char*)O.lf, nf, ng, nc, lane < total ? lane - j : 0, lane < total ? msz : 0, lane);
+        }
+#else
+        sort_lanes(nf, ng, nc, lane, n2);
+#endif
+        // lanes 0..rem-1 <- the old window, then the new entries
+        const int so = W.wp + lane < 64 ? W.wp + lane : 63, sn = lane >= rem ? lane - rem : 0;
+        const double of_ = bperm_d(so, W.wf), og_ = bperm_d(so, W.wg); const int oc_ = bperm_i(so, W.wc);
+        const double mf_ = bperm_d(sn, nf), mg_ = bperm_d(sn, ng); const int mc_ = bperm_i(sn, nc);
+        W.wf = lane < rem ? of_ : mf_; W.wg = lane < rem ? og_ : mg_; W.wc = lane < rem ? oc_ : mc_;
+        W.wp = 0; W.wn = rem + live; W.n_pool -= total;
+        W.bcur = b0 + k;
+        W.lf = (double)W.bcur * (1.0 / PF_SW_Q); W.lg = -PF_INF; W.lc = 0;
+        PF_LDS_ORDER();
+      }
+    }
+  }
+}
+
+// ---- refill of an EMPTY window: the front bucket if it holds anything, else the next non-empty buckets (<= 64 entries); sorted.
+// Returns 0 (the window holds entries again), 1 (nothing is left anywhere: the search has failed), 3 (scratch overflow) or
+// 4 (everything taken was superseded / only the spill list was re-offered: call again).
+template <int SEM, bool PLAT>
+PF_DEV int sw_refill(const SwPool& P, SwWin& W, const Open& O, const Rec* rec, int C, int lane) {
+  constexpr int NBK = PF_SW_NBK, CAP = PF_SW_CAP;
+  {
+    if (W.n_pool == 0) return 1;
+    const int cF = P.cnt[NBK];
+    W.wf = PF_INF; W.wg = 0.0; W.wc = 0;
+    if (cF > 0) {
+      if (cF <= 64) {
+        if (lane < cF) ent_get(P, P.be + NBK * CAP + lane, W.wf, W.wg, W.wc);
+        if (lane == 0) P.cnt[NBK] = 0;
+        int live = cF;
+        if (SEM == 0) live = drop_superseded(rec, C, W.wf, W.wg, W.wc);
+#if PF_RUN_SORT
+        sort_runs((char*)O.lf, W.wf, W.wg, W.wc, 0, lane < cF ? cF : 0, lane);      // one run: the front bucket
+#else
+        int n2 = 1; while (n2 < cF) n2 <<= 1;
+        sort_lanes(W.wf, W.wg, W.wc, lane, n2);
+#endif
+        W.wp = 0; W.wn = live; W.n_pool -= cF;
+        W.lf = (double)W.bcur * (1.0 / PF_SW_Q); W.lg = -PF_INF; W.lc = 0;
+      } else {
+        int nt = PLAT && cF >= PF_SELECT_MIN ? take_smallest_select(P, (char*)O.lf, NBK, cF, W.wf, W.wg, W.wc, lane) : 0;
+        if (nt == 0) { take_smallest64(P, NBK, cF, W.wf, W.wg, W.wc, lane); nt = 64; }
+        W.wp = 0; W.wn = nt; W.n_pool -= nt;
+        W.lf = bcast_d(W.wf, nt - 1); W.lg = bcast_d(W.wg, nt - 1); W.lc = bcast_i(W.wc, nt - 1);   // the rest of the front bucket is above this key
+      }
+    } else {
+      int b0 = -1;
+      for (int base = 0; base < NBK; base += 64) {
+        const int c_ = P.cnt[(W.bcur + base + lane) & (NBK - 1)];
+        const unsigned long long nz = __ballot(c_ > 0);
+        if (nz) { b0 = W.bcur + base + __builtin_ctzll(nz); break; }
+      }
+      if (b0 < 0) {                                  // only spilled entries are left (their buckets emptied since)
+        if (W.n_spill == 0) return 3;   // (n_pool > 0 with nothing anywhere: never loop silently)
+        // window, front bucket and every regular bucket are empty: the circular range may start at the smallest
+        // spilled key, which brings the entries that were beyond it back in range
+        unsigned minb = 0xFFFFFFFFu;
+        for (int base = 0; base < W.n_spill; base += 64)
+          if (base + lane < W.n_spill) { double f_, g_; int c_; ent_get(P, P.se + base + lane, f_, g_, c_); const unsigned b_ = (unsigned)(int)(f_ * PF_SW_Q); minb = b_ < minb ? b_ : minb; }
+        minb = wave_min_u32(minb);
+        if ((int)minb > W.bcur) { W.bcur = (int)minb; W.lf = (double)W.bcur * (1.0 / PF_SW_Q); W.lg = -PF_INF; W.lc = 0; }
+        if (!respill<PLAT>(P, W, lane)) return 3;
+        return 4;
+      }
+      const int cb = P.cnt[(b0 + lane) & (NBK - 1)]; // lane k: size of the k-th bucket from b0 (wraps onto empty ones)
+      const int c0 = bcast_i(cb, 0);
+      if (c0 <= 64) {
+        // take buckets b0 .. b0+k-1, as many as fit the window: lane j loads the j-th entry of their concatenation
+        // (prefix sums of the sizes; each bucket marks where it starts, a running maximum spreads the mark)
+        const int incl = wave_incl_sum(cb);
+        const int k = __builtin_popcountll(__ballot(incl <= 64));    // (sizes are >= 0: the lanes that fit are a prefix)
+        const int total = bcast_i(incl, k - 1);
+        int* mark = (int*)O.sx;
+        mark[lane] = 0;
+        PF_LDS_ORDER();
+        if (lane < k && cb > 0) mark[incl - cb] = lane;
+        PF_LDS_ORDER();
+        const int kk = wave_incl_max(mark[lane]);                      // my entry's bucket, counted from b0
+        const int j = lane - bperm_i(kk, incl - cb);                    // ... and its index in that bucket
+        if (lane < total) {
+          const int bi = (b0 + kk) & (NBK - 1);
+          ent_get(P, P.be + bi * CAP + j, W.wf, W.wg, W.wc);
+        }
+        if (lane < k) P.cnt[(b0 + lane) & (NBK - 1)] = 0;
+        int live = total;
+        if (SEM == 0) live = drop_superseded(rec, C, W.wf, W.wg, W.wc);
+#if PF_RUN_SORT
+        {
+          const int msz = bperm_i(kk, cb);                      // (every lane takes part: a masked-off source lane would read as 0)
+          sort_runs((char*)O.lf, W.wf, W.wg, W.wc, lane < total ? lane - j : 0, lane < total ? msz : 0, lane);
+        }
+#else
+        int n2 = 1; while (n2 < total) n2 <<= 1;
+        sort_lanes(W.wf, W.wg, W.wc, lane, n2);
+#endif
+        W.wp = 0; W.wn = live; W.n_pool -= total;
+        W.bcur = b0 + k;
+        W.lf = (double)W.bcur * (1.0 / PF_SW_Q); W.lg = -PF_INF; W.lc = 0;
+      } else {
+        int nt = PLAT && c0 >= PF_SELECT_MIN ? take_smallest_select(P, (char*)O.lf, b0 & (NBK - 1), c0, W.wf, W.wg, W.wc, lane) : 0;
+        if (nt == 0) { take_smallest64(P, b0 & (NBK - 1), c0, W.wf, W.wg, W.wc, lane); nt = 64; }
+        W.wp = 0; W.wn = nt; W.n_pool -= nt;
+        W.bcur = b0;
+        W.lf = bcast_d(W.wf, nt - 1); W.lg = bcast_d(W.wg, nt - 1); W.lc = bcast_i(W.wc, nt - 1);   // the rest of the bucket is above the window's last key
+      }
+    }
+    PF_LDS_ORDER();
+    if (W.n_spill > 0 && !respill<PLAT>(P, W, lane)) return 3;
+    if (W.wn == 0) return 4;                                    // everything taken was superseded: take the next buckets
+  }
+  return 0;
+}
+
 template <int VARIANT, bool PLAT>
 __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& O, uint32_t tag, uint32_t avm, int start, int target,
                                            int tr, int tc, int max_steps, double h0, int src, AStat& st, int lane) {
@@ -491,172 +646,12 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
 #endif
   for (;;) {
     SW_T(t0)
-    if (PF_EARLY_REFILL && W.wn - W.wp > 0 && W.wn - W.wp < 7 && W.n_pool > 0 && W.n_spill == 0) {
-      // ---- early refill: fewer than seven heads left.  With the front bucket and the spill list empty, every pool
-      // entry lies in a regular bucket at or above the limit, so the next whole buckets, sorted, simply continue the
-      // window (its remaining keys are below the limit): the trips keep seven heads instead of running the window dry.
-      const int rem = W.wn - W.wp;
-      const int c_ = P.cnt[(W.bcur + lane) & (NBK - 1)];
-      const unsigned long long nz = __ballot(c_ > 0);
-      if (nz && P.cnt[NBK] == 0) {
-        const int b0 = W.bcur + __builtin_ctzll(nz);
-        const int cb = P.cnt[(b0 + lane) & (NBK - 1)];
-        const int incl = wave_incl_sum(cb);
-        const int k = __builtin_popcountll(__ballot(incl <= 64 - rem));
-        if (k > 0) {
-          const int total = bcast_i(incl, k - 1);
-          int* mark = (int*)O.sx;
-          mark[lane] = 0;
-          PF_LDS_ORDER();
-          if (lane < k && cb > 0) mark[incl - cb] = lane;
-          PF_LDS_ORDER();
-          const int kk = wave_incl_max(mark[lane]);
-          const int j = lane - bperm_i(kk, incl - cb);
-          double nf = PF_INF, ng = 0.0; int nc = 0;
-          if (lane < total) {
-            const int bi = (b0 + kk) & (NBK - 1);
-            ent_get(P, P.be + bi * CAP + j, nf, ng, nc);
-          }
-          if (lane < k) P.cnt[(b0 + lane) & (NBK - 1)] = 0;
-          int live = total;
-          if (SEM == 0) live = drop_superseded(rec, C, nf, ng, nc);
-#if !PF_RUN_SORT
-          int n2 = 1; while (n2 < total) n2 <<= 1;
-#endif
-#ifdef PF_STAMPS
-          sw_er[0] += 1; sw_er[1] += total; sw_er[2] += ~wave_min_u32(~(lane < k ? (unsigned)cb : 0u)); sw_er[3] += k;
-          const unsigned long long ts0_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
-          { unsigned tmp_ = (unsigned)nc; asm volatile("" : "+v"(tmp_)); }
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          const unsigned long long ts1_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
-          sw_er[4] += ts1_ - ts0_;
-#endif
-#if PF_RUN_SORT
-          {
-            const int msz = bperm_i(kk, cb);                      // (every lane takes part: a masked-off source lane would read as 0)
-            sort_runs((char*)O.lf, nf, ng, nc, lane < total ? lane - j : 0, lane < total ? msz : 0, lane);
-          }
-#else
-          sort_lanes(nf, ng, nc, lane, n2);
-#endif
-#ifdef PF_STAMPS
-          { unsigned tmp_ = (unsigned)nc; asm volatile("" : "+v"(tmp_)); }
-          const unsigned long long ts2_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
-          sw_er[5] += ts2_ - ts1_;
-#endif
-          // lanes 0..rem-1 <- the old window, then the new entries
-          const int so = W.wp + lane < 64 ? W.wp + lane : 63, sn = lane >= rem ? lane - rem : 0;
-          const double of_ = bperm_d(so, W.wf), og_ = bperm_d(so, W.wg); const int oc_ = bperm_i(so, W.wc);
-          const double mf_ = bperm_d(sn, nf), mg_ = bperm_d(sn, ng); const int mc_ = bperm_i(sn, nc);
-          W.wf = lane < rem ? of_ : mf_; W.wg = lane < rem ? og_ : mg_; W.wc = lane < rem ? oc_ : mc_;
-          W.wp = 0; W.wn = rem + live; W.n_pool -= total;
-          W.bcur = b0 + k;
-          W.lf = (double)W.bcur * (1.0 / PF_SW_Q); W.lg = -PF_INF; W.lc = 0;
-          PF_LDS_ORDER();
-        }
-      }
-    }
+    if (PF_EARLY_REFILL) sw_early_refill<SEM>(P, W, O, rec, C, lane, 7);
     if (W.wp == W.wn) {
-      // ---- refill: the front bucket if it holds anything, else the next non-empty buckets (<= 64 entries); sorted ----
-      if (W.n_pool == 0) { status = 1; break; }
-      const int cF = P.cnt[NBK];
-      W.wf = PF_INF; W.wg = 0.0; W.wc = 0;
-      if (cF > 0) {
-        if (cF <= 64) {
-          if (lane < cF) ent_get(P, P.be + NBK * CAP + lane, W.wf, W.wg, W.wc);
-          if (lane == 0) P.cnt[NBK] = 0;
-          int live = cF;
-          if (SEM == 0) live = drop_superseded(rec, C, W.wf, W.wg, W.wc);
-#if PF_RUN_SORT
-          sort_runs((char*)O.lf, W.wf, W.wg, W.wc, 0, lane < cF ? cF : 0, lane);      // one run: the front bucket
-#else
-          int n2 = 1; while (n2 < cF) n2 <<= 1;
-          sort_lanes(W.wf, W.wg, W.wc, lane, n2);
-#endif
-#ifdef PF_STAMPS
-          sw_cnt[0] += 1; sw_cnt[1] += cF;
-#endif
-          W.wp = 0; W.wn = live; W.n_pool -= cF;
-          W.lf = (double)W.bcur * (1.0 / PF_SW_Q); W.lg = -PF_INF; W.lc = 0;
-        } else {
-#ifdef PF_STAMPS
-          sw_cnt[2] += 1; sw_cnt[3] += cF;
-#endif
-          int nt = PLAT && cF >= PF_SELECT_MIN ? take_smallest_select(P, (char*)O.lf, NBK, cF, W.wf, W.wg, W.wc, lane) : 0;
-          if (nt == 0) { take_smallest64(P, NBK, cF, W.wf, W.wg, W.wc, lane); nt = 64; }
-          W.wp = 0; W.wn = nt; W.n_pool -= nt;
-          W.lf = bcast_d(W.wf, nt - 1); W.lg = bcast_d(W.wg, nt - 1); W.lc = bcast_i(W.wc, nt - 1);   // the rest of the front bucket is above this key
-        }
-      } else {
-        int b0 = -1;
-        for (int base = 0; base < NBK; base += 64) {
-          const int c_ = P.cnt[(W.bcur + base + lane) & (NBK - 1)];
-          const unsigned long long nz = __ballot(c_ > 0);
-          if (nz) { b0 = W.bcur + base + __builtin_ctzll(nz); break; }
-        }
-        if (b0 < 0) {                                  // only spilled entries are left (their buckets emptied since)
-          if (W.n_spill == 0) { status = 3; break; }   // (n_pool > 0 with nothing anywhere: never loop silently)
-          // window, front bucket and every regular bucket are empty: the circular range may start at the smallest
-          // spilled key, which brings the entries that were beyond it back in range
-          unsigned minb = 0xFFFFFFFFu;
-          for (int base = 0; base < W.n_spill; base += 64)
-            if (base + lane < W.n_spill) { double f_, g_; int c_; ent_get(P, P.se + base + lane, f_, g_, c_); const unsigned b_ = (unsigned)(int)(f_ * PF_SW_Q); minb = b_ < minb ? b_ : minb; }
-          minb = wave_min_u32(minb);
-          if ((int)minb > W.bcur) { W.bcur = (int)minb; W.lf = (double)W.bcur * (1.0 / PF_SW_Q); W.lg = -PF_INF; W.lc = 0; }
-          if (!respill<PLAT>(P, W, lane)) { status = 3; break; }
-          continue;
-        }
-        const int cb = P.cnt[(b0 + lane) & (NBK - 1)]; // lane k: size of the k-th bucket from b0 (wraps onto empty ones)
-        const int c0 = bcast_i(cb, 0);
-        if (c0 <= 64) {
-          // take buckets b0 .. b0+k-1, as many as fit the window: lane j loads the j-th entry of their concatenation
-          // (prefix sums of the sizes; each bucket marks where it starts, a running maximum spreads the mark)
-          const int incl = wave_incl_sum(cb);
-          const int k = __builtin_popcountll(__ballot(incl <= 64));    // (sizes are >= 0: the lanes that fit are a prefix)
-          const int total = bcast_i(incl, k - 1);
-          int* mark = (int*)O.sx;
-          mark[lane] = 0;
-          PF_LDS_ORDER();
-          if (lane < k && cb > 0) mark[incl - cb] = lane;
-          PF_LDS_ORDER();
-          const int kk = wave_incl_max(mark[lane]);                      // my entry's bucket, counted from b0
-          const int j = lane - bperm_i(kk, incl - cb);                    // ... and its index in that bucket
-          if (lane < total) {
-            const int bi = (b0 + kk) & (NBK - 1);
-            ent_get(P, P.be + bi * CAP + j, W.wf, W.wg, W.wc);
-          }
-          if (lane < k) P.cnt[(b0 + lane) & (NBK - 1)] = 0;
-          int live = total;
-          if (SEM == 0) live = drop_superseded(rec, C, W.wf, W.wg, W.wc);
-#if PF_RUN_SORT
-          {
-            const int msz = bperm_i(kk, cb);                      // (every lane takes part: a masked-off source lane would read as 0)
-            sort_runs((char*)O.lf, W.wf, W.wg, W.wc, lane < total ? lane - j : 0, lane < total ? msz : 0, lane);
-          }
-#else
-          int n2 = 1; while (n2 < total) n2 <<= 1;
-          sort_lanes(W.wf, W.wg, W.wc, lane, n2);
-#endif
-#ifdef PF_STAMPS
-          sw_cnt[6] += 1; sw_cnt[7] += total;
-#endif
-          W.wp = 0; W.wn = live; W.n_pool -= total;
-          W.bcur = b0 + k;
-          W.lf = (double)W.bcur * (1.0 / PF_SW_Q); W.lg = -PF_INF; W.lc = 0;
-        } else {
-#ifdef PF_STAMPS
-          sw_cnt[4] += 1; sw_cnt[5] += c0;
-#endif
-          int nt = PLAT && c0 >= PF_SELECT_MIN ? take_smallest_select(P, (char*)O.lf, b0 & (NBK - 1), c0, W.wf, W.wg, W.wc, lane) : 0;
-          if (nt == 0) { take_smallest64(P, b0 & (NBK - 1), c0, W.wf, W.wg, W.wc, lane); nt = 64; }
-          W.wp = 0; W.wn = nt; W.n_pool -= nt;
-          W.bcur = b0;
-          W.lf = bcast_d(W.wf, nt - 1); W.lg = bcast_d(W.wg, nt - 1); W.lc = bcast_i(W.wc, nt - 1);   // the rest of the bucket is above the window's last key
-        }
-      }
-      PF_LDS_ORDER();
-      if (W.n_spill > 0 && !respill<PLAT>(P, W, lane)) { status = 3; break; }
-      if (W.wn == 0) continue;                                    // everything taken was superseded: take the next buckets
+      const int rr_ = sw_refill<SEM, PLAT>(P, W, O, rec, C, lane);
+      if (rr_ == 1) { status = 1; break; }
+      if (rr_ == 3) { status = 3; break; }
+      if (rr_ == 4) continue;
     }
     SW_T(t1)
     // ---- pop: up to seven heads of the window at once, nine lanes each ----

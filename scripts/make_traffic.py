@@ -11,7 +11,7 @@ import sys, os, glob, csv, json
 d = sys.argv[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RND = "r02"
-KERN = {"mpa512": "k_mpa_sweep", "maaco512": "k_maaco_walk8", "maaco1024": "k_maaco_walk8", "maaco128": "k_maaco_walk(",
+KERN = {"mpa512": "k_mpa_search", "maaco512": "k_maaco_walk8", "maaco1024": "k_maaco_walk8", "maaco128": "k_maaco_walk(",
         "ga512": "k_decode_batch", "pso512": "k_decode_batch", "astar1024": "k_astar_batch"}
 try:
     out = json.load(open(os.path.join(ROOT, "profiles", f"{RND}_traffic.json")))

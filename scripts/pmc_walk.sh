@@ -10,7 +10,7 @@ import csv, glob, sys, collections
 acc = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if any(k in r["Kernel_Name"] for k in ("k_maaco_walk", "k_mpa_sweep", "k_decode_batch", "k_astar_batch")):
+        if any(k in r["Kernel_Name"] for k in ("k_maaco_walk", "k_mpa_search", "k_decode_batch", "k_astar_batch")):
             a = acc[(r["Kernel_Name"][:40], r["Counter_Name"])]; a[0] += float(r["Counter_Value"]); a[1] += 1
 for (k, c), (v, n) in sorted(acc.items()):
     print(f"{k:42s} {c:28s} per-launch {v / n:16.1f}  (n={n})")

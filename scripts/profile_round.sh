@@ -27,7 +27,7 @@ for W in $WL; do
     python3 - "$f" "$OUT/${W}_dominant_trace.csv" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-keep = [r for r in rows if any(k in r["Kernel_Name"] for k in ("k_mpa_sweep", "k_maaco_walk", "k_decode_batch", "k_astar_batch<"))]
+keep = [r for r in rows if any(k in r["Kernel_Name"] for k in ("k_mpa_search", "k_maaco_walk", "k_decode_batch", "k_astar_batch<"))]
 w = csv.writer(open(sys.argv[2], "w"))
 w.writerow(["Kernel_Name", "Start_Timestamp", "End_Timestamp"])
 for r in keep:
