@@ -190,11 +190,22 @@ struct AstarArgs {
   int* cells; int* len; int* status; long long* counters;
 };
 
-template <int VARIANT, bool PLAT>
-__global__ __launch_bounds__(64) void k_astar_batch(AstarArgs p) {
+template <int VARIANT, bool PLAT, bool PR = false>
+__global__ __launch_bounds__(PR ? 128 : 64) __attribute__((amdgpu_waves_per_eu(PR ? 3 : 1, 8))) void k_astar_batch(AstarArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = lane_id();
   const int RC = p.c.G.R * p.c.G.C;
+  if (PR) {                                                       // two wavefronts per search (pf_astar_pr.h): wave 1 owns the bucket pool
+    const int wave = (int)(threadIdx.x >> 6);
+    if (wave == 0) pr_init_ctl(smem, lane);
+    __syncthreads();
+    if (wave == 1) {
+      pool_wave<VARIANT>(smem, p.c.tier2 + (size_t)blockIdx.x * PF_POOL_STRIDE, p.c.rec + (size_t)blockIdx.x * RC, p.c.G.C, lane);
+      return;
+    }
+  }
+  PrLink link = pr_link(smem);
+  PrLink* const L = &link;
   Open O = make_open(smem, p.c.S, p.c.tier2);
   Slot s = slot_load(p.c, RC);
   AStat tot = {0, 0, 0, 0, 0, 0};
@@ -217,8 +228,8 @@ __global__ __launch_bounds__(64) void k_astar_batch(AstarArgs p) {
     const int sa = p.start[a], ta = p.target[a];
     const long long ab = p.avoid_off ? p.avoid_off[a] : 0, ae = p.avoid_off ? p.avoid_off[a + 1] : 0;
     const int rc = ((unsigned)sa >= (unsigned)RC || (unsigned)ta >= (unsigned)RC) ? 1 :
-                   astar<VARIANT, PLAT>(p.c.G, s, O, sa, ta, p.cells + (size_t)a * p.path_cap, p.path_cap, n, st, lane,
-                                  p.avoid_off ? p.avoid_cells + ab : nullptr, (int)(ae - ab));
+                   astar<VARIANT, PLAT, PR>(p.c.G, s, O, sa, ta, p.cells + (size_t)a * p.path_cap, p.path_cap, n, st, lane,
+                                  p.avoid_off ? p.avoid_cells + ab : nullptr, (int)(ae - ab), L);
     if (lane == 0) {
       p.len[a] = rc == 0 ? n : 0;
       p.status[a] = rc;
@@ -231,6 +242,7 @@ __global__ __launch_bounds__(64) void k_astar_batch(AstarArgs p) {
     tot.settled += st.settled; tot.sequential += st.sequential;
     cells += rc == 0 ? n : 0; ovf += rc == 3;
   }
+  if (PR) pr_exit(smem, lane);
   slot_store(p.c, s, lane);
   flush_counters(p.c.cnt, tot, cells, ovf, lane);
 }
@@ -1353,11 +1365,24 @@ __global__ __launch_bounds__(64) void k_mpa_plan(MpaSweepArgs q, MpaJob* jobs, M
 
 struct MpaSearchArgs { Common c; const MpaJob* jobs; MpaRes* res; int n_items, path_cap; int* ph_cells; int* fd_cells; int n; };
 
-__global__ __launch_bounds__(64) void k_mpa_search(MpaSearchArgs p) {
+// PR = two wavefronts per search (pf_astar_pr.h): wave 0 pops, wave 1 owns the bucket pool.  128-thread workgroups, one per slot.
+template <bool PR>
+__global__ __launch_bounds__(PR ? 128 : 64) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_mpa_search(MpaSearchArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = lane_id();
   const Grid& G = p.c.G;
   const int RC = G.R * G.C;
+  if (PR) {
+    const int wave = (int)(threadIdx.x >> 6);
+    if (wave == 0) pr_init_ctl(smem, lane);
+    __syncthreads();
+    if (wave == 1) {
+      pool_wave<1>(smem, p.c.tier2 + (size_t)blockIdx.x * PF_POOL_STRIDE, p.c.rec + (size_t)blockIdx.x * RC, G.C, lane);
+      return;
+    }
+  }
+  PrLink link = pr_link(smem);
+  PrLink* const L = &link;
   Open O = make_open(smem, p.c.S, p.c.tier2);
   Slot s = slot_load(p.c, RC);
   AStat tot = {0, 0, 0, 0, 0, 0};
@@ -1390,7 +1415,7 @@ __global__ __launch_bounds__(64) void k_mpa_search(MpaSearchArgs p) {
       const unsigned long long pq0 = tot.pops;
       if (!isph && seg == 0 && lane == 0 && item < 16384) { g_trace3[4 * item] = 1; g_trace3[4 * item + 1] = g0; }
 #endif
-      const int r2 = astar<1>(G, s, O, astart, seg == 0 ? g0 : g1, buf + n - 1, cap - (n - 1), mlen, tot, lane);
+      const int r2 = astar<1, false, PR>(G, s, O, astart, seg == 0 ? g0 : g1, buf + n - 1, cap - (n - 1), mlen, tot, lane, nullptr, 0, L);
 #ifdef PF_TRACE
       if (lane == 0 && item < 16384) { g_trace2[4 * item + 2 * seg] = tot.pops - pq0; g_trace2[4 * item + 2 * seg + 1] = 100 + r2; }
 #endif
@@ -1414,6 +1439,7 @@ __global__ __launch_bounds__(64) void k_mpa_search(MpaSearchArgs p) {
     }
 #endif
   }
+  if (PR) pr_exit(smem, lane);
   slot_store(p.c, s, lane);
   flush_counters(p.c.cnt, tot, 0, ovf, lane);
 }
@@ -1925,6 +1951,7 @@ float pf_last_kernel_ms(pf_handle* h) { return h->last_ms; }
 // resident agent slots per CU and LDS bin capacity; PF_SLOTS_PER_CU / PF_LDS_S override for experiments
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; }
 static const int kSlotsPerCU = 8;                       // resident one-agent waves per CU at most
+static int g_two_wave = env_int("PF_TWO_WAVE", 0);   // MPA searches on two-wave workgroups: pop wave + pool wave (pf_astar_pr.h; pf_set_option "two_wave")
 static const int kWavesPerCU = env_int("PF_WAVES_PER_CU", 8);   // resident one-agent waves per CU (LDS permitting)
 static int g_mpa_prune = 1;   // exact bound pruning of MPA rebuilds (pf_set_option "mpa_prune")
 static int g_settle_top = env_int("PF_SETTLE_TOP", 60);  // auto mode ("astar_settle" -1): per mille of a DECODE batch, from the head of the longest-first queue, whose A* searches
@@ -2034,18 +2061,18 @@ static int make_queue(pf_handle* h, int n, Plan plan) {
 }
 
 template <typename KArgs, typename Kern>
-static int launch_with_retry(pf_handle* h, Kern kern, KArgs& args, int n) {
+static int launch_with_retry(pf_handle* h, Kern kern, KArgs& args, int n, bool two_wave = false) {
   if (n <= 0) return 0;
   const int S = kLdsS;
   args.c.S = S; args.c.retry = 0;
-  const size_t lds = open_bytes(S);
+  const size_t lds = two_wave ? (size_t)PF_PR_LDS_BYTES : open_bytes(S);
   CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = (int)((160 * 1024) / lds); if (per_cu > kWavesPerCU) per_cu = kWavesPerCU; if (per_cu < 1) per_cu = 1;
   int grid = (h->nslots / kSlotsPerCU) * per_cu; if (grid > n) grid = n; if (grid > h->nslots) grid = h->nslots;
   CK(hipMemsetAsync(h->d_work, 0, sizeof(int), h->stream));
   CK(hipMemsetAsync(h->d_cnt, 0, sizeof(DevCounters), h->stream));
   CK(hipEventRecord(h->ev0, h->stream));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, h->stream, args);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(two_wave ? 128 : 64), lds, h->stream, args);
   CK(hipGetLastError());
   CK(hipEventRecord(h->ev1, h->stream));
   DevCounters dc;
@@ -2104,7 +2131,10 @@ int pf_astar_batch(pf_handle* h, int32_t variant, int32_t allow_diag, int32_t re
   // sparse maps (plateaus of equal f along open runs) go to the separately compiled kernels with the plateau refills
   const bool plat = plateau_map(h);
   if (variant == PF_ASTAR_REF) return plat ? launch_with_retry(h, k_astar_batch<0, true>, a, n) : launch_with_retry(h, k_astar_batch<0, false>, a, n);
-  if (variant == PF_ASTAR_MPA) return plat ? launch_with_retry(h, k_astar_batch<1, true>, a, n) : launch_with_retry(h, k_astar_batch<1, false>, a, n);
+  if (variant == PF_ASTAR_MPA) {
+    if (plat) return launch_with_retry(h, k_astar_batch<1, true>, a, n);
+    return g_two_wave ? launch_with_retry(h, k_astar_batch<1, false, true>, a, n, true) : launch_with_retry(h, k_astar_batch<1, false>, a, n);
+  }
   if (variant == PF_ASTAR_DIJKSTRA) return plat ? launch_with_retry(h, k_astar_batch<2, true>, a, n) : launch_with_retry(h, k_astar_batch<2, false>, a, n);
   return failmsg(h, "pf_astar_batch: unknown variant");
 }
@@ -2240,6 +2270,7 @@ int pf_set_option(pf_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "astar_step_cap")) { g_step_cap = value > 0 ? (long long)value : 0; return 0; }
   if (!strcmp(name, "maaco_pack8_min")) { g_maaco_pack8_min = (int)value; return 0; }
   if (!strcmp(name, "mpa_prune")) { g_mpa_prune = value != 0; return 0; }
+  if (!strcmp(name, "two_wave")) { g_two_wave = value != 0; return 0; }
   if (!strcmp(name, "astar_settle")) { g_settle = value < 0 ? -1 : (value != 0); return 0; }
   if (!strcmp(name, "astar_settle_top")) { g_settle_top = value < 0 ? 0 : (value > 1000 ? 1000 : (int)value); return 0; }
   if (!strcmp(name, "plateau_kernels")) { g_plateau_mode = (int)value; return 0; }
@@ -2889,8 +2920,10 @@ int pf_mpa_iter_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uint
   MpaJob* jobs = (MpaJob*)h->d_jobs; MpaRes* jres = (MpaRes*)h->d_jres;
   MpaSearchArgs sa;
   sa.c = a.ph.c; sa.jobs = jobs; sa.res = jres; sa.n_items = 2 * n; sa.path_cap = path_cap; sa.ph_cells = d_c1_cells; sa.fd_cells = d_c2_cells; sa.n = n;
-  const size_t lds = open_bytes(S);
-  CK(hipFuncSetAttribute((const void*)k_mpa_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const bool pr = g_two_wave != 0 && !plateau_map(h);               // two wavefronts per search (pf_astar_pr.h)
+  const size_t lds = pr ? (size_t)PF_PR_LDS_BYTES : open_bytes(S);
+  if (pr) CK(hipFuncSetAttribute((const void*)k_mpa_search<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  else CK(hipFuncSetAttribute((const void*)k_mpa_search<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = (int)((160 * 1024) / lds); if (per_cu > kWavesPerCU) per_cu = kWavesPerCU; if (per_cu < 1) per_cu = 1;
   int grid = (h->nslots / kSlotsPerCU) * per_cu; if (grid > 2 * n) grid = 2 * n; if (grid > h->nslots) grid = h->nslots;
   CK(hipMemsetAsync(h->d_work, 0, sizeof(int), h->stream));
@@ -2898,7 +2931,8 @@ int pf_mpa_iter_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uint
   hipLaunchKernelGGL(k_mpa_plan, dim3(2 * n), dim3(64), 0, h->stream, a, jobs, jres);
   CK(hipGetLastError());
   CK(hipEventRecord(h->ev0, h->stream));
-  hipLaunchKernelGGL(k_mpa_search, dim3(grid), dim3(64), lds, h->stream, sa);
+  if (pr) hipLaunchKernelGGL(k_mpa_search<true>, dim3(grid), dim3(128), lds, h->stream, sa);
+  else hipLaunchKernelGGL(k_mpa_search<false>, dim3(grid), dim3(64), lds, h->stream, sa);
   CK(hipGetLastError());
   CK(hipEventRecord(h->ev1, h->stream));
   hipLaunchKernelGGL(k_mpa_finish, dim3(2 * n), dim3(64), 0, h->stream, a, (const MpaJob*)jobs, (const MpaRes*)jres);

@@ -76,6 +76,7 @@ PF_DEV int move_dc(int d) { return (int)((0x2252u >> (2 * d)) & 3u) - 1; }   // 
 
 }  // namespace pf
 #include "pf_astar_sw.h"
+#include "pf_astar_pr.h"
 #include "pf_settle.h"
 namespace pf {
 
@@ -92,15 +93,17 @@ namespace pf {
 // ---------------------------------------------------------------------------
 #define PF_FLOOD_K 512
 #define PF_FLOOD_TAB 2048
+// (One wave runs the flood.  Its LDS instructions execute in order, so the hand-over points between the lanes need the
+// stores to have been ISSUED, not a workgroup barrier -- which, in the two-wave workgroups of pf_astar_pr.h, the pool wave
+// would never join.)
+#define PF_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 PF_DEV int pocket_flood(const Grid& G, const Slot& s, int* lds, int from, int to, int exempt, int lane) {
   int* tab = lds;                    // [PF_FLOOD_TAB] visited cells (open addressing), -1 = empty
   int* queue = lds + PF_FLOOD_TAB;   // [PF_FLOOD_K]
   for (int i = lane; i < PF_FLOOD_TAB; i += 64) tab[i] = -1;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_s_barrier();
+  PF_WAVE_SYNC();
   if (lane == 0) { queue[0] = from; tab[(unsigned)(from * 0x9E3779B1u) >> 21] = from; }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_s_barrier();
+  PF_WAVE_SYNC();
   const int C = G.C;
   const uint32_t avm = s.avoid_ep;
   const int q = lane >> 3, m = lane & 7;
@@ -137,8 +140,7 @@ PF_DEV int pocket_flood(const Grid& G, const Slot& s, int* lds, int from, int to
     if (tail + nf > PF_FLOOD_K) return 2;
     if (fresh) queue[tail + __builtin_popcountll(fm & ((1ull << lane) - 1ull))] = n;
     tail += nf;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_barrier();
+    PF_WAVE_SYNC();
   }
   return 1;
 }
@@ -147,9 +149,9 @@ PF_DEV int pocket_flood(const Grid& G, const Slot& s, int* lds, int from, int to
 // (r*C+c) start..target.  out_cap is the room available at `out`.
 // av_list / av_n: the cells of this search's avoid set as a list (the same cells mark_avoid has stamped into the
 // records); only the closed-set variants use it, to re-mark them under the parallel engine's label epoch.
-template <int VARIANT, bool PLAT = false>
+template <int VARIANT, bool PLAT = false, bool PR = false>
 __device__ __forceinline__ int astar(const Grid& G, Slot& s, const Open& O, int start, int target, int* out, int out_cap,
-                     int& out_n, AStat& st, int lane, const int* av_list = nullptr, int av_n = 0) {
+                     int& out_n, AStat& st, int lane, const int* av_list = nullptr, int av_n = 0, PrLink* L = nullptr) {
   // VARIANT 0 AStarSolver.solve (astar.py:33-101), 1 MPA._a_star (MPA.py:106-151), 2 DijkstraSolver.solve
   // (dijkstra.py:32-97: the loop of variant 0 with heap entries (g, node), i.e. h == 0 and key (g, g, node))
   constexpr int SEM = VARIANT == 1 ? 1 : 0;
@@ -212,7 +214,7 @@ __device__ __forceinline__ int astar(const Grid& G, Slot& s, const Open& O, int 
   long long cap_steps = (long long)G.R * C * (SEM == 0 ? 3 : 2);   // astar.py:58 / MPA.py:118 (R,C <= 4096)
   if (G.step_cap > 0 && G.step_cap < cap_steps) cap_steps = G.step_cap;   // test hook, see pf_set_option("astar_step_cap")
   const int max_steps = (int)cap_steps;
-  const int status4 = pop_loop_sw<VARIANT, PLAT>(G, rec, O, tag, avm, start, target, tr, tc, max_steps, h0, (sr << 16) | sc_, st, lane);
+  const int status4 = pop_loop_sw<VARIANT, PLAT, PR>(G, rec, O, tag, avm, start, target, tr, tc, max_steps, h0, (sr << 16) | sc_, st, lane, L);
   if (status4 != 0) return status4;
 
   // ---- walk parents target -> start (astar.py:65-69 / MPA.py:124-130), then reverse in place ----

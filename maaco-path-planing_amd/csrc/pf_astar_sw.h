@@ -262,6 +262,21 @@ PF_DEV bool pool_put1(const SwPool& P, double f, double g, int c, int bcur, int&
   PF_LDS_ORDER();
   return true;
 }
+// ---- two-wave mode (pf_astar_pr.h): the pop wave's end of the link to the pool wave.  Declared here because the window code
+// below sends its evictions through it.
+struct PrLink {
+  int* ctl; PoolEnt* ring; double* ring_f; struct SortFG* hand_fg; int* hand_c;
+  unsigned tail;       // entries written to the ring so far (uniform)
+  unsigned pub;        // ... and published
+  int req;             // last take request
+  int sseq;            // search sequence number
+  bool pending;        // a take request is out
+};
+#define PF_PR_RING_N 256
+PF_DEV void pr_ring_put1(PrLink& L, double f, double g, int c, int lane) {   // one entry (uniform values); published with the trip's other pushes
+  if (lane == 0) { ent_put(L.ring + (L.tail & (PF_PR_RING_N - 1)), g, c); L.ring_f[L.tail & (PF_PR_RING_N - 1)] = f; }
+  L.tail += 1;
+}
 // the window (one entry per lane, sorted in [wp, wn)) and the bookkeeping that goes with it
 struct SwWin {
   double wf, wg; int wc;        // this lane's entry
@@ -271,7 +286,8 @@ struct SwWin {
   int n_pool, n_spill;          // entries outside the window (spilled ones included) / in the spill list
 };
 // insert a key that is below the limit; a full window returns its largest entry to the pool, which becomes the limit
-PF_DEV bool win_insert(const SwPool& P, SwWin& W, double kf, double kg, int kc, int lane) {
+template <bool PR = false>
+PF_DEV bool win_insert(const SwPool& P, SwWin& W, double kf, double kg, int kc, int lane, PrLink* L = nullptr) {
   const bool live = lane >= W.wp && lane < W.wn;
   const int p = W.wp + __builtin_popcountll(__ballot(live && key_lt(W.wf, W.wg, W.wc, kf, kg, kc)));   // first live lane not below the key
   if (W.wn < 64) {
@@ -293,16 +309,19 @@ PF_DEV bool win_insert(const SwPool& P, SwWin& W, double kf, double kg, int kc, 
       if (lane > p) { W.wf = sf; W.wg = sg; W.wc = sc; }
       if (lane == p) { W.wf = kf; W.wg = kg; W.wc = kc; }
     }
-    if (!pool_put1(P, ef, eg, ec, W.bcur, W.n_spill, lane)) return false;
+    if (PR) pr_ring_put1(*L, ef, eg, ec, lane);                      // two-wave mode: the pool wave takes it
+    else if (!pool_put1(P, ef, eg, ec, W.bcur, W.n_spill, lane)) return false;
     W.n_pool += 1;
     W.lf = ef; W.lg = eg; W.lc = ec;
   }
   return true;
 }
 // key below the limit -> window, else -> pool (front bucket / f bucket / spill list)
-PF_DEV bool sw_add(const SwPool& P, SwWin& W, double kf, double kg, int kc, int lane) {
-  if (key_lt(kf, kg, kc, W.lf, W.lg, W.lc)) return win_insert(P, W, kf, kg, kc, lane);
-  if (!pool_put1(P, kf, kg, kc, W.bcur, W.n_spill, lane)) return false;
+template <bool PR = false>
+PF_DEV bool sw_add(const SwPool& P, SwWin& W, double kf, double kg, int kc, int lane, PrLink* L = nullptr) {
+  if (key_lt(kf, kg, kc, W.lf, W.lg, W.lc)) return win_insert<PR>(P, W, kf, kg, kc, lane, L);
+  if (PR) pr_ring_put1(*L, kf, kg, kc, lane);
+  else if (!pool_put1(P, kf, kg, kc, W.bcur, W.n_spill, lane)) return false;
   W.n_pool += 1;
   return true;
 }
@@ -605,16 +624,25 @@ PF_DEV int sw_refill(const SwPool& P, SwWin& W, const Open& O, const Rec* rec, i
   return 0;
 }
 
-template <int VARIANT, bool PLAT>
+// forward declarations of the pop wave's side of the two-wave protocol (pf_astar_pr.h)
+PF_DEV void pr_search_start(PrLink& L, int tr, int tc, int bcur0, bool hzero, int lane);
+PF_DEV bool pr_search_stop(PrLink& L, unsigned& spills, bool& overflow, int lane);
+PF_DEV void pr_request(PrLink& L, int want, int lane);
+PF_DEV int pr_take(PrLink& L, SwWin& W, int lane);
+PF_DEV void pr_publish(PrLink& L, int lane);
+PF_DEV bool pr_wait_room(PrLink& L);
+PF_DEV int pr_ld(const int* p);
+
+template <int VARIANT, bool PLAT, bool PR = false>
 __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& O, uint32_t tag, uint32_t avm, int start, int target,
-                                           int tr, int tc, int max_steps, double h0, int src, AStat& st, int lane) {
+                                           int tr, int tc, int max_steps, double h0, int src, AStat& st, int lane, PrLink* L = nullptr) {
   constexpr int SEM = VARIANT == 1 ? 1 : 0;                   // 0: closed set + decrease-key (A*, Dijkstra), 1: MPA._a_star
   constexpr int NBK = PF_SW_NBK, CAP = PF_SW_CAP;
   const int C = G.C, RC = G.R * G.C;
   SwPool P;
   P.cnt = (int*)O.lf; P.be = (PoolEnt*)O.of; P.se = P.be + (NBK + 1) * CAP;
   P.tr = tr; P.tc = tc; P.hzero = VARIANT == 2;
-  for (int k = lane; k <= NBK; k += 64) P.cnt[k] = 0;
+  if (!PR) { for (int k = lane; k <= NBK; k += 64) P.cnt[k] = 0; }   // (two-wave mode: the pool wave owns the buckets)
   PF_LDS_ORDER();
 
   SwWin W;                                                   // the window: lane k in [wp, wn) holds the (k - wp)-th next pop
@@ -624,6 +652,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
   W.bcur = (int)(h0 * PF_SW_Q) + 1;                           // first bucket (absolute index) not yet taken into the window
   W.lf = (double)W.bcur * (1.0 / PF_SW_Q); W.lg = -PF_INF; W.lc = 0;   // keys below (lf, lg, lc) belong to the window
   W.n_pool = 0; W.n_spill = 0;
+  if (PR) pr_search_start(*L, tr, tc, W.bcur, VARIANT == 2, lane);
   int steps = 0, status = 1;
   unsigned nbr_l = 0, push_l = 0, dk_l = 0;                  // per-lane event counts, summed over the wave once at the end
   int n_max = 1;
@@ -646,12 +675,35 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
 #endif
   for (;;) {
     SW_T(t0)
-    if (PF_EARLY_REFILL) sw_early_refill<SEM>(P, W, O, rec, C, lane, 7);
-    if (W.wp == W.wn) {
-      const int rr_ = sw_refill<SEM, PLAT>(P, W, O, rec, C, lane);
-      if (rr_ == 1) { status = 1; break; }
-      if (rr_ == 3) { status = 3; break; }
-      if (rr_ == 4) continue;
+    unsigned rhead = 0;
+    if (PR) {
+      // two-wave mode: the window is refilled from the pool wave's window (requested at the end of the previous trip)
+      if (!L->pending && W.wp == W.wn) {
+        if (W.n_pool == 0) { status = 1; break; }
+        pr_request(*L, 64, lane);
+#ifdef PF_STAMPS
+        sw_cnt[3] += 1;
+#endif
+      }
+      if (L->pending) {
+#ifdef PF_STAMPS
+        const int wn0_ = W.wn - W.wp; const unsigned long long tq0_ = __builtin_amdgcn_s_memtime();
+#endif
+        if (pr_take(*L, W, lane) != 0) { status = 3; break; }
+#ifdef PF_STAMPS
+        sw_cnt[0] += 1; sw_cnt[1] += (W.wn - W.wp) - wn0_; sw_cnt[2] += __builtin_amdgcn_s_memtime() - tq0_;
+#endif
+        if (W.wp == W.wn) { status = W.n_pool == 0 ? 1 : 3; break; }
+      }
+      rhead = (unsigned)pr_ld(L->ctl + 2 /* PR_HEAD */);        // (used by the push section: its latency is covered by the trip)
+    } else {
+      if (PF_EARLY_REFILL) sw_early_refill<SEM>(P, W, O, rec, C, lane, 7);
+      if (W.wp == W.wn) {
+        const int rr_ = sw_refill<SEM, PLAT>(P, W, O, rec, C, lane);
+        if (rr_ == 1) { status = 1; break; }
+        if (rr_ == 3) { status = 3; break; }
+        if (rr_ == 4) continue;
+      }
     }
     SW_T(t1)
     // ---- pop: up to seven heads of the window at once, nine lanes each ----
@@ -861,8 +913,25 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     const int pb = pba < W.bcur ? NBK : (pba & (NBK - 1));       // below every regular bucket: the front bucket
     const bool inrange = pba - W.bcur < NBK;                   // inside the circular bucket range (front bucket: always)
     int pat = 0;
-    if (top && inrange) pat = __hip_atomic_fetch_add(&P.cnt[pb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     const unsigned long long pm = __ballot(push), im0 = __ballot(tow);
+    if (PR) {
+      // two-wave mode: 16 bytes into the ring, in lane order; the pool wave buckets them
+      if (L->tail - rhead > PF_PR_RING_N - 128) { if (!pr_wait_room(*L)) { status = 3; break; } }
+      const unsigned long long tm = pm & ~im0;
+      if (top) {
+        const unsigned at = (L->tail + (unsigned)__builtin_popcountll(tm & ((1ull << lane) - 1ull))) & (PF_PR_RING_N - 1);
+        ent_put(L->ring + at, tent, nrc); L->ring_f[at] = fnew;     // (f travels too: the pool wave need not take the square root again)
+      }
+      L->tail += (unsigned)__builtin_popcountll(tm);
+      // Published now, not at the end of the trip: the pool wave buckets them while I store records.  And if fewer than seven
+      // heads will be left for the next trip, the take is requested here already (no eviction can follow: the window is
+      // nearly empty), so that the answer is ready when the trip starts.
+      if (W.n_pool + __builtin_popcountll(tm) > 0 && (W.wn - W.wp) + __builtin_popcountll(im0) < 7)
+        pr_request(*L, 64 - (W.wn - W.wp) - __builtin_popcountll(im0), lane);
+      else pr_publish(*L, lane);
+    } else {
+      if (top && inrange) pat = __hip_atomic_fetch_add(&P.cnt[pb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     W.n_pool += __builtin_popcountll(pm & ~im0);
     push_l += (push && !(SEM == 0 && in_open)) ? 1u : 0u;       // heappush calls of the reference
     SW_T(t5)
@@ -883,11 +952,11 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
         }
       }
       // (an eviction inside this loop may have lowered the limit below this key: sw_add re-checks)
-      if (!sw_add(P, W, bcast_d(fnew, l), bcast_d(tent, l), kc, lane)) { status = 3; break; }
+      if (!sw_add<PR>(P, W, bcast_d(fnew, l), bcast_d(tent, l), kc, lane, L)) { status = 3; break; }
     }
     if (status == 3) break;
     SW_T(t6)
-    {
+    if (!PR) {
       const bool fits = inrange && pat < CAP;
       if (top && fits) ent_put(P.be + pb * CAP + pat, tent, nrc);
       const unsigned long long sm = __ballot(top && !fits);     // bucket full or beyond the circular range: spill list
@@ -903,6 +972,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
       }
     }
     if (hit) { status = 0; break; }
+    if (PR) pr_publish(*L, lane);                               // (evictions of the insert loop, if any)
     PF_LDS_ORDER();
     SW_T(t7)
     SW_ACC(0, t0, t1) SW_ACC(1, t1, t2) SW_ACC(2, t2, t3) SW_ACC(3, t3, t4) SW_ACC(4, t4, t5) SW_ACC(5, t5, t6) SW_ACC(6, t6, t7)
@@ -930,6 +1000,11 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     for (int i = 0; i < 6; ++i) atomicAdd(&g_stamps[16 + i], sw_er[i]);
   }
 #endif
+  if (PR) {
+    bool ovf = false;
+    pr_search_stop(*L, st.spills, ovf, lane);
+    if (ovf) status = 3;                                        // the pool wave lost entries (or never answered): never silent
+  }
   if (n_max > st.max_open) st.max_open = n_max;
   st.pops += (unsigned long long)steps; st.pushes += 1u + (unsigned)wave_sum_i((int)push_l);
 #ifdef PF_TRIPS

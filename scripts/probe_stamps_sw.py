@@ -28,8 +28,13 @@ for n in ((int(sys.argv[1]),) if len(sys.argv) > 1 else (1,)):
         print(f"n={n} v{v}: {e.last_kernel_ms():.1f} ms pops {pops} trips {trips} pops/trip {pops / trips:.2f} clocks/trip {out[:7].sum() / trips:.0f}: " +
               "; ".join(f"{names[i]} {out[i] / trips:.0f}" for i in range(7)))
         c = out[8:16].astype(float); er = out[16:].astype(float)
-        if er[0] > 0:
+        if er[0] > 0 and not (os.environ.get("PF_TWO_WAVE", "1") != "0" and v == 1):
             print(f"      early refills: {int(er[0])} (every {trips / er[0]:.1f} trips), entries avg {er[1] / er[0]:.1f}, buckets avg {er[3] / er[0]:.1f}, largest bucket avg {er[2] / er[0]:.1f}; "
                   f"clocks per early refill: waiting for the pool entries {er[4] / er[0]:.0f}, sort {er[5] / er[0]:.0f}")
+        if os.environ.get("PF_TWO_WAVE", "1") != "0" and v == 1:
+            print(f"      two-wave: takes {int(c[0])} (every {trips / max(c[0], 1):.1f} trips), entries per take {c[1] / max(c[0], 1):.1f}, clocks per take {c[2] / max(c[0], 1):.0f}, "
+                  f"takes with an empty window {int(c[3])}")
+            print(f"      pool wave: draining {er[0] / trips:.0f} clocks per trip ({er[0] / max(er[1], 1):.0f} per entry, {er[1] / trips:.1f} entries per trip); background refills {int(er[3])} "
+                  f"({er[2] / max(er[3], 1):.0f} clocks each, {er[2] / trips:.0f} per trip); serving {er[4] / max(c[0], 1):.0f} clocks per take, {int(er[5])} refills at serve time")
         print(f"      refills: front small {int(c[0])} (avg {c[1] / max(c[0], 1):.1f}), front big {int(c[2])} (avg size {c[3] / max(c[2], 1):.1f}), "
               f"regular {int(c[6])} (avg {c[7] / max(c[6], 1):.1f}), regular big {int(c[4])} (avg size {c[5] / max(c[4], 1):.1f})")

@@ -69,6 +69,35 @@ def test_mpa_bound_pruning_changes_nothing(fused):
     assert runs[0][3] > 0 and runs[1][3] == 0
 
 
+@pytest.mark.parametrize("gname,N", [("g256", 384), ("g512", 1024)])
+def test_two_wave_searches_equal_single_wave(gname, N):
+    """pf_astar_pr.h: a search on a pop wave + a pool wave pops exactly what the single wave pops -- whole populations,
+    candidate rows, pop / push counters of every sweep, three phases."""
+    import pathfit
+    from pathfit import env
+    g = env.bench_grid(512) if gname == "g512" else gio.grid("g256")[0]
+    kw = dict(FADs_rate=0.2, P_const=0.5, levy_beta=1.5, turn_penalty_factor=0.1, safety_penalty_factor=0.8,
+              min_safe_distance=1.8, diagonal_obstacle_penalty=100.0)
+    runs = []
+    for two in (1, 0):
+        m = pathfit.MPA(g, N, 6, seed=3, **kw)
+        m.engine.set_option("two_wave", two)
+        log = []
+        for it in range(1, 7):
+            m.step(it)
+            c = m.engine.counters()
+            log.append((c["pops"], c["pushes"], c["nbr_examined"], c["overflow_agents"]))
+        runs.append((m.d_cells.download(), m.d_len.download(), m.d_stats.download(), m.d_cand_len.download(), m.d_cand_stats.download(), log))
+        m.engine.set_option("two_wave", 0)
+        m.engine.close()
+    a, b = runs
+    assert a[5] == b[5], (a[5], b[5])
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+    for i in range(N):
+        assert np.array_equal(a[0][i, :a[1][i]], b[0][i, :b[1][i]])
+    assert all(x[3] == 0 for x in a[5])
+
+
 @pytest.mark.parametrize("beta", [7.0, 2.0])
 def test_maaco_solve_matches_oracle_loop(beta):
     import pathfit, pf_oracle as po, pf_loops
