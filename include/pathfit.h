@@ -166,6 +166,20 @@ int pf_maaco_evaporate(pf_handle* h);
 int pf_maaco_deposit(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_cells, const int32_t* d_len,
                      const double* d_plen);
 int pf_maaco_clip(pf_handle* h, double best_len_overall);
+/* The same update (MAACO.py:304-332) in ONE pass over tau for the paths of one batch on one GPU: per cell evaporate (:305),
+ * the deposits in ant order (:306-311), clip (:312-332) -- the same fp64 operations in the same order as the three calls
+ * above.  Successful ants mark their own deposits at the end of their walk (option "maaco_mark_in_walk", default 1), so
+ * the update of the batch that was just walked needs no pass over the paths. */
+int pf_maaco_update(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_cells, const int32_t* d_len, const double* d_plen,
+                    double best_len_overall);
+/* One whole iteration of MAACO.solve_path_planning (MAACO.py:340-359) for the ants of one GPU, enqueued back to back: walks,
+ * best-of-iteration scan (:343-349), take-over test against the caller's overall best (:351-358), one-pass pheromone update.
+ * ONE 104-byte copy comes back: out13 = {ib_len, ib_turns, ib_idx, took, best_len, best_turns, tmin, tmax, skipped, steps,
+ * candidates, path_cells, overflow_agents}.  overflow_agents > 0: the pheromone was left untouched (skipped = 1); repeat
+ * the call with longer path rows. */
+int pf_maaco_iterate(pf_handle* h, int32_t iter, uint64_t seed, int32_t ant0, int32_t n, int32_t path_cap,
+                     int32_t* d_cells, int32_t* d_len, double* d_plen, int32_t* d_turns, int32_t* d_status,
+                     double best_len, double best_turns, double* out13);
 /* pheromone_matrix attribute round trip (double[R*C]) */
 int pf_maaco_get_pheromone(pf_handle* h, double* tau);
 int pf_maaco_set_pheromone(pf_handle* h, const double* tau);

@@ -437,6 +437,10 @@ struct MaacoArgs {
   int start, target, iter, num_iterations; double q0;
   unsigned long long seed; int ant0, n, path_cap;
   int* cells; int* len; double* plen; int* turns; int* status;
+  // non-null: a successful ant marks the cells it visited in the deposit bit matrix as it finishes (bit a & 63 of word
+  // [a >> 6][cell]; atomicOr is order independent, so the matrix equals k_visit_bits') and leaves its deposit Q / L in dep[a]
+  // (MAACO.py:307-308): the separate pass over all paths is gone
+  unsigned long long* bits; double* dep; double Q;
 };
 
 __global__ void k_pack_tep(int RC, const double* tau, const double* eta, double* tep) {
@@ -598,6 +602,16 @@ __global__ __launch_bounds__(64) void k_maaco_walk(MaacoArgs p) {
       p.plen[a] = rc == 0 ? plen : PF_INF;
       p.turns[a] = rc == 0 ? nturn : -1;
       p.status[a] = rc;
+    }
+    if (p.bits) {
+      const bool good = rc == 0 && n > 0 && plen > 1e-6;           // MAACO.py:307
+      if (lane == 0) p.dep[a] = good ? p.Q / plen : 0.0;            // :308
+      if (good) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // lane 0 wrote the path
+        unsigned long long* w = p.bits + (size_t)(a >> 6) * RC;
+        const unsigned long long bit = 1ull << (a & 63);
+        for (int i = lane; i < n; i += 64) atomicOr(&w[out[i]], bit);
+      }
     }
     cells_tot += rc == 0 ? n : 0; ovf_tot += rc == 3;
   }
@@ -782,6 +796,31 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
       cells_tot += rc == 0 ? n : 0; ovf_tot += rc == 3;
       need = true;
     }
+    if (p.bits) {
+      // the ants that finished in this round mark their deposits: the WHOLE wave walks each finished path (64 cells a round;
+      // the other groups would only wait for a group that marked alone, 8 cells a round)
+      const bool fin = alive && done;
+      const bool good = fin && rc == 0 && n > 0 && plen > 1e-6;    // MAACO.py:307
+      if (fin && k == 0) p.dep[a] = good ? p.Q / plen : 0.0;        // :308
+      unsigned long long gm = __ballot(good && k == 0);
+      if (gm) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // lane k == 0 wrote the path
+        for (; gm; gm &= gm - 1) {
+          const int l = __builtin_ctzll(gm);
+          const int aa = bcast_i(a, l), nn = bcast_i(n, l);
+          const int* oo = p.cells + (size_t)aa * p.path_cap;
+          unsigned long long* w = p.bits + (size_t)(aa >> 6) * RC;
+          const unsigned long long bit = 1ull << (aa & 63);
+          for (int i = lane; i < nn; i += 256) {                    // four cell loads in flight, then their (unwaited) atomics
+            int c4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) c4[u] = i + 64 * u < nn ? oo[i + 64 * u] : -1;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (c4[u] >= 0) __hip_atomic_fetch_or(&w[c4[u]], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+    }
   }
   if (k == 0) {
     p.slot_epoch[slot] = epoch;
@@ -904,6 +943,69 @@ __global__ void k_tau_clip(double* tau, const uint8_t* occ, int RC, double tmin,
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= RC) return;
   tau[i] = occ[i] == 1 ? 1e-9 : fmin(fmax(tau[i], tmin), tmax);   // MAACO.py:326-332
+}
+
+// MAACO.py:351-358 on the device, so that an iteration needs ONE small copy to the host: does the iteration's best ant take
+// over the overall best, and what are the clip bounds of the pheromone update that follows (:312-323, with the overall best
+// AFTER this iteration's take).  state = {ib_len, ib_turns, ib_idx, took, best_len, best_turns, tmin, tmax, skip, steps,
+// candidates, path_cells, overflow}; skip = 1 when an ant overflowed its path row (the caller redoes the iteration with
+// longer rows: the pheromone must not move).
+__global__ void k_maaco_take(const double* scan3, double best_len, double best_turns, double rho, int R, int C, const DevCounters* cnt,
+                             double* state) {
+  const double il = scan3[0], it = scan3[1];
+  double took = 0.0;
+  if (il < best_len) { best_len = il; best_turns = it; took = 1.0; }                          // :351-354
+  else if (fabs(il - best_len) < 1e-9 && it < best_turns) { best_turns = it; took = 1.0; }    // :355-358
+  double bl = best_len;                                            // MAACO.py:312-316
+  if (bl == PF_INF) bl = (double)(R + C);
+  if (bl < 1e-6) bl = 1e-6;
+  const double tmax = (1.0 / (1.0 - rho)) * (1.0 / bl);            // :317
+  int mx = C > R ? C : R; if (mx < 1) mx = 1;
+  state[0] = il; state[1] = it; state[2] = scan3[2]; state[3] = took; state[4] = best_len; state[5] = best_turns;
+  state[6] = tmax / (2.0 * mx); state[7] = tmax;                    // :323
+  state[8] = cnt->overflow ? 1.0 : 0.0;
+  state[9] = (double)cnt->steps; state[10] = (double)cnt->candidates; state[11] = (double)cnt->path_cells; state[12] = (double)cnt->overflow;
+}
+// The whole of MAACO.py:304-332 in ONE pass over tau: per cell t = tau * (1 - rho) (:305), then the deposits of the ants that
+// visited it in ant order (:306-311; k_tau_deposit's ordered walk of the bit matrix), then the clip (:326-332) -- the same
+// fp64 operations in the same order as the three kernels, one read and one write of tau instead of three each.  The clip
+// bounds come from `state` (k_maaco_take) or, when state is null, from the arguments.
+__global__ __launch_bounds__(1024) void k_tau_update(double* tau, const uint8_t* occ, int RC, unsigned long long* bits, int nwords,
+                                                    const double* dep, double keep, const double* state, double tmin_a, double tmax_a) {
+  extern __shared__ __attribute__((aligned(16))) double sdep[];    // [PF_DEP_CHUNK]
+  if (state && state[8] != 0.0) return;                            // an ant overflowed: the iteration is redone, tau stays
+  const double tmin = state ? state[6] : tmin_a, tmax = state ? state[7] : tmax_a;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < RC;
+  double t = live ? tau[i] * keep : 0.0;                           // :305
+  for (int c0 = 0; c0 < nwords; c0 += PF_DEP_CHUNK / 64) {
+    const int cw = nwords - c0 < PF_DEP_CHUNK / 64 ? nwords - c0 : PF_DEP_CHUNK / 64;
+    __syncthreads();
+    for (int k = threadIdx.x; k < cw * 64; k += blockDim.x) sdep[k] = dep[c0 * 64 + k];
+    __syncthreads();
+    if (!live) continue;
+    for (int w0 = 0; w0 < cw; w0 += 8) {
+      unsigned long long b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) b[u] = (w0 + u < cw) ? bits[(size_t)(c0 + w0 + u) * RC + i] : 0ull;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (b[u]) bits[(size_t)(c0 + w0 + u) * RC + i] = 0ull;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        unsigned long long x = b[u];
+        const double* dw = sdep + (w0 + u) * 64;
+        while (x) {
+          const int j0 = __builtin_ctzll(x); x &= x - 1;
+          const bool h1 = x != 0; const int j1 = h1 ? __builtin_ctzll(x) : j0; x &= x - 1;
+          const bool h2 = x != 0; const int j2 = h2 ? __builtin_ctzll(x) : j0; x &= x - 1;
+          const bool h3 = x != 0; const int j3 = h3 ? __builtin_ctzll(x) : j0; x &= x - 1;
+          const double d0 = dw[j0], d1 = dw[j1], d2 = dw[j2], d3 = dw[j3];
+          t += d0; t += h1 ? d1 : 0.0; t += h2 ? d2 : 0.0; t += h3 ? d3 : 0.0;
+        }
+      }
+    }
+  }
+  if (live) tau[i] = occ[i] == 1 ? 1e-9 : fmin(fmax(t, tmin), tmax);   // :326-332 (paths never cross obstacles: their words are empty)
 }
 
 // ===========================================================================
@@ -1738,6 +1840,8 @@ struct pf_handle {
   pf_maaco_params mp = {};
   double *d_tau = nullptr, *d_taua = nullptr, *d_eta = nullptr, *d_dep = nullptr, *d_tep = nullptr;
   bool bits_clean = false;            // the visit-bit matrix is all zero (k_tau_deposit leaves it so)
+  int marks_n = 0; const int* marks_cells = nullptr;   // the last walk batch marked its own deposits (for these n ants / this path buffer)
+  double* d_mstate = nullptr;         // pf_maaco_iterate's 13 doubles
   unsigned* d_visit = nullptr; unsigned* d_visit_epoch = nullptr; int maaco_slots = 0;
   unsigned long long* d_bits = nullptr; size_t bits_words = 0; int dep_cap = 0;
   // MPA
@@ -1902,7 +2006,7 @@ void pf_destroy(pf_handle* h) {
   if (h->comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(h->stream); g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
   void* ptrs[] = {h->d_occ, h->d_mm_r1, h->d_mm_r0, h->d_mm_r1_nd, h->d_mm_r0_nd, h->d_d2near, h->d_rec, h->d_slot_state,
                   h->d_work, h->d_cnt, h->d_pen, h->d_tier2, h->d_tau, h->d_taua, h->d_eta, h->d_dep, h->d_tep, h->d_visit, h->d_visit_epoch,
-                  h->d_bits, h->d_tmp, h->d_elite_stats, h->d_init_cells, h->d_init_stats, h->d_est, h->d_est2, h->d_iota, h->d_queue, h->d_sort_tmp, h->d_jobs, h->d_jres, h->d_prop, h->d_doubt, h->d_scan, h->d_scan3, h->d_okey, h->d_okey2, h->d_oval2, h->d_elite_cells, h->d_elite_len, h->d_ga_pool, h->d_st_lab, h->d_st_touched, h->d_st_par, h->d_st_epoch,
+                  h->d_bits, h->d_mstate, h->d_tmp, h->d_elite_stats, h->d_init_cells, h->d_init_stats, h->d_est, h->d_est2, h->d_iota, h->d_queue, h->d_sort_tmp, h->d_jobs, h->d_jres, h->d_prop, h->d_doubt, h->d_scan, h->d_scan3, h->d_okey, h->d_okey2, h->d_oval2, h->d_elite_cells, h->d_elite_len, h->d_ga_pool, h->d_st_lab, h->d_st_touched, h->d_st_par, h->d_st_epoch,
                   h->d_comp[0], h->d_comp[1], h->d_comp[2], h->d_comp[3], h->d_ds, h->d_dt};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1950,9 +2054,9 @@ float pf_last_kernel_ms(pf_handle* h) { return h->last_ms; }
 // ---- scratch / launch helpers ----------------------------------------------
 // resident agent slots per CU and LDS bin capacity; PF_SLOTS_PER_CU / PF_LDS_S override for experiments
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; }
-static const int kSlotsPerCU = 8;                       // resident one-agent waves per CU at most
+static const int kSlotsPerCU = env_int("PF_SLOTS_PER_CU", 8);   // search slots (record / pool scratch) per CU = resident one-agent waves per CU at most
 static int g_two_wave = env_int("PF_TWO_WAVE", 0);   // MPA searches on two-wave workgroups: pop wave + pool wave (pf_astar_pr.h; pf_set_option "two_wave")
-static const int kWavesPerCU = env_int("PF_WAVES_PER_CU", 8);   // resident one-agent waves per CU (LDS permitting)
+static const int kWavesPerCU = env_int("PF_WAVES_PER_CU", kSlotsPerCU);   // resident one-agent waves per CU (LDS permitting)
 static int g_mpa_prune = 1;   // exact bound pruning of MPA rebuilds (pf_set_option "mpa_prune")
 static int g_settle_top = env_int("PF_SETTLE_TOP", 60);  // auto mode ("astar_settle" -1): per mille of a DECODE batch, from the head of the longest-first queue, whose A* searches
                                                          // also try the engine (pf_set_option "astar_settle_top")
@@ -1963,6 +2067,7 @@ static int g_settle = env_int("PF_SETTLE", -1);  // closed-set searches try the 
 static double g_doubt_log = 1.0 / 8589934592.0;   // 2^-33 relative margin on normalvariate's accept test (pf_set_option "mpa_doubt_log_e15" overrides, in 1e-15)
 static double g_doubt_round = 1e-7;                // absolute margin on the fraction fed to round()   ("mpa_doubt_round_e15")
 static int g_maaco_pack8_min = env_int("PF_MAACO_PACK8_MIN", 2048);   // ants per batch from which 8 ants share a wavefront
+static int g_maaco_mark = env_int("PF_MAACO_MARK", 1);   // successful ants mark their deposits in the walk kernel (pf_set_option "maaco_mark_in_walk")
 static int g_tabu_epoch = -1;                      // test hook ("maaco_tabu_epoch"): >= 0 -> the next walk batch starts its tabu slots from this epoch (wrap coverage)
 static const int kLdsS = 16;
 static int ensure_slots(pf_handle* h, int allow_diag = 1, int restrict_corner = 1) {
@@ -2271,6 +2376,7 @@ int pf_set_option(pf_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "maaco_pack8_min")) { g_maaco_pack8_min = (int)value; return 0; }
   if (!strcmp(name, "mpa_prune")) { g_mpa_prune = value != 0; return 0; }
   if (!strcmp(name, "two_wave")) { g_two_wave = value != 0; return 0; }
+  if (!strcmp(name, "maaco_mark_in_walk")) { g_maaco_mark = value != 0; return 0; }
   if (!strcmp(name, "astar_settle")) { g_settle = value < 0 ? -1 : (value != 0); return 0; }
   if (!strcmp(name, "astar_settle_top")) { g_settle_top = value < 0 ? 0 : (value > 1000 ? 1000 : (int)value); return 0; }
   if (!strcmp(name, "plateau_kernels")) { g_plateau_mode = (int)value; return 0; }
@@ -2376,12 +2482,26 @@ static double maaco_q0(int it, int K, double q0_initial) {          // MAACO.py:
   return fmin(fmax(q, 0.01), 0.99);
 }
 
-int pf_maaco_walk_batch(pf_handle* h, int32_t iter, uint64_t seed, int32_t ant0, int32_t n, int32_t path_cap,
-                        int32_t* d_cells, int32_t* d_len, double* d_plen, int32_t* d_turns, int32_t* d_status) {
-  if (!h) return -2;
-  if (!h->maaco_ready) return failmsg(h, "pf_maaco_walk_batch: call pf_maaco_setup first");
-  if (n < 0 || path_cap < 2 || !d_cells || !d_len || !d_plen || !d_turns || !d_status) return failmsg(h, "pf_maaco_walk_batch: bad arguments");
-  if (n == 0) { memset(&h->last, 0, sizeof(h->last)); return 0; }   // an empty batch has empty counters (not the previous batch's overflow)
+// room for the deposit bit matrix / the per-ant deposits of a batch of n ants; the matrix is (re)zeroed unless the last
+// deposit pass left it so
+static int maaco_ensure_bits(pf_handle* h, int n) {
+  const size_t words = (size_t)(n + 63) / 64;
+  if (words > h->bits_words) {
+    if (h->d_bits) CK(hipFree(h->d_bits));
+    CK(hipMalloc(&h->d_bits, words * h->RC * sizeof(unsigned long long)));
+    h->bits_words = words;
+    h->bits_clean = false;
+  }
+  if ((int)(words * 64) > h->dep_cap) { if (h->d_dep) CK(hipFree(h->d_dep)); CK(hipMalloc(&h->d_dep, sizeof(double) * (size_t)words * 64)); h->dep_cap = (int)(words * 64); }
+  if (!h->bits_clean)      // (the deposit kernels hand the matrix back zeroed; a fresh buffer, a failed or an abandoned batch does not)
+    CK(hipMemsetAsync(h->d_bits, 0, h->bits_words * h->RC * sizeof(unsigned long long), h->stream));
+  h->bits_clean = false;
+  CK(hipMemsetAsync(h->d_dep, 0, sizeof(double) * words * 64, h->stream));
+  return 0;
+}
+// enqueue the walk of ants [ant0, ant0 + n) (nothing waits); the ants mark their own deposits when g_maaco_mark is on
+static int maaco_enqueue_walk(pf_handle* h, int32_t iter, uint64_t seed, int32_t ant0, int32_t n, int32_t path_cap,
+                              int32_t* d_cells, int32_t* d_len, double* d_plen, int32_t* d_turns, int32_t* d_status) {
   CK(hipSetDevice(h->device));
   MaacoArgs a;
   a.G = make_grid(h, 1, 1);
@@ -2394,6 +2514,13 @@ int pf_maaco_walk_batch(pf_handle* h, int32_t iter, uint64_t seed, int32_t ant0,
   a.q0 = maaco_q0(iter, h->mp.num_iterations, h->mp.q0_initial);
   a.seed = seed; a.ant0 = ant0; a.n = n; a.path_cap = path_cap;
   a.cells = d_cells; a.len = d_len; a.plen = d_plen; a.turns = d_turns; a.status = d_status;
+  a.bits = nullptr; a.dep = nullptr; a.Q = h->mp.Q;
+  h->marks_n = 0; h->marks_cells = nullptr;
+  if (g_maaco_mark) {
+    if (maaco_ensure_bits(h, n)) return -1;
+    a.bits = h->d_bits; a.dep = h->d_dep;
+    h->marks_n = n; h->marks_cells = d_cells;                       // deposit_begin for exactly this batch finds its marks made
+  }
   // eight ants per wavefront (k_maaco_walk8) once the batch can fill the chip that way; else one per wave
   const bool pack8 = n >= g_maaco_pack8_min;
   int grid = pack8 ? h->maaco_slots / 8 : (h->maaco_slots < 8192 ? h->maaco_slots : 8192);
@@ -2410,8 +2537,56 @@ int pf_maaco_walk_batch(pf_handle* h, int32_t iter, uint64_t seed, int32_t ant0,
   else hipLaunchKernelGGL(k_maaco_walk, dim3(grid), dim3(64), 0, h->stream, a);
   CK(hipGetLastError());
   CK(hipEventRecord(h->ev1, h->stream));
+  return 0;
+}
+int pf_maaco_walk_batch(pf_handle* h, int32_t iter, uint64_t seed, int32_t ant0, int32_t n, int32_t path_cap,
+                        int32_t* d_cells, int32_t* d_len, double* d_plen, int32_t* d_turns, int32_t* d_status) {
+  if (!h) return -2;
+  if (!h->maaco_ready) return failmsg(h, "pf_maaco_walk_batch: call pf_maaco_setup first");
+  if (n < 0 || path_cap < 2 || !d_cells || !d_len || !d_plen || !d_turns || !d_status) return failmsg(h, "pf_maaco_walk_batch: bad arguments");
+  if (n == 0) { memset(&h->last, 0, sizeof(h->last)); h->marks_n = 0; return 0; }   // an empty batch has empty counters (not the previous batch's overflow)
+  if (maaco_enqueue_walk(h, iter, seed, ant0, n, path_cap, d_cells, d_len, d_plen, d_turns, d_status)) return -1;
   DevCounters dc; if (end_batch(h, &dc)) return -1;
   CK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  return 0;
+}
+
+// One whole iteration of MAACO.solve_path_planning (MAACO.py:340-359) for ants [ant0, ant0 + n) of ONE GPU, enqueued back to
+// back: the walks (each successful ant marks its own deposits), the best-of-iteration scan (:343-349), the take-over test
+// against the caller's overall best (:351-358), and the pheromone update in one pass (:304-332).  ONE small copy comes back:
+// out13 = {ib_len, ib_turns, ib_idx, took, best_len, best_turns, tmin, tmax, skipped, steps, candidates, path_cells,
+// overflow_agents}.  If an ant overflowed its path row (overflow_agents > 0) the pheromone is left untouched and the
+// caller repeats the call with longer rows (same iteration, same streams).
+int pf_maaco_iterate(pf_handle* h, int32_t iter, uint64_t seed, int32_t ant0, int32_t n, int32_t path_cap,
+                     int32_t* d_cells, int32_t* d_len, double* d_plen, int32_t* d_turns, int32_t* d_status,
+                     double best_len, double best_turns, double* out13) {
+  if (!h) return -2;
+  if (!h->maaco_ready) return failmsg(h, "pf_maaco_iterate: call pf_maaco_setup first");
+  if (n <= 0 || path_cap < 2 || !d_cells || !d_len || !d_plen || !d_turns || !d_status || !out13) return failmsg(h, "pf_maaco_iterate: bad arguments");
+  const int mark0 = g_maaco_mark; g_maaco_mark = 1;
+  const int rc = maaco_enqueue_walk(h, iter, seed, ant0, n, path_cap, d_cells, d_len, d_plen, d_turns, d_status);
+  g_maaco_mark = mark0;
+  if (rc) return -1;
+  if (!h->d_scan3) CK(hipMalloc(&h->d_scan3, 24));
+  if (!h->d_mstate) CK(hipMalloc(&h->d_mstate, 16 * sizeof(double)));
+  hipLaunchKernelGGL(k_maaco_best, dim3(1), dim3(1024), 0, h->stream, n, d_plen, d_turns, (double*)h->d_scan3);
+  hipLaunchKernelGGL(k_maaco_take, dim3(1), dim3(1), 0, h->stream, (const double*)h->d_scan3, best_len, best_turns, h->mp.rho, h->R, h->C,
+                     (const DevCounters*)h->d_cnt, h->d_mstate);
+  const int words = (n + 63) / 64;
+  CK(hipFuncSetAttribute((const void*)k_tau_update, hipFuncAttributeMaxDynamicSharedMemorySize, PF_DEP_CHUNK * (int)sizeof(double)));
+  hipLaunchKernelGGL(k_tau_update, dim3((h->RC + 1023) / 1024), dim3(1024), PF_DEP_CHUNK * sizeof(double), h->stream, h->d_tau, h->d_occ,
+                     h->RC, h->d_bits, words, h->d_dep, 1.0 - h->mp.rho, (const double*)h->d_mstate, 0.0, 0.0);
+  CK(hipGetLastError());
+  CK(hipMemcpyAsync(out13, h->d_mstate, 13 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  CK(hipStreamSynchronize(h->stream));
+  h->d2h_small += 1;
+  CK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  memset(&h->last, 0, sizeof(h->last));
+  h->last.steps = (unsigned long long)out13[9]; h->last.candidates = (unsigned long long)out13[10];
+  h->last.path_cells = (unsigned long long)out13[11]; h->last.overflow_agents = (unsigned long long)out13[12];
+  h->marks_n = 0;
+  h->bits_clean = out13[8] == 0.0;                                  // the update pass read and zeroed every word (a skipped one did not)
+  if (out13[8] == 0.0) return maaco_refresh_taua(h);                // (alpha == 1: nothing to do, nothing waits)
   return 0;
 }
 
@@ -2433,21 +2608,37 @@ int pf_maaco_deposit_begin(pf_handle* h, int32_t n, int32_t path_cap, const int3
   if (n <= 0) return 0;
   CK(hipSetDevice(h->device));
   const size_t words = (size_t)(n + 63) / 64;
-  if (words > h->bits_words) {
-    if (h->d_bits) CK(hipFree(h->d_bits));
-    CK(hipMalloc(&h->d_bits, words * h->RC * sizeof(unsigned long long)));
-    h->bits_words = words;
-    h->bits_clean = false;
+  if (h->marks_n == n && h->marks_cells == d_cells) {
+    // the walk batch that produced exactly these paths has marked them already (pf_set_option "maaco_mark_in_walk")
+    h->marks_n = 0;
+  } else {
+    if (maaco_ensure_bits(h, n)) return -1;
+    hipLaunchKernelGGL(k_visit_bits, dim3(n), dim3(64), 0, h->stream, n, path_cap, d_cells, d_len, d_plen, h->mp.Q, h->d_bits, h->RC, h->d_dep);
+    CK(hipGetLastError());
   }
-  if (n > h->dep_cap) { if (h->d_dep) CK(hipFree(h->d_dep)); CK(hipMalloc(&h->d_dep, sizeof(double) * (size_t)words * 64)); h->dep_cap = (int)(words * 64); }
-  if (!h->bits_clean)      // (k_tau_deposit hands the matrix back zeroed; a fresh buffer or a failed call does not)
-    CK(hipMemsetAsync(h->d_bits, 0, h->bits_words * h->RC * sizeof(unsigned long long), h->stream));
-  h->bits_clean = false;
-  CK(hipMemsetAsync(h->d_dep, 0, sizeof(double) * words * 64, h->stream));
-  hipLaunchKernelGGL(k_visit_bits, dim3(n), dim3(64), 0, h->stream, n, path_cap, d_cells, d_len, d_plen, h->mp.Q, h->d_bits, h->RC, h->d_dep);
-  CK(hipGetLastError());
   h->dep_words = (int)words; h->dep_done = 0;
   return 0;
+}
+// MAACO.py:304-332 in one pass (evaporate, ordered deposits, clip) for the paths of one batch: the single-GPU form of
+// pf_maaco_evaporate + pf_maaco_deposit + pf_maaco_clip (the sharded fold keeps those: rank 0 alone evaporates).
+int pf_maaco_update(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_cells, const int32_t* d_len, const double* d_plen,
+                    double best_len_overall) {
+  if (!h || !h->maaco_ready) return failmsg(h, "pf_maaco_update: setup first");
+  if (n < 0 || (n > 0 && (!d_cells || !d_len || !d_plen))) return failmsg(h, "pf_maaco_update: bad arguments");
+  if (pf_maaco_deposit_begin(h, n, path_cap, d_cells, d_len, d_plen)) return -1;
+  double bl = best_len_overall;                                     // MAACO.py:312-316
+  if (bl == INFINITY) bl = (double)(h->R + h->C);
+  if (bl < 1e-6) bl = 1e-6;
+  const double tmax = (1.0 / (1.0 - h->mp.rho)) * (1.0 / bl);       // :317
+  int mx = h->C > h->R ? h->C : h->R; if (mx < 1) mx = 1;
+  const double tmin = tmax / (2.0 * mx);                            // :323
+  CK(hipFuncSetAttribute((const void*)k_tau_update, hipFuncAttributeMaxDynamicSharedMemorySize, PF_DEP_CHUNK * (int)sizeof(double)));
+  hipLaunchKernelGGL(k_tau_update, dim3((h->RC + 1023) / 1024), dim3(1024), PF_DEP_CHUNK * sizeof(double), h->stream, h->d_tau, h->d_occ,
+                     h->RC, h->d_bits, h->dep_words, h->d_dep, 1.0 - h->mp.rho, (const double*)nullptr, tmin, tmax);
+  CK(hipGetLastError());
+  if (h->dep_words) h->bits_clean = true;
+  h->dep_words = 0;
+  return maaco_refresh_taua(h);
 }
 int pf_maaco_deposit_cells(pf_handle* h, int32_t cell0, int32_t cell1) {
   if (!h || !h->maaco_ready) return failmsg(h, "pf_maaco_deposit_cells: setup first");

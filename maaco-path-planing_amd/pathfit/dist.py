@@ -354,6 +354,8 @@ class ShardedMAACO:
     def step(self, iter_num):
         m, c, e = self.local, self.comm, self.local.engine
         n = self.a1 - self.a0
+        if c.world == 1 and not c.loopback and hasattr(m, "iterate_dev"):
+            return m.iterate_dev(iter_num, self.a0, n)                  # one GPU: the whole iteration in one enqueue (no exchange)
         m.walk_iteration_dev(iter_num, self.a0, n)
         dc, dl, dp, dt, ds = m.walk_bufs()
         c.all_gather(dp, 0, self._allp, self.counts)                     # C2: 12 B per ant
@@ -392,6 +394,9 @@ class ShardedMAACO:
         dc, dl, dp = m.walk_bufs()[:3]
         tau = e.tau_buf
         RC = m.rows * m.cols
+        if c.world == 1 and hasattr(e, "maaco_update"):
+            e.maaco_update(n, m.path_cap, dc, dl, dp, m.best_path_length_overall)   # evaporate + ordered deposits + clip in one pass
+            return
         if c.world == 1:
             e.maaco_evaporate()
             e.maaco_deposit_begin(n, m.path_cap, dc, dl, dp)

@@ -291,6 +291,20 @@ class Engine:
                                             d_len.ptr, d_plen.ptr, d_turns.ptr, d_status.ptr))
         self._logk("maaco_walk")
 
+    def maaco_update(self, n, path_cap, d_cells, d_len, d_plen, best_len_overall):
+        """MAACO.py:304-332 in one pass over tau (evaporate, ordered deposits, clip): the single-GPU form of the three calls below."""
+        self._ck(self.L.pf_maaco_update(self.h, n, path_cap, d_cells.ptr, d_len.ptr, d_plen.ptr, float(best_len_overall)))
+
+    def maaco_iterate(self, it, seed, ant0, n, path_cap, d_cells, d_len, d_plen, d_turns, d_status, best_len, best_turns):
+        """One whole iteration (walks, best scan, take-over test, pheromone update) enqueued back to back; one 104-byte copy back.
+        -> dict(ib_len, ib_turns, ib_idx, took, best_len, best_turns, skipped, overflow_agents)."""
+        out = np.zeros(13)
+        self._ck(self.L.pf_maaco_iterate(self.h, int(it), int(seed), int(ant0), int(n), int(path_cap), d_cells.ptr, d_len.ptr, d_plen.ptr,
+                                         d_turns.ptr, d_status.ptr, float(best_len), float(best_turns), out.ctypes.data))
+        self._logk("maaco_walk")
+        return {"ib_len": float(out[0]), "ib_turns": float(out[1]), "ib_idx": int(out[2]), "took": out[3] != 0.0, "best_len": float(out[4]),
+                "best_turns": float(out[5]), "skipped": out[8] != 0.0, "overflow_agents": int(out[12])}
+
     def maaco_evaporate(self):
         self._ck(self.L.pf_maaco_evaporate(self.h))
 

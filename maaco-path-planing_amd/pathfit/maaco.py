@@ -105,28 +105,36 @@ class MAACO:
         return self.ant_path(0).tolist(), float(plen[0]), int(turns[0])
 
     def update_pheromone(self, n=None):
-        """MAACO.py:304-332 with the walks of the last walk_iteration call."""
+        """MAACO.py:304-332 with the walks of the last walk_iteration call (one pass over tau)."""
         dc, dl, dp = self._bufs[1], self._bufs[2], self._bufs[3]
         n = self._bufs[0][0] if n is None else n
-        e = self.engine
-        e.maaco_evaporate()
-        e.maaco_deposit(n, self.path_cap, dc, dl, dp)
-        e.maaco_clip(self.best_path_length_overall)
+        self.engine.maaco_update(n, self.path_cap, dc, dl, dp, self.best_path_length_overall)
+
+    def iterate_dev(self, iter_num, ant0=0, n=None):
+        """One iteration of solve_path_planning (MAACO.py:340-359) for ants [ant0, ant0 + n), everything enqueued back to back on
+        the device -- walks, best-of-iteration scan, take-over test (:351-358), one-pass pheromone update -- with ONE 104-byte
+        copy back (the path row of a new overall best follows only when there is one).  -> ib_len."""
+        n = self.num_ants if n is None else n
+        while True:
+            dc, dl, dp, dt, ds = self._alloc(n)
+            r = self.engine.maaco_iterate(iter_num, self.seed, ant0, n, self.path_cap, dc, dl, dp, dt, ds,
+                                          self.best_path_length_overall, self.best_path_turns_overall)
+            if r["overflow_agents"] and self.path_cap < self.rows * self.cols:
+                self.path_cap = min(self.rows * self.cols, self.path_cap * 4)     # path rows too small: redo (tau was left untouched)
+                continue
+            if r["overflow_agents"]:
+                raise RuntimeError("pathfit: path capacity overflow in a MAACO walk")
+            break
+        if r["took"] and r["ib_idx"] >= 0:
+            self.best_path_length_overall = r["best_len"]
+            self.best_path_overall = self.ant_path(r["ib_idx"]).tolist()
+            self.best_path_turns_overall = int(r["best_turns"]) if r["best_turns"] != INF else INF
+        self.convergence_curve_data.append(self.best_path_length_overall if self.best_path_length_overall != INF else None)
+        return r["ib_len"]
 
     def solve_path_planning(self):
         for iter_num in range(1, self.num_iterations + 1):
-            n = self.walk_iteration_dev(iter_num)
-            # MAACO.py:343-349 best-of-iteration scan, on the device columns (24 bytes come back)
-            ib_len, ib_turns, ib_idx = self.engine.maaco_best_dev(n, self._bufs[3], self._bufs[4])
-            if ib_len < self.best_path_length_overall:                                   # :351-354
-                self.best_path_length_overall = ib_len
-                self.best_path_overall = self.ant_path(ib_idx).tolist()
-                self.best_path_turns_overall = int(ib_turns)
-            elif abs(ib_len - self.best_path_length_overall) < 1e-9 and ib_turns < self.best_path_turns_overall:   # :355-358
-                self.best_path_overall = self.ant_path(ib_idx).tolist()
-                self.best_path_turns_overall = int(ib_turns)
-            self.update_pheromone()                                                       # :359
-            self.convergence_curve_data.append(self.best_path_length_overall if self.best_path_length_overall != INF else None)
+            ib_len = self.iterate_dev(iter_num)                                          # MAACO.py:340-359
             if self.verbose and (iter_num % 10 == 0 or iter_num == 1 or iter_num == self.num_iterations):
                 print(f"MAACO Iter {iter_num}/{self.num_iterations}: Iter Best L={ib_len:.2f}, "
                       f"Overall Best L={self.best_path_length_overall:.2f}, T={self.best_path_turns_overall}")
