@@ -141,6 +141,36 @@ __global__ void k_grid_prep(const uint8_t* occ, int R, int C, uint8_t* mm_r1, ui
   d2near[cell] = (uint8_t)best;
 }
 
+// Exact squared distance to the nearest obstacle within a window of radius W, for any W (helper.py:67-80 accepts any
+// min_safe_distance): two separable integer passes.  Rows: the distance to the nearest obstacle in the same row (|dc| <= W,
+// else BIG); columns: d2[r][c] = min over |dr| <= W of dr^2 + g[r + dr][c]^2.  Every obstacle at Euclidean distance <= W lies
+// inside both windows, so every d2 <= W^2 is exact; cells with nothing that close hold `cap`.
+#define PF_EDT_BIG 0x3FFFFFFF
+__global__ void k_edt_rows(const uint8_t* occ, int R, int C, int W, int* g) {
+  const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= R * C) return;
+  const int r = cell / C, c = cell - r * C;
+  int best = PF_EDT_BIG;
+  for (int d = 0; d <= W && best == PF_EDT_BIG; ++d) {
+    if ((c - d >= 0 && occ[r * C + c - d] == 1) || (c + d < C && occ[r * C + c + d] == 1)) best = d;
+  }
+  g[cell] = best;
+}
+__global__ void k_edt_cols(const int* g, int R, int C, int W, int cap, int* d2) {
+  const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= R * C) return;
+  const int r = cell / C, c = cell - r * C;
+  long best = cap;
+  const int r0 = r - W < 0 ? 0 : r - W, r1 = r + W > R - 1 ? R - 1 : r + W;
+  for (int rr = r0; rr <= r1; ++rr) {
+    const int gv = g[rr * C + c];
+    if (gv == PF_EDT_BIG) continue;
+    const long v = (long)(rr - r) * (rr - r) + (long)gv * gv;
+    best = v < best ? v : best;
+  }
+  d2[cell] = (int)best;
+}
+
 // search scratch initialisation: every record carries its cell's static move mask
 __global__ void k_slot_init(Rec* rec, const uint8_t* mm, int RC, size_t total) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1830,6 +1860,7 @@ struct pf_handle {
   pf_counters last = {};
   double* d_pen = nullptr;
   double pen_min_safe = -1.0;
+  int* d_d2wide = nullptr; int wide_W = 0; double* d_penw = nullptr; int penw_n = 0; double penw_min_safe = -1.0;   // min_safe_distance > 15.9
   int edt_radius = 7;      // radius of the obstacle-distance window d2near was built with
   double obst_frac = -1.0; // share of obstacle cells (lazy; picks the plateau kernels on open maps)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -2006,7 +2037,7 @@ void pf_destroy(pf_handle* h) {
   if (h->comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(h->stream); g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
   void* ptrs[] = {h->d_occ, h->d_mm_r1, h->d_mm_r0, h->d_mm_r1_nd, h->d_mm_r0_nd, h->d_d2near, h->d_rec, h->d_slot_state,
                   h->d_work, h->d_cnt, h->d_pen, h->d_tier2, h->d_tau, h->d_taua, h->d_eta, h->d_dep, h->d_tep, h->d_visit, h->d_visit_epoch,
-                  h->d_bits, h->d_mstate, h->d_tmp, h->d_elite_stats, h->d_init_cells, h->d_init_stats, h->d_est, h->d_est2, h->d_iota, h->d_queue, h->d_sort_tmp, h->d_jobs, h->d_jres, h->d_prop, h->d_doubt, h->d_scan, h->d_scan3, h->d_okey, h->d_okey2, h->d_oval2, h->d_elite_cells, h->d_elite_len, h->d_ga_pool, h->d_st_lab, h->d_st_touched, h->d_st_par, h->d_st_epoch,
+                  h->d_bits, h->d_mstate, h->d_d2wide, h->d_penw, h->d_tmp, h->d_elite_stats, h->d_init_cells, h->d_init_stats, h->d_est, h->d_est2, h->d_iota, h->d_queue, h->d_sort_tmp, h->d_jobs, h->d_jres, h->d_prop, h->d_doubt, h->d_scan, h->d_scan3, h->d_okey, h->d_okey2, h->d_oval2, h->d_elite_cells, h->d_elite_len, h->d_ga_pool, h->d_st_lab, h->d_st_touched, h->d_st_par, h->d_st_epoch,
                   h->d_comp[0], h->d_comp[1], h->d_comp[2], h->d_comp[3], h->d_ds, h->d_dt};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -2032,6 +2063,7 @@ int pf_update_grid(pf_handle* h, const uint8_t* grid) {
   CK(hipStreamSynchronize(h->stream));
   for (int k = 0; k < 4; ++k) if (h->d_comp[k]) { (void)hipFree(h->d_comp[k]); h->d_comp[k] = nullptr; }
   h->rec_policy = -1;                                               // the records embed the old move masks
+  h->wide_W = 0;                                                    // the wide distance table belongs to the old map
   h->obst_frac = -1.0;
   h->mpa_ready = false; h->maaco_ready = false;                     // their tables (initial path, bounds, tau / eta) belong to the old map
   if (h->d_ds) { (void)hipFree(h->d_ds); h->d_ds = nullptr; }
@@ -2187,7 +2219,38 @@ static int launch_with_retry(pf_handle* h, Kern kern, KArgs& args, int n, bool t
 }
 
 static int ensure_pen(pf_handle* h, double min_safe) {
-  if (min_safe > 15.9) return failmsg(h, "min_safe_distance > 15.9 is not supported (squared obstacle distances are kept in a u8 table)");
+  if (!(min_safe <= 15.9)) {
+    // wide mode: helper.py:67-80 takes any min_safe_distance.  Exact i32 squared distances in a window of radius
+    // W = ceil(min_safe) (device EDT), penalty LUT over d2 = 0 .. W^2 + 1 built with the host's libm like the small one.
+    if (!(min_safe < 1e9)) return failmsg(h, "min_safe_distance must be finite");
+    CK(hipSetDevice(h->device));
+    int W = (int)ceil(min_safe); const int mx = h->R > h->C ? h->R : h->C; if (W > mx) W = mx;
+    if (h->wide_W != W) {
+      if (!h->d_d2wide) CK(hipMalloc(&h->d_d2wide, sizeof(int) * (size_t)h->RC));
+      int* g = nullptr; CK(hipMalloc(&g, sizeof(int) * (size_t)h->RC));
+      const int nb = (h->RC + 255) / 256;
+      k_edt_rows<<<nb, 256, 0, h->stream>>>(h->d_occ, h->R, h->C, W, g);
+      k_edt_cols<<<nb, 256, 0, h->stream>>>(g, h->R, h->C, W, W * W + 1, h->d_d2wide);
+      CK(hipGetLastError());
+      CK(hipStreamSynchronize(h->stream));
+      CK(hipFree(g));
+      h->wide_W = W; h->penw_min_safe = -1.0;
+    }
+    if (h->penw_min_safe != min_safe) {
+      const int n = W * W + 2;
+      std::vector<double> pen((size_t)n);
+      for (int d2 = 0; d2 < n; ++d2) {
+        const double d = sqrt((double)d2);                         // helper.py:76
+        pen[d2] = (d2 <= W * W && d < min_safe) ? pow(min_safe - d, 2.0) : 0.0;   // helper.py:77-78 (float ** 2 -> libm pow)
+      }
+      if (h->d_penw) CK(hipFree(h->d_penw));
+      CK(hipMalloc(&h->d_penw, sizeof(double) * (size_t)n));
+      CK(hipMemcpyAsync(h->d_penw, pen.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+      CK(hipStreamSynchronize(h->stream));
+      h->penw_n = n; h->penw_min_safe = min_safe;
+    }
+    return 0;
+  }
   if (min_safe > (double)h->edt_radius) {                           // widen the obstacle-distance window once (K0 again, radius 15)
     CK(hipSetDevice(h->device));
     k_grid_prep<<<(h->RC + 255) / 256, 256, 0, h->stream>>>(h->d_occ, h->R, h->C, h->d_mm_r1, h->d_mm_r0, h->d_d2near, 15);
@@ -2209,7 +2272,8 @@ static int make_scorep(pf_handle* h, const pf_score_params* sp, ScoreP* out) {
   if (sp->variant == 0) { if (ensure_pen(h, sp->min_safe)) return -1; }
   else if (h->pen_min_safe < 0) { if (ensure_pen(h, 0.0)) return -1; }
   out->variant = sp->variant; out->restrict_policy = sp->restrict_policy; out->w_turn = sp->w_turn; out->w_safe = sp->w_safe;
-  out->diag_pen = sp->diag_pen; out->pen = h->d_pen;
+  out->diag_pen = sp->diag_pen; out->pen = h->d_pen; out->d2w = nullptr; out->pen_n = 256;
+  if (sp->variant == 0 && !(sp->min_safe <= 15.9)) { out->pen = h->d_penw; out->d2w = h->d_d2wide; out->pen_n = h->penw_n; }
   return 0;
 }
 

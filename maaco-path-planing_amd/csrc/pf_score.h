@@ -8,7 +8,8 @@
 // cuts / the obstacle-distance lookup are lane-parallel.  The O(L * n_obst)
 // numpy scan of helper.py:67-80 is replaced by one byte lookup per cell into
 // d2near (K0) + a penalty LUT built on the host with libm pow (bit-equal, see
-// oracle safety_window).
+// oracle safety_window); for min_safe_distance > 15.9 the byte table is replaced by an exact
+// i32 squared-distance transform of the same window (k_edt_rows / k_edt_cols).
 #pragma once
 #include "pf_device.h"
 
@@ -17,7 +18,9 @@ namespace pf {
 struct ScoreP {
   int variant, restrict_policy;
   double w_turn, w_safe, diag_pen;
-  const double* pen;  // [256] penalty by clipped squared distance (device, read-only)
+  const double* pen;  // [256] penalty by clipped squared distance (device, read-only) -- or [pen_n] in wide mode
+  const int* d2w;     // wide mode (min_safe_distance > 15.9): exact squared distance to the nearest obstacle per cell, clipped at
+  int pen_n;          // pen_n - 1 (device EDT, two separable i32 passes); null: the u8 table G.d2near
 };
 
 // out: uniform {length, turns, safety, diag, fitness}
@@ -48,7 +51,10 @@ PF_DEV void score_path(const Grid& G, const ScoreP& P, const int* cells, int L, 
     }
     const bool turn = v2 && (dr != r2 - r1 || dc != c2 - c1);        // helper.py:58-65
     double pen = 0.0;
-    if (P.variant == 0 && v0) pen = P.pen[G.d2near[cell0]];
+    if (P.variant == 0 && v0) {
+      if (P.d2w) { const int d2 = P.d2w[cell0]; pen = P.pen[d2 < P.pen_n - 1 ? d2 : P.pen_n - 1]; }
+      else pen = P.pen[G.d2near[cell0]];
+    }
     turns += __builtin_popcountll(__ballot(turn));
     ncut += __builtin_popcountll(__ballot(cut));
     // serial fp64 chains, in path order

@@ -547,6 +547,9 @@ class PSOSolver(_WaypointSolver):
         # asynchronous=True reproduces pso.py:222-229 exactly (a particle sees the gbest updated by the particles
         # before it in the same sweep) by speculate-and-repair; False = one batch per sweep (sweep-start gbest)
         self.asynchronous = bool(asynchronous)
+        # asynchronous mode speculates on ALL particles not yet final in one batch; a bound (particles per round) changes how
+        # much is speculated, never the result (tests/test_gpu_fullsize.py checks exactly that at 2048 particles)
+        self.max_speculation = None
 
     def _reconstruct_path_from_position(self, position_waypoints_float):
         """pso.py:56-94 for one particle."""
@@ -733,7 +736,8 @@ class PSOSolver(_WaypointSolver):
         cur = 0                                                            # global index of the first particle not yet final
         while cur < N:
             a0 = max(lo, cur)                                              # my particles [a0, hi) are evaluated this round
-            m = max(hi - a0, 0)
+            top = hi if not (self.asynchronous and self.max_speculation) else min(hi, cur + int(self.max_speculation))
+            m = max(top - a0, 0)
             idx, fit = -1, INF
             if m:
                 l0 = a0 - lo
@@ -759,7 +763,8 @@ class PSOSolver(_WaypointSolver):
                 f_star = float(allv[r_star, 1])
             else:
                 r_star, p_star, f_star = rank, mine, fit
-            upto = (p_star if p_star >= 0 else N - 1) if self.asynchronous else N - 1   # last particle whose evaluation is final
+            last_eval = N - 1 if not (self.asynchronous and self.max_speculation) else min(N, cur + int(self.max_speculation)) - 1
+            upto = (p_star if p_star >= 0 else last_eval) if self.asynchronous else N - 1   # last particle whose evaluation is final
             k = min(upto, hi - 1) - a0 + 1                                 # my evaluated particles that are final now
             if m and k > 0:
                 l0 = a0 - lo
@@ -782,10 +787,10 @@ class PSOSolver(_WaypointSolver):
                     c.broadcast(d["gb"], 0, W * 2, r_star)                 # the new gbest position: W x 16 B
                 self._gowner = r_star
                 gfit = f_star
-            if m and upto < hi - 1:                                        # roll back my not yet final particles
+            if m and upto < top - 1:                                       # roll back my evaluated but not yet final particles
                 r0 = max(upto + 1, a0) - lo
-                e.d2d(d["pos"].at(r0 * W * 2), d["pos0"].at(r0 * W * 2), (hi - lo - r0) * st_sz)
-                e.d2d(d["vel"].at(r0 * W * 2), d["vel0"].at(r0 * W * 2), (hi - lo - r0) * st_sz)
+                e.d2d(d["pos"].at(r0 * W * 2), d["pos0"].at(r0 * W * 2), (top - lo - r0) * st_sz)
+                e.d2d(d["vel"].at(r0 * W * 2), d["vel0"].at(r0 * W * 2), (top - lo - r0) * st_sz)
             cur = upto + 1
         self._particles_stale = True
         self._it += 1

@@ -232,8 +232,9 @@ def test_two_ranks_equal_one(tmp_path, what):
 
 def test_wide_safety_windows_and_dynamic_maps():
     """helper.calculate_path_safety_penalty (helper.py:67-80) accepts any min_safe_distance -- the device
-    window widens to radius 15 on demand (up to 15.9; beyond that the call fails loudly) -- and a handle's map can be
-    replaced in place (pf_update_grid re-runs the grid preparation on the device)."""
+    byte window widens to radius 15 on demand (up to 15.9); beyond that an exact i32 squared-distance transform of the
+    needed radius is built on the device (two separable passes) -- and a handle's map can be replaced in place
+    (pf_update_grid re-runs the grid preparation on the device)."""
     import pathfit, pf_oracle as po
     from pathfit.engine import score_params, PathfitError
     g, s, t = gio.grid("g256")
@@ -242,12 +243,14 @@ def test_wide_safety_windows_and_dynamic_maps():
     free = np.flatnonzero(g.reshape(-1) != 1)
     paths = [o.astar(int(a), int(b), None, 0)[0] for a, b in zip(rnd.choice(free, 12), rnd.choice(free, 12))]
     paths = [p for p in paths if len(p) > 1]
-    for ms in (1.8, 3.2, 7.0, 7.5, 9.25, 15.9):
+    for ms in (1.8, 3.2, 7.0, 7.5, 9.25, 15.9, 16.5, 20.0, 40.0, 20.0, 300.0, 9.25):
         got = e.score_host(paths, score_params(0, True, 0.3, 0.8, ms, 100.0))
         for p, row in zip(paths, got):
             assert np.array_equal(row, o.score(p, 0, 0.3, 0.8, ms, True, 100.0)), ms
+    for p, row in zip(paths[:3], e.score_host(paths[:3], score_params(0, True, 0.3, 0.8, 40.0, 100.0))):
+        assert np.array_equal(row, o.score(p, 0, 0.3, 0.8, 40.0, True, 100.0, literal_safety=True))      # the O(L * n_obst) scan itself
     with pytest.raises(PathfitError):
-        e.score_host(paths, score_params(0, True, 0.3, 0.8, 16.5, 100.0))
+        e.score_host(paths, score_params(0, True, 0.3, 0.8, float("inf"), 100.0))
     # a new map in the same handle: searches and scores follow it
     g2 = g.copy(); g2[g2 > 1] = 0
     g2[100:140, 60:200] = 1; g2[0, 0] = 2; g2[-1, -1] = 3
@@ -260,9 +263,10 @@ def test_wide_safety_windows_and_dynamic_maps():
         for i in range(16):
             assert np.array_equal(got[i], o2.astar(int(st_[i]), int(tg_[i]), None, variant)[0]), (variant, i)
     p2 = [p for p in got if len(p) > 1]
-    sc = e.score_host(p2, score_params(0, True, 0.3, 0.8, 9.25, 100.0))
-    for p, row in zip(p2, sc):
-        assert np.array_equal(row, o2.score(p, 0, 0.3, 0.8, 9.25, True, 100.0))
+    for ms in (9.25, 25.0):
+        sc = e.score_host(p2, score_params(0, True, 0.3, 0.8, ms, 100.0))
+        for p, row in zip(p2, sc):
+            assert np.array_equal(row, o2.score(p, 0, 0.3, 0.8, ms, True, 100.0))
 
 
 def test_sharded_solvers_over_rccl_loopback():

@@ -123,6 +123,72 @@ def test_cfg4_ga_pso_2048_per_gpu_512():
     assert all(np.array_equal(a, b) for a, b in zip(paths, paths2)) and np.array_equal(stats, stats2)
 
 
+def test_cfg4_solver_loops_2048_agents_512():
+    """BASELINE.json configs[3] per-GPU share through the SOLVER LOOPS (not only the decode kernel): PSOSolver with 2048
+    particles, two asynchronous sweeps, and one GASolver generation of 2048 individuals, on G512.  Properties: legal paths,
+    stored stats == independent recomputation, pbest monotone, gbest == the first minimum of pbest, the speculate-and-repair
+    rounds are invariant under the amount of speculation, the GA population is sorted and never loses its best."""
+    import pathfit
+    from pathfit import env
+    g = env.bench_grid(512)
+    S, T = 0, 512 * 512 - 1
+    kw = dict(turn_penalty_factor=0.3, safety_penalty_factor=0.8, min_safe_distance=1.8, diagonal_obstacle_penalty_value=100.0)
+    N, W = 2048, 5
+    runs = []
+    for spec in (None, 300):
+        e = pathfit.Engine(g)
+        ps = pathfit.PSOSolver(g, num_iterations=2, num_particles=N, num_waypoints_per_particle=W, w=0.7, c1=1.5, c2=1.5, engine=e,
+                               seed=9, asynchronous=True, **kw)
+        ps.max_speculation = spec
+        assert ps.begin()
+        pbf = [ps._d["pbf"].download().copy()]
+        for _ in range(2):
+            gf = ps.sweep()
+            pbf.append(ps._d["pbf"].download().copy())
+            assert (pbf[-1] <= pbf[-2]).all()                                   # pso.py:216 strict improvement only
+            assert gf == pbf[-1].min() == ps.convergence_curve[-1]              # pso.py:222-229
+        d = ps._d
+        cells, lens, stats = d["cells"].download(), d["len"].download(), d["stats"].download()
+        pbc, pbl = d["pb_cells"].download(), d["pb_len"].download()
+        res = ps.finish()
+        g_idx = int(np.argmin(pbf[-1]))                                         # first minimum
+        assert res[5] == pbf[-1][g_idx]
+        if spec is None:
+            for a, (L, Tn) in check_paths(g, cells, lens, S, T, sample=48).items():
+                assert stats[a, 0] == L and stats[a, 1] == Tn
+            check_paths(g, pbc, pbl, S, T, sample=48)
+            assert (lens > 0).sum() > N // 10                           # (a waypoint on an obstacle makes a particle infeasible, pso.py:77: ~20 % survive)
+        runs.append((pbf[-1], d["pos"].download(), d["vel"].download(), d["pb"].download(), list(ps.convergence_curve), list(res[0]), res[5]))
+        e.close()
+    a, b = runs
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    assert a[4] == b[4] and a[5] == b[5] and a[6] == b[6]
+
+    e = pathfit.Engine(g)
+    ga = pathfit.GASolver(g, num_generations=1, population_size=N, num_waypoints_per_chromosome=W, mutation_rate=0.1, crossover_rate=0.8,
+                          engine=e, seed=5, **kw)
+    res = ga.solve()
+    pop = ga.population
+    assert len(pop) == N
+    fit = np.array([p["fitness"] for p in pop])
+    assert (np.diff(fit) >= 0).all() and res[5] == fit[0] <= ga.convergence_curve[0]      # ga_solver.py:209-213
+    C_ = 512
+    for i in np.linspace(0, N - 1, 40).astype(int):
+        p = pop[i]
+        cp = np.array(p["path"].cells if hasattr(p["path"], "cells") else [r * C_ + c for r, c in p["path"]], np.int32)
+        if np.isinf(p["fitness"]):
+            assert cp.size == 0
+            continue
+        got = check_paths(g, cp[None, :], np.array([cp.size]), S, T)
+        assert got[0] == (p["length"], p["turns"])
+        at = 0                                              # ga_solver.py:58-93: the waypoints are visited in order (a waypoint may
+        for r, c in p["chromosome"]:                        # also be crossed earlier: the segment's goal is exempt from the avoid set)
+            hits = np.flatnonzero(cp[at:] == r * C_ + c)
+            assert hits.size, (i, r, c)
+            at += int(hits[0])
+    e.close()
+
+
 def test_cfg5_maaco_and_astar_8192_per_gpu_1024():
     import pathfit
     from pathfit import env
