@@ -330,18 +330,19 @@ def main():
     ap.add_argument("--agents", type=int, default=0, help="agents per GPU (default: the config's)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline sample")
+    ap.add_argument("--extra-cpu-seconds", type=float, default=2.0, help="budget of each extra workload's cpu_baseline legs")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="headline only (default at N>1 and for non-default workloads)")
     ap.add_argument("--phase1-only", action="store_true", help="mpa512: the round-1 protocol (every step a phase-1 iteration)")
     ap.add_argument("--pso-sync", action="store_true", help="pso512: one batch per sweep (sweep-start gbest) instead of the exact asynchronous mode")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + PF_BENCH_SHARE_GPU=1 rehearses N ranks on one GPU (exchange logic only)")
-    ap.add_argument("--cpu-worker", default="", help=argparse.SUPPRESS)   # internal: "lo:hi" slice for the all-cores CPU leg
+    ap.add_argument("--cpu-worker", default="", help=argparse.SUPPRESS)   # internal: "workload:lo:hi" slice for the all-cores CPU leg
     a = ap.parse_args()
     if a.cpu_worker:                                                       # a child of cpu_baseline(): no GPU, no torch
-        lo, hi = (int(x) for x in a.cpu_worker.split(":"))
+        wl, lo, hi = a.cpu_worker.split(":")
         from pathfit import env as env_
-        print(json.dumps(_mpa_cpu_slice(env_.bench_grid(512), a.seed, lo, hi, a.cpu_seconds)), flush=True)
+        print(json.dumps(_cpu_slice(wl, env_.bench_grid(gsize_of(wl)), a.seed, int(lo), int(hi), a.cpu_seconds)), flush=True)
         return
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:                      # not under torchrun: start the N ranks ourselves
         rc, line = launch_ranks(a.gpus, sys.argv[1:])
@@ -447,6 +448,8 @@ def main():
                                "roofline": roof2, "config": r2.cfg}
                 r2 = None
                 e2.close()
+                if not a.no_cpu:                        # the CPU side of every workload, 1 core and all cores, ~2 s each
+                    extra[name]["cpu_baseline"] = cpu_baseline(name, env.bench_grid(gsize_of(name)), a.seed, a.extra_cpu_seconds)
             except Exception as ex:                     # an extra must never cost the headline
                 extra[name] = {"error": repr(ex)[:300]}
 
@@ -464,57 +467,31 @@ def main():
         dist.destroy_process_group()
 
 
-def _mpa_cpu_slice(grid, seed, lo, hi, budget_s):
-    """Predators [lo, hi) of MPA iteration 1 on the CPU oracle, at most budget_s seconds -> (count, seconds)."""
-    import pf_oracle as po
-    import pf_loops
-    orc = po.Oracle(grid)
-    ref = pf_loops.MpaOracle(orc, 0, grid.size - 1, 4096, 15, FADs_rate=0.2, P_const=0.5, levy_beta=2.0, w_turn=0.1, w_safe=0.8,
-                             min_safe=1.8, diag_pen=100.0, seed=seed)
-    ref._sort()
-    elite = ref.pop[0]
-    CF = (1.0 - 1 / 15) ** (2.0 / 15)
-    t0 = time.perf_counter()
-    n = lo
-    while time.perf_counter() - t0 < budget_s and n < hi:
-        cand = ref.phase_candidate(1, n, elite, CF)
-        ind = cand if cand[1][4] < ref.pop[n][1][4] else ref.pop[n]
-        ref.fads(1, n, ind, CF)
-        n += 1
-    return {"count": n - lo, "seconds": time.perf_counter() - t0}
+CPU_TOTAL = {"mpa512": 4096, "maaco128": 256, "maaco512": 16384, "maaco1024": 8192, "astar1024": 8192, "ga512": 2048, "pso512": 2048}
 
 
-def _mpa_cpu_all_cores(seed, budget_s):
-    """The same sample spread over every host core this process may use: one child process per core (fresh
-    interpreters, no GPU), each taking a contiguous slice of the 4096 predators."""
-    import subprocess
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, 16))                  # a one-GPU box's CPU share
-    per = -(-4096 // cores)
-    procs = []
-    for k in range(cores):
-        lo, hi = k * per, min(4096, (k + 1) * per)
-        if lo >= hi:
-            break
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", f"{lo}:{hi}", "--seed", str(seed),
-                                       "--cpu-seconds", str(budget_s)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
-    tot, secs = 0, 0.0
-    for pr in procs:
-        out, _ = pr.communicate(timeout=budget_s * 4 + 120)
-        r = json.loads(out.strip().splitlines()[-1])
-        tot += r["count"]; secs = max(secs, r["seconds"])
-    return {"value": round(tot / secs, 3), "cores": len(procs), "sample": f"{tot} predators of iteration 1 in {len(procs)} processes"}
+def cpu_info():
+    """CPU model string (/proc/cpuinfo), hardware concurrency and the cores this process may use."""
+    model = None
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return {"model": model, "hardware_concurrency": os.cpu_count(), "usable_cores": usable}
 
 
-def cpu_baseline(workload, grid, seed, budget_s):
-    """Time the CPU oracle (the C port of the reference's algorithm; checker code, kind 'port') on a bounded
-    sample of the SAME workload, single thread (mpa512: also on all host cores)."""
+def _cpu_slice(workload, grid, seed, lo, hi, budget_s):
+    """Agents [lo, hi) of the workload's first step on the CPU oracle (the C port of the reference's algorithm; checker
+    code), at most budget_s seconds -> {count, seconds, what}."""
     import pf_oracle as po
     import pf_loops
     orc = po.Oracle(grid)
     s, t = 0, grid.size - 1
-    t0 = time.perf_counter()
-    n = 0
+    n = lo
     if workload == "mpa512":
         ref = pf_loops.MpaOracle(orc, s, t, 4096, 15, FADs_rate=0.2, P_const=0.5, levy_beta=2.0, w_turn=0.1, w_safe=0.8,
                                  min_safe=1.8, diag_pen=100.0, seed=seed)
@@ -522,46 +499,74 @@ def cpu_baseline(workload, grid, seed, budget_s):
         elite = ref.pop[0]
         CF = (1.0 - 1 / 15) ** (2.0 / 15)
         t0 = time.perf_counter()
-        while time.perf_counter() - t0 < budget_s and n < 4096:
+        while time.perf_counter() - t0 < budget_s and n < hi:
             cand = ref.phase_candidate(1, n, elite, CF)
             ind = cand if cand[1][4] < ref.pop[n][1][4] else ref.pop[n]
             ref.fads(1, n, ind, CF)
             n += 1
-        sample = f"first {n} predators of iteration 1 (phase sweep + memory + FADs), same grid/params/seed"
+        what = "predators of iteration 1 (phase sweep + memory + FADs)"
     elif workload.startswith("maaco"):
         P = po.MaacoParams(alpha=1.0, beta=7.0, rho=0.1, Q=2.5, a_turn=1.0, wh_max=0.9, wh_min=0.2, k_h=0.9, q0_initial=0.5,
                            C0=0.1, num_iterations=100)
         tau, dist = orc.maaco_init(s, t, 0.1)
         t0 = time.perf_counter()
-        while time.perf_counter() - t0 < budget_s and n < 16384:
+        while time.perf_counter() - t0 < budget_s and n < hi:
             orc.maaco_walk(s, t, P, tau, dist, 1, seed, n)
             n += 1
-        sample = f"first {n} ant walks of iteration 1, same grid/params/seed"
+        what = "ant walks of iteration 1"
     elif workload == "astar1024":
         rng = np.random.default_rng(seed)
         free = np.flatnonzero(grid.reshape(-1) != 1)
         ss, tt = rng.choice(free, 8192), rng.choice(free, 8192)
         t0 = time.perf_counter()
-        while time.perf_counter() - t0 < budget_s and n < 8192:
+        while time.perf_counter() - t0 < budget_s and n < hi:
             orc.astar(int(ss[n]), int(tt[n]), None, 0)
             n += 1
-        sample = f"first {n} pairs (AStarSolver connector), same grid and seed"
+        what = "pairs (AStarSolver connector)"
     else:
         rng = np.random.default_rng(seed)
         free = np.flatnonzero(grid.reshape(-1) != 1)
         wp = rng.choice(free, (2048, 5)).astype(np.int32)
         t0 = time.perf_counter()
-        while time.perf_counter() - t0 < budget_s and n < 2048:
+        while time.perf_counter() - t0 < budget_s and n < hi:
             p, _ = orc.decode(s, t, wp[n])
             orc.score(p, 0, 0.3, 0.8, 1.8, True, 100.0)
             n += 1
-        sample = f"first {n} chromosomes (W=5 decode + score), same grid and seed"
-    dt = time.perf_counter() - t0
-    out = {"value": round(n / dt, 3), "unit": "evals/s", "cores": 1, "kind": "port", "sample": sample,
-           "seconds": round(dt, 2)}
-    if workload == "mpa512":
+        what = "chromosomes (W=5 decode + score)"
+    return {"count": n - lo, "seconds": time.perf_counter() - t0, "what": what}
+
+
+def _cpu_all_cores(workload, seed, budget_s):
+    """The same sample spread over every host core this process may use: one child process per core (fresh
+    interpreters, no GPU), each taking a contiguous slice of the workload's agents."""
+    import subprocess
+    cores = max(1, min(cpu_info()["usable_cores"], 16))   # a one-GPU box's CPU share
+    total = CPU_TOTAL[workload]
+    per = -(-total // cores)
+    procs = []
+    for k in range(cores):
+        lo, hi = k * per, min(total, (k + 1) * per)
+        if lo >= hi:
+            break
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", f"{workload}:{lo}:{hi}", "--seed", str(seed),
+                                       "--cpu-seconds", str(budget_s)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
+    tot, secs = 0, 0.0
+    for pr in procs:
+        out, _ = pr.communicate(timeout=budget_s * 4 + 180)
+        r = json.loads(out.strip().splitlines()[-1])
+        tot += r["count"]; secs = max(secs, r["seconds"])
+    return {"value": round(tot / secs, 3), "cores": len(procs), "sample": f"{tot} agents in {len(procs)} processes"}
+
+
+def cpu_baseline(workload, grid, seed, budget_s, all_cores=True):
+    """Time the CPU oracle (the C port of the reference's algorithm; checker code, kind 'port') on a bounded sample of the
+    SAME workload: single thread and -- SURVEY.md 8d -- on all host cores, with the CPU model and core counts."""
+    r = _cpu_slice(workload, grid, seed, 0, CPU_TOTAL[workload], budget_s)
+    out = {"value": round(r["count"] / r["seconds"], 3), "unit": "evals/s", "cores": 1, "kind": "port",
+           "sample": f"first {r['count']} {r['what']}, same grid/params/seed", "seconds": round(r["seconds"], 2), "cpu": cpu_info()}
+    if all_cores:
         try:
-            out["all_cores"] = _mpa_cpu_all_cores(seed, min(budget_s, 8.0))
+            out["all_cores"] = _cpu_all_cores(workload, seed, min(budget_s, 8.0))
         except Exception as e:                      # the single-core figure stands on its own
             out["all_cores"] = {"error": repr(e)[:200]}
     return out
