@@ -31,6 +31,8 @@ namespace pf {
 #define PF_ST_Q 64.0
 #define PF_ST_NBK 256
 #define PF_LAB_KEYMASK ((1ull << 57) - 1ull)
+#define PF_PAR_IRREG 0x7Fu            /* par[x]: x is irregular (no earlier argmin parent) */
+#define PF_PAR_SEEN 0x80u             /* par[x] bit 7: reached by the ancestor walk of this search */
 
 PF_DEV unsigned long long lab_enc(double g, unsigned code) {
   const unsigned long long b = dbits(g);
@@ -41,6 +43,76 @@ PF_DEV double lab_dec(unsigned long long v) {
   return k ? __builtin_bit_cast(double, k + (1022ull << 52)) : 0.0;
 }
 PF_DEV int opposite_move(int m) { return m < 4 ? (m ^ 1) : 11 - m; }   // helper.py:30-36 order: 0<->1 2<->3 4<->7 5<->6
+
+// Irregular nodes exist.  What the sequential loop does around one differs from the fixpoint only DOWNSTREAM of it: a node
+// all of whose argmin parents (offer == label) behave as in the theorem receives its label from the same parent at the same
+// point of the pop order (every other offer it ever gets is above its label: labels of the sequential loop are never below
+// the fixpoint's), so by induction over the key order the theorem holds on the set of nodes none of whose ancestors in the
+// argmin-parent DAG is irregular.  The goal's path only needs the goal to be in that set: walk the DAG backwards from the
+// goal (g strictly falls along its edges) and hand the search back only if an irregular node is met.  DESIGN.md 4.3.
+// par[x] = move from the smallest-key regular parent (0..7) or PF_PAR_IRREG, bit 7 = reached by this walk.
+// Returns true when no ancestor of the goal is irregular.  noinline + scalar arguments: the walk is cold (2-7 % of the
+// searches), and inlined its mere presence cost the sequential pop loop of the same kernel 15 % (k_decode_batch 108 -> 125 ms
+// with the engine switched off: register allocation / code layout).
+template <int VARIANT>
+__device__ __attribute__((noinline)) bool cone_walk(const uint8_t* gmm, int C, uint64_t magicC, const unsigned long long* lab, unsigned char* par,
+                                                    int* queue, int qcap, int start, int target, int tr, int tc, unsigned code, double F, int lane) {
+  const unsigned long long blocked = (unsigned long long)code << 57;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if ((par[target] & 0x7Fu) == PF_PAR_IRREG) return false;               // the goal itself
+  int qh = 0, qt = 1;
+  if (lane == 0) { queue[0] = target; par[target] |= PF_PAR_SEEN; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  bool tainted = false;
+  while (qh < qt) {
+    const bool in = qh + lane < qt;
+    const int x = in ? queue[qh + lane] : start;
+    qh = qh + 64 < qt ? qh + 64 : qt;
+    const double gx = lab_dec(lab[x]);
+    const int r = (int)(((uint64_t)(uint32_t)x * magicC) >> 40), c = x - r * C;
+    const unsigned mm = (in && x != start) ? gmm[x] : 0u;
+    unsigned long long vp[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { vp[k] = ~0ull; if ((mm >> k) & 1u) vp[k] = lab[x + move_dr(k) * C + move_dc(k)]; }
+    // the eight claims of a node go out together (one memory round trip per round of the walk, not eight)
+    unsigned old8[8]; bool arg8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int p = x + move_dr(k) * C + move_dc(k);
+      const bool live = ((mm >> k) & 1u) && (vp[k] >> 57) == code && (vp[k] != blocked || p == start) && p != target;
+      const double gp = lab_dec(vp[k]);
+      const int pr = r + move_dr(k), pc = c + move_dc(k);
+      long dr_ = pr - tr, dc_ = pc - tc;
+      const double fp_ = VARIANT == 2 ? gp : gp + __builtin_sqrt((double)(dr_ * dr_ + dc_ * dc_));
+      arg8[k] = live && gp + (k < 4 ? 1.0 : PF_SQRT2) == gx && (fp_ < F || fp_ == F) && p != start;   // an expanded argmin parent (earlier or not)
+      old8[k] = 0u;
+      if (arg8[k]) {
+        // claim p: its byte of the aligned word (the other bytes belong to neighbouring cells)
+        const unsigned long long ad = (unsigned long long)(par + p);
+        old8[k] = __hip_atomic_fetch_or((unsigned*)(ad & ~3ull), (unsigned)PF_PAR_SEEN << (8u * (unsigned)(ad & 3ull)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int p = x + move_dr(k) * C + move_dc(k);
+      const unsigned pv = (old8[k] >> (8u * (unsigned)((unsigned long long)(par + p) & 3ull))) & 0xFFu;
+      if (arg8[k] && (pv & 0x7Fu) == PF_PAR_IRREG) tainted = true;    // an irregular ancestor
+      const bool fresh = arg8[k] && !(pv & PF_PAR_SEEN);
+      const unsigned long long fm = __ballot(fresh);
+      if (fm) {
+        const int at = qt + __builtin_popcountll(fm & ((1ull << lane) - 1ull));
+        if (fresh) { if (at < qcap) queue[at] = p; else tainted = true; }
+        qt += __builtin_popcountll(fm);
+      }
+    }
+    if (__ballot(tainted)) return false;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return true;
+}
 
 template <int VARIANT>
 __device__ __forceinline__ int settle(const Grid& G, const Open& O, const SettleMem& M, int start, int target, int tr, int tc,
@@ -190,6 +262,7 @@ __device__ __forceinline__ int settle(const Grid& G, const Open& O, const Settle
   if ((vt >> 57) != code || vt == blocked) return 1;                 // the goal was never reached: astar.py:101 -> []
   F = lab_dec(vt);
   // ---- regularity + parents, one touched node per lane ----
+  // par[x] = the move from its smallest-key regular parent (0..7), or PF_PAR_IRREG when x is irregular
   bool bad = false;
   for (int i0 = 0; i0 < nt; i0 += 64) {
     const bool in = i0 + lane < nt;
@@ -217,9 +290,12 @@ __device__ __forceinline__ int settle(const Grid& G, const Open& O, const Settle
       const bool earlier = arg && (fp_ < F || fp_ == F) && (fp_ < fx || fp_ == fx);   // expanded, and popped before x (g(p) < g(x))
       if (earlier && (best < 0 || key_lt(fp_, gp, p, bf, bg, bc))) { best = k; bf = fp_; bg = gp; bc = p; }
     }
-    if (reg) { if (best < 0) bad = true; else M.par[x] = (unsigned char)opposite_move(best); }
+    if (reg) { if (best < 0) { bad = true; M.par[x] = PF_PAR_IRREG; } else M.par[x] = (unsigned char)opposite_move(best); }
   }
-  if (__ballot(bad)) return PF_ST_SEQ;
+  if (__ballot(bad)) {
+    // Irregular nodes exist: certify the goal's ancestor cone instead of the whole region (cone_walk below).
+    if (!cone_walk<VARIANT>(G.mm, C, G.magicC, M.lab, M.par, M.touched, M.touched_cap, start, target, tr, tc, code, F, lane)) return PF_ST_SEQ;
+  }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   // ---- the path: parents from the goal (astar.py:65-69), then reverse in place ----
@@ -228,7 +304,7 @@ __device__ __forceinline__ int settle(const Grid& G, const Open& O, const Settle
   while (cell != start) {
     if (n >= out_cap - 1 || n > guard) return 3;
     if (lane == 0) out[n] = cell;
-    const int mv = M.par[cell];
+    const int mv = M.par[cell] & 7;
     cell -= move_dr(mv) * C + move_dc(mv);
     n += 1;
   }
