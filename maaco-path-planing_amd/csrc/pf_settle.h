@@ -115,8 +115,8 @@ __device__ __attribute__((noinline)) bool cone_walk(const uint8_t* gmm, int C, u
 }
 
 template <int VARIANT>
-__device__ __forceinline__ int settle(const Grid& G, const Open& O, const SettleMem& M, int start, int target, int tr, int tc,
-                                      const int* av_list, int av_n, int* out, int out_cap, int& out_n, AStat& st, int lane) {
+__device__ __forceinline__ int settle_impl(const Grid& G, const Open& O, const SettleMem& M, int start, int target, int tr, int tc,
+                                           const int* av_list, int av_n, int* out, int out_cap, int& out_n, AStat& st, int lane) {
   constexpr int NBK = PF_ST_NBK, CAP = PF_SETTLE_CAP;
   const int C = G.C, RC = G.R * G.C;
   int* cnt = (int*)O.lf;                                            // LDS [NBK] entries per bucket
@@ -317,6 +317,40 @@ __device__ __forceinline__ int settle(const Grid& G, const Open& O, const Settle
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   out_n = n;
   return 0;
+}
+
+// The engine as seen by the search wrapper: a REAL call.  It runs once per search; inlined into the kernels, its code and
+// registers were part of the function that also holds the sequential pop loop, the kernel's hot code, which paid for it in
+// register allocation and layout.  Arguments are scalars (a struct passed by reference would be forced into scratch memory in
+// the caller); the wave's LDS is reached through the dynamic-LDS symbol, which every kernel here places at offset 0.
+// Returns status | out_n << 8; the work counters come back through the 3 words at PF_SX_OFF.
+extern __shared__ __attribute__((aligned(16))) char pf_dyn_lds[];
+template <int VARIANT>
+__device__ __attribute__((noinline)) long long settle_call(const uint8_t* gmm, int R, int C, uint64_t magicC, char* pool, unsigned long long* lab,
+                                                          int* touched, unsigned char* par, unsigned* epoch, int touched_cap, int start,
+                                                          int target, int tr, int tc, const int* av_list, int av_n, int* out, int out_cap, int lane) {
+  Grid G; G.occ = nullptr; G.mm = gmm; G.d2near = nullptr; G.comp = nullptr; G.R = R; G.C = C; G.magicC = magicC; G.step_cap = 0;
+  Open O; O.lf = (double*)pf_dyn_lds; O.sx = pf_dyn_lds + PF_SX_OFF; O.of = (double*)pool;
+  SettleMem M; M.lab = lab; M.touched = touched; M.par = par; M.epoch = epoch; M.touched_cap = touched_cap; M.astar_too = true;
+  AStat st = {0, 0, 0, 0, 0, 0};
+  int out_n = 0;
+  const int rs = settle_impl<VARIANT>(G, O, M, start, target, tr, tc, av_list, av_n, out, out_cap, out_n, st, lane);
+  PF_LDS_ORDER();
+  if (lane == 0) { unsigned* w = (unsigned*)(pf_dyn_lds + PF_SX_OFF); w[0] = (unsigned)st.pops; w[1] = (unsigned)st.pushes; w[2] = (unsigned)st.nbr; }
+  PF_LDS_ORDER();
+  return (long long)rs | ((long long)out_n << 8);
+}
+template <int VARIANT>
+__device__ __forceinline__ int settle(const Grid& G, const Open& O, const SettleMem& M, int start, int target, int tr, int tc,
+                                      const int* av_list, int av_n, int* out, int out_cap, int& out_n, AStat& st, int lane) {
+  const long long r = settle_call<VARIANT>(G.mm, G.R, G.C, G.magicC, (char*)O.of, M.lab, M.touched, M.par, M.epoch, M.touched_cap, start, target,
+                                           tr, tc, av_list, av_n, out, out_cap, lane);
+  PF_LDS_ORDER();
+  const unsigned* w = (const unsigned*)O.sx;
+  st.pops += w[0]; st.pushes += w[1]; st.nbr += w[2];
+  PF_LDS_ORDER();
+  out_n = (int)(r >> 8);
+  return (int)(r & 0xFF);
 }
 
 }  // namespace pf
