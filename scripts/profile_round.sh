@@ -1,9 +1,9 @@
 #!/bin/bash
 # One round of profiling runs on the GPU box (run through gpurun from the repo root):
-#   bash scripts/profile_round.sh gpurun_out/prof_r02 [workloads...]
+#   bash scripts/profile_round.sh gpurun_out/prof_r03 [workloads...]
 # per workload: rocprofv3 --kernel-trace --stats, --pmc FETCH_SIZE, --pmc WRITE_SIZE (separate passes, as
 # MI355X_MICROARCH.md prescribes: the two do not fit one pass) and the unprofiled bench line; scripts/make_traffic.py turns
-# them into profiles/r02_traffic.json + profiles/r02_<workload>_kernel_stats.csv.  The program goes straight after `--`
+# them into profiles/r03_traffic.json + profiles/r03_<workload>_kernel_stats.csv.  The program goes straight after `--`
 # (python3 itself: no env / bash -c hop, the profiler's preload has already initialised the GPU).
 set -o pipefail
 OUT=$(realpath "$1"); shift; mkdir -p "$OUT"
@@ -38,5 +38,5 @@ done
 find "$OUT" -type f \( -name '*.db' -o -name '*kernel_trace.csv' -o -name '*agent_info.csv' \) -delete
 cd "$ROOT"
 python3 scripts/make_traffic.py "$OUT" > "$OUT/traffic_summary.log" 2>&1 || true
-cp profiles/r02_traffic.json profiles/r02_*_kernel_stats.csv "$OUT/" 2>/dev/null || true
+cp profiles/${PF_ROUND:-r03}_traffic.json profiles/${PF_ROUND:-r03}_*_kernel_stats.csv "$OUT/" 2>/dev/null || true
 tail -60 "$OUT/traffic_summary.log"
