@@ -284,6 +284,9 @@ int pf_selftest_rng(pf_handle* h, uint64_t seed, uint64_t dom, uint64_t it, uint
 int pf_sort_order_by_key(pf_handle* h, int32_t n, const double* d_vals, int32_t stride, int32_t offset, int32_t* d_order);
 /* d_dst[i] = d_src[i * stride + offset] (a stats column packed for an all_gather) */
 int pf_gather_col(pf_handle* h, int32_t n, const double* d_src, int32_t stride, int32_t offset, double* d_dst);
+/* d_out[i] = d_a[i] + sign * d_b[i] (sign = +1 / -1; one IEEE operation per element, in place allowed): the non-strict MAACO
+ * exchange (all_reduce of per-rank pheromone deltas; no reference counterpart) forms and applies its deltas with it. */
+int pf_vec_add_f64(pf_handle* h, int32_t n, const double* d_a, const double* d_b, double sign, double* d_out);
 /* The elite of an MPA iteration (MPA.py:334, population[0] after the sort) lives in a library-owned buffer: cells
  * [R*C] int32, length int32, stats double[5].  pf_mpa_pick_elite copies the row of predator d_order[0] - first_id of
  * this rank's store into it; a sharded run broadcasts the three pieces from the owner instead.  Passing

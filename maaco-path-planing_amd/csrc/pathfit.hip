@@ -3266,6 +3266,20 @@ int pf_sort_order_by_key(pf_handle* h, int32_t n, const double* d_vals, int32_t 
   CK(hipMemcpyAsync(d_order, h->d_oval2, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, h->stream));
   return 0;
 }
+// out[i] = a[i] + sign * b[i] on device columns (the non-strict MAACO exchange forms its per-rank pheromone delta and applies the
+// reduced one with it: no matrix crosses PCIe)
+__global__ void k_vec_axpy(int n, const double* a, const double* b, double sign, double* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] + sign * b[i];
+}
+int pf_vec_add_f64(pf_handle* h, int32_t n, const double* d_a, const double* d_b, double sign, double* d_out) {
+  if (!h) return -2;
+  if (n < 0 || !d_a || !d_b || !d_out || !(sign == 1.0 || sign == -1.0)) return failmsg(h, "pf_vec_add_f64: bad arguments (sign is +1 or -1)");
+  CK(hipSetDevice(h->device));
+  if (n > 0) hipLaunchKernelGGL(k_vec_axpy, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, d_a, d_b, sign, d_out);
+  CK(hipGetLastError());
+  return 0;
+}
 int pf_gather_col(pf_handle* h, int32_t n, const double* d_src, int32_t stride, int32_t offset, double* d_dst) {
   if (!h) return -2;
   if (n < 0 || !d_src || !d_dst || stride < 1 || offset < 0 || offset >= stride) return failmsg(h, "pf_gather_col: bad arguments");

@@ -390,6 +390,10 @@ class Engine:
     def sort_order_by_key(self, n, d_vals, stride, offset, d_order):
         self._ck(self.L.pf_sort_order_by_key(self.h, int(n), d_vals.ptr, int(stride), int(offset), d_order.ptr))
 
+    def vec_add(self, n, d_a, d_b, sign, d_out):
+        """d_out = d_a + sign * d_b (sign +1 / -1) on device columns."""
+        self._ck(self.L.pf_vec_add_f64(self.h, int(n), d_a.ptr, d_b.ptr, float(sign), d_out.ptr))
+
     def gather_col(self, n, d_src, stride, offset, d_dst):
         self._ck(self.L.pf_gather_col(self.h, int(n), d_src.ptr, int(stride), int(offset), d_dst.ptr))
 

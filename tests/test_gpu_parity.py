@@ -96,6 +96,57 @@ def test_astar_golden_both_variants():
                     assert (not SEQ and variant == 0) or (cnt[j, 1] == ost[1] == z["pushes"][i] and cnt[j, 3] == ost[4])
 
 
+def test_big_cases_at_bench_sizes():
+    """HIP == the UNMODIFIED reference on the bench grids themselves (tests/golden/big_cases.npz, oracle/capture_golden_big.py):
+    both connectors on G512 and G1024 incl. the corner-to-corner searches, a path-prefix avoid set, the reference's heap pop / push
+    counts (sequential engine); GA chained decodes + fp64 stats on G512."""
+    from pathfit.engine import score_params
+    z = gio.load("big_cases")
+    names = [str(s) for s in z["grid_names"]]
+    for gid, gname in enumerate(names):
+        e, o, _, _, g = eng(f"up{int(gname[1:]) // 256}:g256")
+        for variant in (0, 1):
+            idx = [i for i in range(len(z["start"])) if z["grid_id"][i] == gid and z["variant"][i] == variant]
+            avoid = [gio.csr_get(z["avoid_off"], z["avoid"], i) if z["has_avoid"][i] else None for i in idx]
+            paths, st, cnt = e.astar_host(variant, z["start"][idx], z["target"][idx], avoid, path_cap=16 * 1024, want_counters=True)
+            for j, i in enumerate(idx):
+                want = gio.csr_get(z["path_off"], z["path"], i)
+                assert st[j] != 3 and np.array_equal(paths[j], want), (gname, variant, i)
+                if len(want) > 1 and (SEQ or variant == 1):
+                    assert cnt[j, 0] == z["pops"][i] and cnt[j, 1] == z["pushes"][i], (gname, variant, i, cnt[j], z["pops"][i], z["pushes"][i])
+    e = eng("up2:g256")[0]
+    sp = score_params(0, True, 0.3, 0.8, 1.8, 100.0)
+    for W in (3, 5):
+        js = [j for j in range(len(z["dec_wp"])) if int((z["dec_wp"][j] >= 0).sum()) == W]
+        wp = np.ascontiguousarray(np.asarray(z["dec_wp"], np.int32)[js, :W])
+        paths, st, stats = e.decode_host(0, 512 * 512 - 1, wp_cells=wp, sp=sp, path_cap=16 * 1024)
+        for k, j in enumerate(js):
+            assert np.array_equal(paths[k], gio.csr_get(z["dec_path_off"], z["dec_path"], j))
+            assert np.array_equal(stats[k], z["dec_stats"][j])
+    # MPA._reconstruct_path_segment of the reference's own initial path at 512^2 (main.py:44-52 parameters)
+    from pathfit._lib import MpaParams
+    base = np.asarray(z["reb_base"], np.int32)
+    seed, it = (int(v) for v in z["reb_seed_it"])
+    n = len(z["reb_idx"])
+    spm = score_params(1, True, 0.1, 0.8, 1.8, 100.0)
+    e.mpa_setup(MpaParams(0.5, 2.0, float(z["reb_sigma"][0]), 0.2, n, 0, 512 * 512 - 1, 1, 1), spm)
+    cap = 8192
+    pop = np.zeros((n, cap), np.int32); pop[:, :len(base)] = base
+    plen = np.full(n, len(base), np.int32)
+    pstats = np.tile(np.asarray(z["reb_base_stats"], np.float64), (n, 1))
+    dpop, dlen, dstats, del_ = e.put(pop), e.put(plen), e.put(pstats), e.put(base)
+    oc, ol, os_, ost = e.buf((n, cap), np.int32), e.buf(n, np.int32), e.buf((n, 5), np.float64), e.buf(n, np.int32)
+    d_idx, d_lv = e.put(z["reb_idx"], np.int32), e.put(z["reb_is_levy"], np.int32)
+    d_sc, d_ag = e.put(z["reb_scale"], np.float64), e.put(z["reb_agent"], np.int32)
+    e._ck(e.L.pf_mpa_rebuild_batch(e.h, it, seed, n, cap, dpop.ptr, dlen.ptr, dstats.ptr, del_.ptr, len(base),
+                                   d_idx.ptr, d_lv.ptr, d_sc.ptr, d_ag.ptr, oc.ptr, ol.ptr, os_.ptr, ost.ptr))
+    cells, lens, stats, st = oc.download(), ol.download(), os_.download(), ost.download()
+    for i in range(n):
+        want = gio.csr_get(z["reb_out_off"], z["reb_out"], i)
+        assert st[i] != 3 and np.array_equal(cells[i, :lens[i]], want), (i, st[i])
+        assert np.array_equal(stats[i], z["reb_stats"][i]), i
+
+
 def test_dijkstra_golden_and_facade():
     """DijkstraSolver (dijkstra.py:32-97): HIP variant 2 == golden paths / pops / pushes of the unmodified reference; the
     facade returns the reference's 6-tuple."""

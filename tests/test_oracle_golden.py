@@ -60,6 +60,43 @@ def test_astar_both_variants():
             assert st[0] == z["pops"][i] and st[1] == z["pushes"][i], i
 
 
+def test_big_cases_at_bench_sizes():
+    """The oracle against vectors captured from the UNMODIFIED reference on the bench grids themselves (G512, G1024:
+    oracle/capture_golden_big.py): both connectors incl. the corner-to-corner searches the sweeps end on, a path-prefix
+    avoid set, heap pop / push counts; GA chained decodes + stats on G512."""
+    import pf_oracle as po
+    z = gio.load("big_cases")
+    names = [str(s) for s in z["grid_names"]]
+    orcs = {}
+    for i in range(len(z["start"])):
+        name = names[int(z["grid_id"][i])]
+        if name not in orcs:
+            orcs[name] = po.Oracle(gio.upsample(gio.grid("g256")[0], int(name[1:]) // 256))
+        avoid = gio.csr_get(z["avoid_off"], z["avoid"], i) if z["has_avoid"][i] else None
+        path, st = orcs[name].astar(int(z["start"][i]), int(z["target"][i]), avoid, int(z["variant"][i]))
+        want = gio.csr_get(z["path_off"], z["path"], i)
+        assert np.array_equal(path, want), (i, name)
+        if len(want) > 1:
+            assert st[0] == z["pops"][i] and st[1] == z["pushes"][i], (i, name, st[:2], z["pops"][i], z["pushes"][i])
+    assert max(int(v) for v in z["pops"]) > 90000                       # the 512^2 corner-to-corner search is in there
+    o = orcs["G512"]
+    for j in range(len(z["dec_wp"])):
+        wp = z["dec_wp"][j]; wp = wp[wp >= 0]                                # (3 or 5 waypoints)
+        p, _ = o.decode(0, 512 * 512 - 1, wp)
+        assert np.array_equal(p, gio.csr_get(z["dec_path_off"], z["dec_path"], j))
+        assert np.array_equal(o.score(p, 0, 0.3, 0.8, 1.8, True, 100.0), z["dec_stats"][j])
+    # MPA._reconstruct_path_segment of the reference's own initial path at 512^2 (main.py:44-52 parameters)
+    base = z["reb_base"]
+    seed, it = (int(v) for v in z["reb_seed_it"])
+    assert np.array_equal(o.score(base, 1, 0.1, 0.8, 1.8, True, 100.0), z["reb_base_stats"])
+    for i in range(len(z["reb_idx"])):
+        g = o.rng(seed, pfrng.DOM_MPA, it, int(z["reb_agent"][i]))
+        out, _, _, _ = o.mpa_rebuild(0, 512 * 512 - 1, base, base, int(z["reb_idx"][i]), int(z["reb_is_levy"][i]), float(z["reb_scale"][i]),
+                                     2.0, float(z["reb_sigma"][0]), g)
+        assert np.array_equal(out, gio.csr_get(z["reb_out_off"], z["reb_out"], i)) and g.ctr == z["reb_draws"][i], i
+        assert np.array_equal(o.score(out, 1, 0.1, 0.8, 1.8, True, 100.0), z["reb_stats"][i]), i
+
+
 def test_dijkstra_solver():
     """DijkstraSolver.solve (dijkstra.py:32-97) = variant 2 of the restated connector."""
     z = gio.load("dijkstra_cases")
