@@ -32,6 +32,7 @@ using namespace pf;
 // ===========================================================================
 struct DevCounters {
   unsigned long long pops, pushes, nbr, path_cells, steps, candidates, deckey, overflow, pruned, settled, sequential;
+  unsigned long long done;   // agents of the running batch that have finished (k_decode_batch: the tail policy of the parallel engine)
 };
 
 struct Common {
@@ -49,6 +50,8 @@ struct Common {
   bool st_astar;         // also for the A* variant (else Dijkstra only)
   int st_top;            // ... or only for the items at queue positions below this (the longest-expected ones: the batch ends on
                          // them, and the engine shortens a search's chain at the price of more traffic per node)
+  int st_tail;           // ... and, in a decode batch, for every search that STARTS once at most this many agents are unfinished: the
+                         // chip is mostly idle by then and what is left are the long chains the batch ends on
 };
 
 PF_DEV Open make_open(char* smem, int /*S*/, char* tier2) {
@@ -335,6 +338,10 @@ __global__ __launch_bounds__(64) void k_decode_batch(DecodeArgs p) {
         }
       }
       int m = 0;
+      if (p.c.st_tail > 0 && !s.sm.astar_too) {                  // the batch's tail: few agents left, the chip mostly idle -> shorten the chain
+        const unsigned long long dn = __hip_atomic_load(&p.c.cnt->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((long long)p.n - (long long)first_u64(dn) <= (long long)p.c.st_tail) s.sm.astar_too = true;
+      }
       rc = astar<0, PLAT>(G, s, O, cur, goal, out + n - 1, p.path_cap - (n - 1), m, tot, lane, out, n);   // ga_solver.py:68-72 (avoid = the cells visited so far)
       if (rc != 0) break;                                        // :74 / :85 -> []
       mark_avoid(s, out + n, m - 1, lane);                       // :76 nodes_in_path_so_far.update
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(64) void k_decode_batch(DecodeArgs p) {
     if (rc != 0) n = 0;
     double sc[5];
     if (p.do_score) score_path(G, p.sp, out, n, lane, sc);
-    if (lane == 0) { p.len[a] = n; p.status[a] = rc; }
+    if (lane == 0) { p.len[a] = n; p.status[a] = rc; atomicAdd(&p.c.cnt->done, 1ull); }
     if (p.do_score && lane < 5) p.stats[(size_t)a * 5 + lane] = sc[lane];
     cells += n; ovf += rc == 3;
   }
@@ -2090,8 +2097,10 @@ static const int kSlotsPerCU = env_int("PF_SLOTS_PER_CU", 8);   // search slots 
 static int g_two_wave = env_int("PF_TWO_WAVE", 0);   // MPA searches on two-wave workgroups: pop wave + pool wave (pf_astar_pr.h; pf_set_option "two_wave")
 static const int kWavesPerCU = env_int("PF_WAVES_PER_CU", kSlotsPerCU);   // resident one-agent waves per CU (LDS permitting)
 static int g_mpa_prune = 1;   // exact bound pruning of MPA rebuilds (pf_set_option "mpa_prune")
-static int g_settle_top = env_int("PF_SETTLE_TOP", 60);  // auto mode ("astar_settle" -1): per mille of a DECODE batch, from the head of the longest-first queue, whose A* searches
+static int g_settle_top = env_int("PF_SETTLE_TOP", 0);  // auto mode ("astar_settle" -1): per mille of a DECODE batch, from the head of the longest-first queue, whose A* searches
                                                          // also try the engine (pf_set_option "astar_settle_top")
+static int g_settle_tail = env_int("PF_SETTLE_TAIL", 600);   // auto mode: per mille of the SEARCH SLOTS; once no more agents of a decode batch than this are unfinished, every search that starts
+                                                              // tries the engine (pf_set_option "astar_settle_tail")
 static int g_settle = env_int("PF_SETTLE", -1);  // closed-set searches try the 64-nodes-per-trip engine first (pf_settle.h; pf_set_option "astar_settle"):
                                                   // -1 (default) Dijkstra only -- h == 0 makes every node regular, so it is never handed back, and it measures
                                                   // 1.6x (2048 concurrent searches) to 3.5x (one search) faster; 1 also A* (exact too -- certified or handed back --
@@ -2154,7 +2163,7 @@ static Common make_common(pf_handle* h, int allow_diag, int restrict_corner, int
   c.G = make_grid(h, allow_diag, restrict_corner);
   c.rec = h->d_rec; c.tier2 = h->d_tier2; c.slot_state = h->d_slot_state; c.work = h->d_work; c.queue = nullptr; c.cnt = h->d_cnt; c.S = S; c.retry = retry;
   const bool st_on = g_settle != 0 && h->d_st_lab;
-  c.st_lab = st_on ? h->d_st_lab : nullptr; c.st_astar = g_settle > 0; c.st_top = 0; c.st_touched = h->d_st_touched; c.st_par = h->d_st_par; c.st_epoch = h->d_st_epoch;
+  c.st_lab = st_on ? h->d_st_lab : nullptr; c.st_astar = g_settle > 0; c.st_top = 0; c.st_tail = 0; c.st_touched = h->d_st_touched; c.st_par = h->d_st_par; c.st_epoch = h->d_st_epoch;
   return c;
 }
 static int begin_batch(pf_handle* h) {
@@ -2346,11 +2355,17 @@ int pf_decode_batch(pf_handle* h, int32_t allow_diag, int32_t restrict_corner, i
   if (n > 64) {
     if (make_queue(h, n, [&](float* est) { hipLaunchKernelGGL(k_plan_decode, dim3((n + 255) / 256), dim3(256), 0, h->stream, a.c.G, n, W, d_wp_cells, d_wp_pos, start, target, est); })) return -1;
     a.c.queue = h->d_queue;
-    // A decode is a chain of W + 1 closed-set searches, so a fallback costs one link, not the chain: the agents at the head of
-    // the longest-first queue (the ones the batch ends on) try the parallel settling engine, which shortens their chains
-    // 1.6x; the others stay sequential, which costs less traffic per node.  ga512 121 -> 108 ms, pso512 60.4 -> 55.9 ms at 6 %.
+    // A decode is a chain of W + 1 closed-set searches, so a fallback costs one link, not the chain.  r02: the agents at the head
+    // of the longest-first queue try the parallel settling engine from the start (ga512 121 -> 108 ms at 6 %).  r03: the TAIL
+    // policy below replaces it by default (astar_settle_top 0): under full load the engine is traffic-bound and no faster than
+    // the sequential loop, so nobody uses it while the chip is full; once the unfinished agents no longer fill 60 % of the
+    // search slots, every search that starts does (one box: sequential only 117.7 ms, head 6 % 111.8, tail 60 % 102.3).
     if (g_settle < 0) a.c.st_top = (int)((long long)n * g_settle_top / 1000);
   }
+  // ... and whatever is still running when the batch is nearly done (chains of W + 1 searches: the switch happens between
+  // links, each search is certified or handed back on its own)
+  // (measured against the chip, not the batch: a batch that never fills the search slots runs on the engine from its start)
+  if (g_settle < 0) a.c.st_tail = (int)((long long)h->nslots * g_settle_tail / 1000);
   return plateau_map(h) ? launch_with_retry(h, k_decode_batch<true>, a, n) : launch_with_retry(h, k_decode_batch<false>, a, n);
 }
 
@@ -2442,6 +2457,7 @@ int pf_set_option(pf_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "two_wave")) { g_two_wave = value != 0; return 0; }
   if (!strcmp(name, "maaco_mark_in_walk")) { g_maaco_mark = value != 0; return 0; }
   if (!strcmp(name, "astar_settle")) { g_settle = value < 0 ? -1 : (value != 0); return 0; }
+  if (!strcmp(name, "astar_settle_tail")) { g_settle_tail = value < 0 ? 0 : (value > 1000 ? 1000 : (int)value); return 0; }
   if (!strcmp(name, "astar_settle_top")) { g_settle_top = value < 0 ? 0 : (value > 1000 ? 1000 : (int)value); return 0; }
   if (!strcmp(name, "plateau_kernels")) { g_plateau_mode = (int)value; return 0; }
   if (!strcmp(name, "maaco_tabu_epoch")) { g_tabu_epoch = (int)value; return 0; }

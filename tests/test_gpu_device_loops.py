@@ -303,9 +303,10 @@ def test_sharded_solvers_over_rccl_loopback():
 
 
 def test_head_of_queue_settling_leaves_decodes_unchanged():
-    """Default mode (`astar_settle` -1): the decodes at the head of a batch's longest-first queue try the parallel settling
-    engine (`astar_settle_top` per mille of the batch), the others the sequential loop.  Whatever the share, paths, statuses
-    and scores are those of the all-sequential batch."""
+    """Default mode (`astar_settle` -1): which decode searches try the parallel settling engine is a POLICY -- the agents at the
+    head of the longest-first queue (`astar_settle_top`, per mille of the batch) and / or every search that starts once the
+    batch's unfinished agents no longer fill `astar_settle_tail` per mille of the search slots.  Whatever the shares, paths,
+    statuses and scores are those of the all-sequential batch."""
     import pathfit
     g = gio.grid("g256")[0]
     e = pathfit.Engine(g)
@@ -316,18 +317,21 @@ def test_head_of_queue_settling_leaves_decodes_unchanged():
     sp = pathfit.score_params(0, True, 0.3, 0.8, 1.8, 100.0)
     outs = []
     try:
-        for mode, top in ((0, 0), (-1, 0), (-1, 60), (-1, 500), (-1, 1000), (1, 0)):
-            e.set_option("astar_settle", mode); e.set_option("astar_settle_top", top)
+        # (mode, head share, tail share): the tail share is measured against the chip's 2048 search slots, so 300 agents are
+        # "the tail" from the start for any share >= 150
+        for mode, top, tail in ((0, 0, 0), (-1, 0, 0), (-1, 60, 0), (-1, 500, 0), (-1, 1000, 0), (1, 0, 0), (-1, 0, 20), (-1, 0, 600)):
+            e.set_option("astar_settle", mode); e.set_option("astar_settle_top", top); e.set_option("astar_settle_tail", tail)
             dc, dl, ds, dst = e.buf((n, cap), np.int32), e.buf(n, np.int32), e.buf(n, np.int32), e.buf((n, 5), np.float64)
             e.decode_batch(n, W, 0, g.size - 1, cap, dc, dl, ds, d_wp, None, sp, dst)
             c = e.counters()
             outs.append((dc.download(), dl.download(), ds.download(), dst.download(), c["settled_searches"] + c["sequential_searches"]))
     finally:
-        e.set_option("astar_settle", -1); e.set_option("astar_settle_top", 60)
+        e.set_option("astar_settle", -1); e.set_option("astar_settle_top", 0); e.set_option("astar_settle_tail", 600)
     ref = outs[0]
     assert ref[4] == 0 and outs[1][4] == 0                    # nothing tries the engine with a share of 0
     tried = [o[4] for o in outs]
     assert 0 < tried[2] < tried[3] < tried[4] == tried[5]     # 6 % < 50 % < everything == `astar_settle` 1
+    assert 0 < tried[6] < tried[7] == tried[5]                # the last 40 agents' remaining links < the whole batch (300 <= 60 % of 2048)
     for o in outs[1:]:
         assert np.array_equal(ref[1], o[1]) and np.array_equal(ref[2], o[2]) and np.array_equal(ref[3], o[3])
         for i in range(n):
