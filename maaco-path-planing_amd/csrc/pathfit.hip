@@ -324,6 +324,22 @@ __global__ __launch_bounds__(64) void k_decode_batch(DecodeArgs p) {
     slot_begin_eval(s, RC, lane);
     int* out = p.cells + (size_t)a * p.path_cap;
     int n = 1, cur = p.start, rc = 0;
+    // Exact short cut.  A waypoint on an obstacle makes its segment's connector return [] at once (astar.py:37-39), and an empty
+    // segment makes the whole decode return [] (ga_solver.py:74 / pso.py:77) -- whatever the segments before it found, and they
+    // have no effect outside the call.  So the answer is known before the first search: PSO positions round onto obstacles
+    // 27 % of the time per waypoint (~80 % of a swarm on G512), and the reference spends their earlier segments for nothing.
+    for (int k = 0; k < p.W && rc == 0; ++k) {
+      int goal;
+      if (p.wp_cells) goal = p.wp_cells[(size_t)a * p.W + k];
+      else {
+        const double x = p.wp_pos[((size_t)a * p.W + k) * 2], y = p.wp_pos[((size_t)a * p.W + k) * 2 + 1];
+        long r = (long)__builtin_rint(x), c = (long)__builtin_rint(y);
+        r = r < 0 ? 0 : (r > G.R - 1 ? G.R - 1 : r);
+        c = c < 0 ? 0 : (c > G.C - 1 ? G.C - 1 : c);
+        goal = (int)(r * G.C + c);
+      }
+      if ((unsigned)goal >= (unsigned)RC || G.occ[goal] == 1) rc = 1;
+    }
     if (lane == 0) { out[0] = p.start; s.rec[p.start].meta = s.avoid_ep << PF_AVOID_SHIFT; }   // ga_solver.py:63-65
     for (int k = 0; k <= p.W && rc == 0; ++k) {
       int goal = p.target;
