@@ -28,9 +28,16 @@ namespace pf {
 #define PF_ST_SEQ 5                 /* internal: not certified -> the caller runs the sequential engine */
 #define PF_SETTLE_CAP 1024          /* entries per bucket (16 B each) */
 // the band structure of this engine is its own (the pop loop's bucket width is tuned separately, pf_astar_sw.h)
+#ifndef PF_ST_Q
 #define PF_ST_Q 64.0
+#endif
 #define PF_ST_NBK 256
 #define PF_LAB_KEYMASK ((1ull << 57) - 1ull)
+#ifndef PF_ST_WIDE
+#define PF_ST_WIDE 1                /* nodes per lane and trip (64 x this many nodes per trip) */
+#endif
+#define PF_ST_MARK_OFF 2048         /* byte offset in the wave's LDS of the band marks (64 x PF_ST_WIDE ints; the bucket counts end at 1024) */
+static_assert(PF_ST_MARK_OFF >= 4 * PF_ST_NBK && PF_ST_MARK_OFF + 256 * PF_ST_WIDE <= PF_GEO_OFF, "band marks between the bucket counts and the replay table");
 #define PF_PAR_IRREG 0x7Fu            /* par[x]: x is irregular (no earlier argmin parent) */
 #define PF_PAR_SEEN 0x80u             /* par[x] bit 7: reached by the ancestor walk of this search */
 
@@ -166,88 +173,122 @@ __device__ __forceinline__ int settle_impl(const Grid& G, const Open& O, const S
       bcur = b0;
     }
     if (F != PF_INF && (double)bcur > F * PF_ST_Q) break;            // every remaining entry has f above the goal's
-    // ---- one entry per lane: the whole buckets from bcur on that fit 64 lanes (a fixpoint does not care about the order,
-    // and one 1/64-wide band alone rarely holds 64 nodes), or 64 entries of the first one when it is larger ----
-    int eidx = -1;                                                   // my entry's index in the pool
+    // ---- K entries per lane: the whole buckets from bcur on that fit 64 K slots (a fixpoint does not care about the order, and
+    // one 1/64-wide band alone rarely holds that many nodes), or 64 K entries of the first one when it is larger.  A trip is
+    // three dependent memory round trips whatever its width (r03: ~3/4 of its time on an idle chip), so K nodes per lane cost
+    // K times the arithmetic but the same latency. ----
+    constexpr int K = PF_ST_WIDE;
+    int eidx[K];                                                     // my entries' indices in the pool
+#pragma unroll
+    for (int u = 0; u < K; ++u) eidx[u] = -1;
     {
       const int lim = F == PF_INF ? 0x7FFFFFFF : (int)(F * PF_ST_Q);  // last band that can hold a node of the region
       const int cb = bcur + lane <= lim ? cnt[(bcur + lane) & (NBK - 1)] : 0;   // lane k: size of the k-th band from bcur
       const int c0 = bcast_i(cb, 0);
-      if (c0 > 64) {
-        eidx = (bcur & (NBK - 1)) * CAP + c0 - 64 + lane;
+      if (c0 > 64 * K) {
+#pragma unroll
+        for (int u = 0; u < K; ++u) eidx[u] = (bcur & (NBK - 1)) * CAP + c0 - 64 * K + 64 * u + lane;
         PF_LDS_ORDER();
-        if (lane == 0) cnt[bcur & (NBK - 1)] = c0 - 64;
+        if (lane == 0) cnt[bcur & (NBK - 1)] = c0 - 64 * K;
       } else {
         const int incl = wave_incl_sum(cb);
-        const int k = __builtin_popcountll(__ballot(incl <= 64));     // (sizes are >= 0: the bands that fit are a prefix; k >= 1)
+        const int k = __builtin_popcountll(__ballot(incl <= 64 * K));   // (sizes are >= 0: the bands that fit are a prefix; k >= 1)
         const int total = bcast_i(incl, k - 1);
-        int* mark = (int*)O.sx;
-        mark[lane] = 0;
+        int* mark = (int*)((char*)O.lf + PF_ST_MARK_OFF);               // [64 K]: where, among the taken entries, each band starts
+#pragma unroll
+        for (int u = 0; u < K; ++u) mark[64 * u + lane] = 0;
         PF_LDS_ORDER();
         if (lane < k && cb > 0) mark[incl - cb] = lane;
         PF_LDS_ORDER();
-        const int kk = wave_incl_max(mark[lane]);                      // my entry's band, counted from bcur
-        const int j = lane - bperm_i(kk, incl - cb);                    // ... and its index in that band
-        if (lane < total) eidx = ((bcur + kk) & (NBK - 1)) * CAP + j;
+        int carry = 0;
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+          int kk = wave_incl_max(mark[64 * u + lane]);                  // my entry's band, counted from bcur
+          kk = kk > carry ? kk : carry;
+          carry = bcast_i(kk, 63);
+          const int j = 64 * u + lane - bperm_i(kk, incl - cb);         // ... and its index in that band
+          if (64 * u + lane < total) eidx[u] = ((bcur + kk) & (NBK - 1)) * CAP + j;
+        }
         PF_LDS_ORDER();
         if (lane < k) cnt[(bcur + lane) & (NBK - 1)] = 0;
       }
       PF_LDS_ORDER();
     }
     // (1) the entries (read where the stores of earlier trips landed: never a stale L1 line of a recycled slot)
-    double g = 0.0; int cell = start;
-    bool have = eidx >= 0;
-    if (have) {
-      g = __builtin_bit_cast(double, __hip_atomic_load((const unsigned long long*)eg + eidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      cell = __hip_atomic_load(ec + eidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double g[K]; int cell[K]; bool have[K];
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+      g[u] = 0.0; cell[u] = start; have[u] = eidx[u] >= 0;
+      if (have[u]) {
+        g[u] = __builtin_bit_cast(double, __hip_atomic_load((const unsigned long long*)eg + eidx[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        cell[u] = __hip_atomic_load(ec + eidx[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     // (2) own label + move mask + the eight neighbour labels, one batch (addresses clamped: the move mask rejects what the clamp invents)
-    unsigned long long own = 0, vn[8]; unsigned mm = 0;
-    if (have) {
-      own = __hip_atomic_load(&M.lab[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // a live entry must never be mistaken for a superseded one
-      mm = G.mm[cell];
+    unsigned long long own[K], vn[K][8]; unsigned mm[K];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { int n = cell + move_dr(k) * C + move_dc(k); n = n < 0 ? 0 : (n >= RC ? RC - 1 : n); vn[k] = M.lab[n]; }
+    for (int u = 0; u < K; ++u) {
+      own[u] = 0; mm[u] = 0;
+      if (have[u]) {
+        own[u] = __hip_atomic_load(&M.lab[cell[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // a live entry must never be mistaken for a superseded one
+        mm[u] = G.mm[cell[u]];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { int n = cell[u] + move_dr(k) * C + move_dc(k); n = n < 0 ? 0 : (n >= RC ? RC - 1 : n); vn[u][k] = M.lab[n]; }
+      }
     }
-    const int r = row_of(G, cell), c = cell - r * C;
-    long hdr = r - tr, hdc = c - tc;
-    const double f = VARIANT == 2 ? g : g + __builtin_sqrt((double)(hdr * hdr + hdc * hdc));
-    have = have && cell != target && own == lab_enc(g, code) && !(own == blocked && cell != start) && f <= F;   // superseded / goal / outside the region
-    if (have) exp_l += 1;
+    int rr[K], cc[K];
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+      rr[u] = row_of(G, cell[u]); cc[u] = cell[u] - rr[u] * C;
+      long hdr = rr[u] - tr, hdc = cc[u] - tc;
+      const double f = VARIANT == 2 ? g[u] : g[u] + __builtin_sqrt((double)(hdr * hdr + hdc * hdc));
+      have[u] = have[u] && cell[u] != target && own[u] == lab_enc(g[u], code) && !(own[u] == blocked && cell[u] != start) && f <= F;   // superseded / goal / outside the region
+      if (have[u]) exp_l += 1;
+    }
     // (3) the atomics, all in flight together; a label only ever falls, so a pre-check against the (possibly stale) loaded
     // value never drops a relaxation that would have won
-    unsigned long long old[8];
-    unsigned wonm = 0;
+    unsigned long long old[K][8];
+    unsigned wonm[K];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const bool ok = have && ((mm >> k) & 1u);
-      const unsigned long long nv = lab_enc(g + (k < 4 ? 1.0 : PF_SQRT2), code);      // astar.py:84-85
-      old[k] = 0ull;
-      if (ok) { nbr_l += 1; if (nv < vn[k]) old[k] = __hip_atomic_fetch_min(&M.lab[cell + move_dr(k) * C + move_dc(k)], nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }   // :87
+    for (int u = 0; u < K; ++u) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const bool ok = have[u] && ((mm[u] >> k) & 1u);
+        const unsigned long long nv = lab_enc(g[u] + (k < 4 ? 1.0 : PF_SQRT2), code);      // astar.py:84-85
+        old[u][k] = 0ull;
+        if (ok) { nbr_l += 1; if (nv < vn[u][k]) old[u][k] = __hip_atomic_fetch_min(&M.lab[cell[u] + move_dr(k) * C + move_dc(k)], nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }   // :87
+      }
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) wonm |= (old[k] > lab_enc(g + (k < 4 ? 1.0 : PF_SQRT2), code)) ? (1u << k) : 0u;
+    for (int u = 0; u < K; ++u) {
+      wonm[u] = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) wonm[u] |= (old[u][k] > lab_enc(g[u] + (k < 4 ? 1.0 : PF_SQRT2), code)) ? (1u << k) : 0u;
+    }
     // ---- pushes of the winners (LDS slot atomics + fire-and-forget stores) and the touched log ----
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const bool won = (wonm >> k) & 1u;
-      const unsigned long long wm = __ballot(won);
-      if (wm) {
-        const int n = cell + move_dr(k) * C + move_dc(k);
-        const double t = g + (k < 4 ? 1.0 : PF_SQRT2);
-        const int nr = r + move_dr(k), nc = c + move_dc(k);
-        long dr_ = nr - tr, dc_ = nc - tc;
-        const double fn = VARIANT == 2 ? t : t + __builtin_sqrt((double)(dr_ * dr_ + dc_ * dc_));   // :90
-        int ba = (int)(fn * PF_ST_Q); ba = ba < bcur ? bcur : ba;     // (an ulp below the current band: it is processed with it)
-        if (won) {
-          push_l += 1;
-          const int at = __hip_atomic_fetch_add(&cnt[ba & (NBK - 1)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (at >= CAP || ba - bcur >= NBK) fail = true;
-          else { eg[(size_t)(ba & (NBK - 1)) * CAP + at] = t; ec[(size_t)(ba & (NBK - 1)) * CAP + at] = n; }
-          const int tt = nt + __builtin_popcountll(wm & ((1ull << lane) - 1ull));
-          if (tt < M.touched_cap) M.touched[tt] = n; else fail = true;
+    for (int u = 0; u < K; ++u) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const bool won = (wonm[u] >> k) & 1u;
+        const unsigned long long wm = __ballot(won);
+        if (wm) {
+          const int n = cell[u] + move_dr(k) * C + move_dc(k);
+          const double t = g[u] + (k < 4 ? 1.0 : PF_SQRT2);
+          const int nr = rr[u] + move_dr(k), nc = cc[u] + move_dc(k);
+          long dr_ = nr - tr, dc_ = nc - tc;
+          const double fn = VARIANT == 2 ? t : t + __builtin_sqrt((double)(dr_ * dr_ + dc_ * dc_));   // :90
+          int ba = (int)(fn * PF_ST_Q); ba = ba < bcur ? bcur : ba;     // (an ulp below the current band: it is processed with it)
+          if (won) {
+            push_l += 1;
+            const int at = __hip_atomic_fetch_add(&cnt[ba & (NBK - 1)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (at >= CAP || ba - bcur >= NBK) fail = true;
+            else { eg[(size_t)(ba & (NBK - 1)) * CAP + at] = t; ec[(size_t)(ba & (NBK - 1)) * CAP + at] = n; }
+            const int tt = nt + __builtin_popcountll(wm & ((1ull << lane) - 1ull));
+            if (tt < M.touched_cap) M.touched[tt] = n; else fail = true;
+          }
+          nt += __builtin_popcountll(wm);
         }
-        nt += __builtin_popcountll(wm);
       }
     }
     if (__ballot(fail)) { fail = true; break; }
