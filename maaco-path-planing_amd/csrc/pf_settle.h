@@ -36,7 +36,10 @@ namespace pf {
 #ifndef PF_ST_WIDE
 #define PF_ST_WIDE 1                /* nodes per lane and trip (64 x this many nodes per trip) */
 #endif
-#define PF_ST_MARK_OFF 2048         /* byte offset in the wave's LDS of the band marks (64 x PF_ST_WIDE ints; the bucket counts end at 1024) */
+#define PF_ST_MARK_OFF 1024         /* byte offset in the wave's LDS of the band marks (64 x PF_ST_WIDE ints; the bucket counts end at 1024) */
+#define PF_ST_WIN_OFF 2048          /* ... of the trip's winner list: PF_ST_WIN_CAP cells (int), then as many labels (double) */
+#define PF_ST_WIN_CAP (PF_ST_WIDE == 1 ? 512 : 768)   /* 64 nodes x 8 moves can never overflow it; a wider build hands the search back if a trip ever does */
+static_assert(PF_ST_MARK_OFF + 256 * PF_ST_WIDE <= PF_ST_WIN_OFF && PF_ST_WIN_OFF + 12 * PF_ST_WIN_CAP <= PF_GEO_OFF, "settle LDS layout");
 static_assert(PF_ST_MARK_OFF >= 4 * PF_ST_NBK && PF_ST_MARK_OFF + 256 * PF_ST_WIDE <= PF_GEO_OFF, "band marks between the bucket counts and the replay table");
 #define PF_PAR_IRREG 0x7Fu            /* par[x]: x is irregular (no earlier argmin parent) */
 #define PF_PAR_SEEN 0x80u             /* par[x] bit 7: reached by the ancestor walk of this search */
@@ -266,30 +269,47 @@ __device__ __forceinline__ int settle_impl(const Grid& G, const Open& O, const S
       for (int k = 0; k < 8; ++k) wonm[u] |= (old[u][k] > lab_enc(g[u] + (k < 4 ? 1.0 : PF_SQRT2), code)) ? (1u << k) : 0u;
     }
     // ---- pushes of the winners (LDS slot atomics + fire-and-forget stores) and the touched log ----
+    // A node wins 1-1.5 of its eight relaxations.  Instead of eight wave-wide rounds (one per move, each with its ballot, sqrt,
+    // bucket atomic and stores whenever ANY lane won that move: ~60 instructions a round, half of the trip's arithmetic), the
+    // winners are written to a list in LDS -- a lane appends its own, a prefix sum gives it its place -- and then handled one per
+    // lane: ceil(winners / 64) rounds, usually one or two.
+    {
+      int wcnt = 0;
 #pragma unroll
-    for (int u = 0; u < K; ++u) {
+      for (int u = 0; u < K; ++u) wcnt += __builtin_popcount(wonm[u]);
+      const int incl = wave_incl_sum(wcnt);
+      const int total = bcast_i(incl, 63);
+      int* ln = (int*)((char*)O.lf + PF_ST_WIN_OFF);
+      double* lt = (double*)((char*)O.lf + PF_ST_WIN_OFF + 4 * PF_ST_WIN_CAP);
+      if (total > PF_ST_WIN_CAP) { fail = true; break; }
+      int wi = incl - wcnt;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const bool won = (wonm[u] >> k) & 1u;
-        const unsigned long long wm = __ballot(won);
-        if (wm) {
-          const int n = cell[u] + move_dr(k) * C + move_dc(k);
-          const double t = g[u] + (k < 4 ? 1.0 : PF_SQRT2);
-          const int nr = rr[u] + move_dr(k), nc = cc[u] + move_dc(k);
-          long dr_ = nr - tr, dc_ = nc - tc;
-          const double fn = VARIANT == 2 ? t : t + __builtin_sqrt((double)(dr_ * dr_ + dc_ * dc_));   // :90
-          int ba = (int)(fn * PF_ST_Q); ba = ba < bcur ? bcur : ba;     // (an ulp below the current band: it is processed with it)
-          if (won) {
-            push_l += 1;
-            const int at = __hip_atomic_fetch_add(&cnt[ba & (NBK - 1)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (at >= CAP || ba - bcur >= NBK) fail = true;
-            else { eg[(size_t)(ba & (NBK - 1)) * CAP + at] = t; ec[(size_t)(ba & (NBK - 1)) * CAP + at] = n; }
-            const int tt = nt + __builtin_popcountll(wm & ((1ull << lane) - 1ull));
-            if (tt < M.touched_cap) M.touched[tt] = n; else fail = true;
-          }
-          nt += __builtin_popcountll(wm);
+      for (int u = 0; u < K; ++u)
+        for (unsigned m = wonm[u]; m; m &= m - 1) {
+          const int k = __builtin_ctz(m);
+          ln[wi] = cell[u] + move_dr(k) * C + move_dc(k); lt[wi] = g[u] + (k < 4 ? 1.0 : PF_SQRT2);
+          wi += 1;
+        }
+      PF_LDS_ORDER();
+      for (int c0 = 0; c0 < total; c0 += 64) {
+        const bool won = c0 + lane < total;
+        int n = start; double t = 0.0;
+        if (won) { n = ln[c0 + lane]; t = lt[c0 + lane]; }
+        const int nr = row_of(G, n), nc = n - nr * C;
+        long dr_ = nr - tr, dc_ = nc - tc;
+        const double fn = VARIANT == 2 ? t : t + __builtin_sqrt((double)(dr_ * dr_ + dc_ * dc_));   // :90
+        int ba = (int)(fn * PF_ST_Q); ba = ba < bcur ? bcur : ba;       // (an ulp below the current band: it is processed with it)
+        if (won) {
+          push_l += 1;
+          const int at = __hip_atomic_fetch_add(&cnt[ba & (NBK - 1)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (at >= CAP || ba - bcur >= NBK) fail = true;
+          else { eg[(size_t)(ba & (NBK - 1)) * CAP + at] = t; ec[(size_t)(ba & (NBK - 1)) * CAP + at] = n; }
+          const int tt = nt + c0 + lane;
+          if (tt < M.touched_cap) M.touched[tt] = n; else fail = true;
         }
       }
+      nt += total;
+      PF_LDS_ORDER();
     }
     if (__ballot(fail)) { fail = true; break; }
     F = (vt >> 57) == code ? lab_dec(vt) : PF_INF;                   // (h(goal) = 0: f = g) -- the bound the NEXT trip works with
