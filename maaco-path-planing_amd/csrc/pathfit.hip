@@ -2597,7 +2597,7 @@ static int maaco_ensure_bits(pf_handle* h, int n) {
 }
 // enqueue the walk of ants [ant0, ant0 + n) (nothing waits); the ants mark their own deposits when g_maaco_mark is on
 static int maaco_enqueue_walk(pf_handle* h, int32_t iter, uint64_t seed, int32_t ant0, int32_t n, int32_t path_cap,
-                              int32_t* d_cells, int32_t* d_len, double* d_plen, int32_t* d_turns, int32_t* d_status) {
+                              int32_t* d_cells, int32_t* d_len, double* d_plen, int32_t* d_turns, int32_t* d_status, bool mark) {
   CK(hipSetDevice(h->device));
   MaacoArgs a;
   a.G = make_grid(h, 1, 1);
@@ -2612,7 +2612,7 @@ static int maaco_enqueue_walk(pf_handle* h, int32_t iter, uint64_t seed, int32_t
   a.cells = d_cells; a.len = d_len; a.plen = d_plen; a.turns = d_turns; a.status = d_status;
   a.bits = nullptr; a.dep = nullptr; a.Q = h->mp.Q;
   h->marks_n = 0; h->marks_cells = nullptr;
-  if (g_maaco_mark) {
+  if (mark) {
     if (maaco_ensure_bits(h, n)) return -1;
     a.bits = h->d_bits; a.dep = h->d_dep;
     h->marks_n = n; h->marks_cells = d_cells;                       // deposit_begin for exactly this batch finds its marks made
@@ -2641,7 +2641,7 @@ int pf_maaco_walk_batch(pf_handle* h, int32_t iter, uint64_t seed, int32_t ant0,
   if (!h->maaco_ready) return failmsg(h, "pf_maaco_walk_batch: call pf_maaco_setup first");
   if (n < 0 || path_cap < 2 || !d_cells || !d_len || !d_plen || !d_turns || !d_status) return failmsg(h, "pf_maaco_walk_batch: bad arguments");
   if (n == 0) { memset(&h->last, 0, sizeof(h->last)); h->marks_n = 0; return 0; }   // an empty batch has empty counters (not the previous batch's overflow)
-  if (maaco_enqueue_walk(h, iter, seed, ant0, n, path_cap, d_cells, d_len, d_plen, d_turns, d_status)) return -1;
+  if (maaco_enqueue_walk(h, iter, seed, ant0, n, path_cap, d_cells, d_len, d_plen, d_turns, d_status, g_maaco_mark != 0)) return -1;
   DevCounters dc; if (end_batch(h, &dc)) return -1;
   CK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
   return 0;
@@ -2659,10 +2659,7 @@ int pf_maaco_iterate(pf_handle* h, int32_t iter, uint64_t seed, int32_t ant0, in
   if (!h) return -2;
   if (!h->maaco_ready) return failmsg(h, "pf_maaco_iterate: call pf_maaco_setup first");
   if (n <= 0 || path_cap < 2 || !d_cells || !d_len || !d_plen || !d_turns || !d_status || !out13) return failmsg(h, "pf_maaco_iterate: bad arguments");
-  const int mark0 = g_maaco_mark; g_maaco_mark = 1;
-  const int rc = maaco_enqueue_walk(h, iter, seed, ant0, n, path_cap, d_cells, d_len, d_plen, d_turns, d_status);
-  g_maaco_mark = mark0;
-  if (rc) return -1;
+  if (maaco_enqueue_walk(h, iter, seed, ant0, n, path_cap, d_cells, d_len, d_plen, d_turns, d_status, true)) return -1;   // (this path always marks)
   if (!h->d_scan3) CK(hipMalloc(&h->d_scan3, 24));
   if (!h->d_mstate) CK(hipMalloc(&h->d_mstate, 16 * sizeof(double)));
   hipLaunchKernelGGL(k_maaco_best, dim3(1), dim3(1024), 0, h->stream, n, d_plen, d_turns, (double*)h->d_scan3);
