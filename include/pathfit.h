@@ -283,6 +283,9 @@ int pf_selftest_rng(pf_handle* h, uint64_t seed, uint64_t dom, uint64_t it, uint
  * list.sort(key=fitness) (MPA.py:321,333,412; ga_solver.py:209): d_order holds the list (position -> id); it is
  * re-ordered by a STABLE device sort on key[pos] = d_vals[d_order[pos] * stride + offset].  Stream ordered. */
 int pf_sort_order_by_key(pf_handle* h, int32_t n, const double* d_vals, int32_t stride, int32_t offset, int32_t* d_order);
+/* population[0] after the sort (MPA.py:334, :413; ga_solver.py:210): out2 = {id at the head of d_order, its key
+ * d_vals[id * stride + offset]} in one 16-byte copy */
+int pf_sorted_head(pf_handle* h, const int32_t* d_order, const double* d_vals, int32_t stride, int32_t offset, double* out2);
 /* d_dst[i] = d_src[i * stride + offset] (a stats column packed for an all_gather) */
 int pf_gather_col(pf_handle* h, int32_t n, const double* d_src, int32_t stride, int32_t offset, double* d_dst);
 /* d_out[i] = d_a[i] + sign * d_b[i] (sign = +1 / -1; one IEEE operation per element, in place allowed): the non-strict MAACO

@@ -3295,6 +3295,23 @@ int pf_sort_order_by_key(pf_handle* h, int32_t n, const double* d_vals, int32_t 
   CK(hipMemcpyAsync(d_order, h->d_oval2, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, h->stream));
   return 0;
 }
+// the head of a sorted list in ONE small copy: out2 = {d_order[0], d_vals[d_order[0] * stride + offset]}
+__global__ void k_sorted_head(const int* order, const double* vals, int stride, int offset, double* out2) {
+  const int id = order[0];
+  out2[0] = (double)id; out2[1] = vals[(size_t)id * stride + offset];
+}
+int pf_sorted_head(pf_handle* h, const int32_t* d_order, const double* d_vals, int32_t stride, int32_t offset, double* out2) {
+  if (!h) return -2;
+  if (!d_order || !d_vals || !out2 || stride < 1 || offset < 0 || offset >= stride) return failmsg(h, "pf_sorted_head: bad arguments");
+  CK(hipSetDevice(h->device));
+  if (!h->d_scan3) CK(hipMalloc(&h->d_scan3, 24));
+  hipLaunchKernelGGL(k_sorted_head, dim3(1), dim3(1), 0, h->stream, d_order, d_vals, stride, offset, (double*)h->d_scan3);
+  CK(hipGetLastError());
+  CK(hipMemcpyAsync(out2, h->d_scan3, 16, hipMemcpyDeviceToHost, h->stream));
+  CK(hipStreamSynchronize(h->stream));
+  h->d2h_small += 1;
+  return 0;
+}
 // out[i] = a[i] + sign * b[i] on device columns (the non-strict MAACO exchange forms its per-rank pheromone delta and applies the
 // reduced one with it: no matrix crosses PCIe)
 __global__ void k_vec_axpy(int n, const double* a, const double* b, double sign, double* out) {

@@ -93,6 +93,7 @@ SYMBOLS = {
     "pf_ga_assemble_dev": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pf_sort_order_by_key": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp]),
     "pf_gather_col": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp]),
+    "pf_sorted_head": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "pf_vec_add_f64": (C.c_int, [_vp, _i32, _vp, _vp, _dbl, _vp]),
     "pf_mpa_elite_buf": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "pf_mpa_pick_elite": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _i32]),

@@ -390,6 +390,12 @@ class Engine:
     def sort_order_by_key(self, n, d_vals, stride, offset, d_order):
         self._ck(self.L.pf_sort_order_by_key(self.h, int(n), d_vals.ptr, int(stride), int(offset), d_order.ptr))
 
+    def sorted_head(self, d_order, d_vals, stride=1, offset=0):
+        """(id at the head of the sorted list, its key): one 16-byte copy."""
+        out = np.zeros(2)
+        self._ck(self.L.pf_sorted_head(self.h, d_order.ptr, d_vals.ptr, int(stride), int(offset), out.ctypes.data))
+        return int(out[0]), float(out[1])
+
     def vec_add(self, n, d_a, d_b, sign, d_out):
         """d_out = d_a + sign * d_b (sign +1 / -1) on device columns."""
         self._ck(self.L.pf_vec_add_f64(self.h, int(n), d_a.ptr, d_b.ptr, float(sign), d_out.ptr))
