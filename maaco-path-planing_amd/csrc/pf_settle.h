@@ -161,7 +161,9 @@ __device__ __forceinline__ int settle_impl(const Grid& G, const Open& O, const S
   // with the atomics that survive the pre-check.  The goal's label (the region bound F) is requested at the top and
   // consumed at the bottom: a bound that is one trip old only ever over-expands, which the certificate below catches.
   double F = PF_INF;
+  int trips = 0;
   for (;;) {
+    trips += 1;
     const unsigned long long vt = __hip_atomic_load(&M.lab[target], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (at L2, where the atomics land)
     // ---- next non-empty bucket ----
     PF_LDS_ORDER();
@@ -316,6 +318,7 @@ __device__ __forceinline__ int settle_impl(const Grid& G, const Open& O, const S
   }
   st.pops += (unsigned long long)wave_sum_i((int)exp_l); st.pushes += 1u + (unsigned)wave_sum_i((int)push_l);
   st.nbr += (unsigned)wave_sum_i((int)nbr_l);
+  st.max_open = trips;                                                // (a search answered here reports its trips where the sequential loop reports its open-list high-water mark)
   if (fail) return PF_ST_SEQ;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                  // the passes below read the labels the atomics left in L2
@@ -397,7 +400,7 @@ __device__ __attribute__((noinline)) long long settle_call(const uint8_t* gmm, i
   int out_n = 0;
   const int rs = settle_impl<VARIANT>(G, O, M, start, target, tr, tc, av_list, av_n, out, out_cap, out_n, st, lane);
   PF_LDS_ORDER();
-  if (lane == 0) { unsigned* w = (unsigned*)(pf_dyn_lds + PF_SX_OFF); w[0] = (unsigned)st.pops; w[1] = (unsigned)st.pushes; w[2] = (unsigned)st.nbr; }
+  if (lane == 0) { unsigned* w = (unsigned*)(pf_dyn_lds + PF_SX_OFF); w[0] = (unsigned)st.pops; w[1] = (unsigned)st.pushes; w[2] = (unsigned)st.nbr; w[3] = (unsigned)st.max_open; }
   PF_LDS_ORDER();
   return (long long)rs | ((long long)out_n << 8);
 }
@@ -409,6 +412,7 @@ __device__ __forceinline__ int settle(const Grid& G, const Open& O, const Settle
   PF_LDS_ORDER();
   const unsigned* w = (const unsigned*)O.sx;
   st.pops += w[0]; st.pushes += w[1]; st.nbr += w[2];
+  if ((int)(r & 0xFF) != PF_ST_SEQ && (int)w[3] > st.max_open) st.max_open = (int)w[3];
   PF_LDS_ORDER();
   out_n = (int)(r >> 8);
   return (int)(r & 0xFF);
