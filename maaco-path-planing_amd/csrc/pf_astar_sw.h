@@ -35,6 +35,9 @@ PF_DEV unsigned long long dbits(double x) { return (unsigned long long)__double_
 #ifndef PF_EARLY_REFILL
 #define PF_EARLY_REFILL 1   /* 0: refill only when the window is empty (A/B builds: 123-127 k against 131.5 k evals/s) */
 #endif
+#ifndef PF_EARLY_BELOW
+#define PF_EARLY_BELOW 7    /* the early refill runs when fewer live entries than this are left (7 = the heads of one trip) */
+#endif
 #ifndef PF_RUN_SORT
 #define PF_RUN_SORT 1       /* 0: the bitonic network for every refill (A/B builds) */
 #endif
@@ -697,7 +700,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
       }
       rhead = (unsigned)pr_ld(L->ctl + 2 /* PR_HEAD */);        // (used by the push section: its latency is covered by the trip)
     } else {
-      if (PF_EARLY_REFILL) sw_early_refill<SEM>(P, W, O, rec, C, lane, 7);
+      if (PF_EARLY_REFILL) sw_early_refill<SEM>(P, W, O, rec, C, lane, PF_EARLY_BELOW);
       if (W.wp == W.wn) {
         const int rr_ = sw_refill<SEM, PLAT>(P, W, O, rec, C, lane);
         if (rr_ == 1) { status = 1; break; }
