@@ -886,7 +886,7 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
 // occurrence p of the minimum length, which resets (idx, turns) to ant p; afterwards only ants within 1e-9 of that
 // minimum with strictly fewer turns take over, so the result is the first ant, among p and the later near-minimum ants,
 // that attains their smallest turn count.  out = {best_len, best_turns (inf for none), best_idx as a double (-1 none)}.
-__global__ __launch_bounds__(1024) void k_maaco_best(int n, const double* plen, const int* turns, double* out) {
+PF_DEV void maaco_best_block(int n, const double* plen, const int* turns, double* out) {
   __shared__ unsigned long long red[1024];
   __shared__ double sL; __shared__ int sP;
   const int t = threadIdx.x;
@@ -922,6 +922,9 @@ __global__ __launch_bounds__(1024) void k_maaco_best(int n, const double* plen, 
     const unsigned T = (unsigned)(k >> 32);
     out[0] = Lmin; out[1] = T == 0x7FFFFFFFu ? PF_INF : (double)T; out[2] = (double)(unsigned)(k & 0xFFFFFFFFull);
   }
+}
+__global__ __launch_bounds__(1024) void k_maaco_best(int n, const double* plen, const int* turns, double* out) {
+  maaco_best_block(n, plen, turns, out);
 }
 
 // ===========================================================================
@@ -1003,8 +1006,8 @@ __global__ void k_tau_clip(double* tau, const uint8_t* occ, int RC, double tmin,
 // AFTER this iteration's take).  state = {ib_len, ib_turns, ib_idx, took, best_len, best_turns, tmin, tmax, skip, steps,
 // candidates, path_cells, overflow}; skip = 1 when an ant overflowed its path row (the caller redoes the iteration with
 // longer rows: the pheromone must not move).
-__global__ void k_maaco_take(const double* scan3, double best_len, double best_turns, double rho, int R, int C, const DevCounters* cnt,
-                             double* state) {
+PF_DEV void maaco_take(const double* scan3, double best_len, double best_turns, double rho, int R, int C, const DevCounters* cnt,
+                       double* state) {
   const double il = scan3[0], it = scan3[1];
   double took = 0.0;
   if (il < best_len) { best_len = il; best_turns = it; took = 1.0; }                          // :351-354
@@ -1018,6 +1021,19 @@ __global__ void k_maaco_take(const double* scan3, double best_len, double best_t
   state[6] = tmax / (2.0 * mx); state[7] = tmax;                    // :323
   state[8] = cnt->overflow ? 1.0 : 0.0;
   state[9] = (double)cnt->steps; state[10] = (double)cnt->candidates; state[11] = (double)cnt->path_cells; state[12] = (double)cnt->overflow;
+}
+// The scan and the take-over test of one iteration in ONE launch (a 1024-thread block): thread 0 runs the test once the block's
+// scan is in `scan3`, mirrors the 13 doubles into `host_state` (pinned, device-visible host memory: the caller reads them after an
+// event, no copy is enqueued) and hands the iteration's private work counter / counters back zeroed for the next walk.
+__global__ __launch_bounds__(1024) void k_maaco_best_take(int n, const double* plen, const int* turns, double* scan3, double best_len,
+                                                         double best_turns, double rho, int R, int C, int* work, DevCounters* cnt,
+                                                         double* state, double* host_state) {
+  maaco_best_block(n, plen, turns, scan3);
+  if (threadIdx.x != 0) return;                                    // (thread 0 wrote scan3 itself: program order)
+  maaco_take(scan3, best_len, best_turns, rho, R, C, cnt, state);
+  for (int k = 0; k < 13; ++k) host_state[k] = state[k];
+  *work = 0;
+  DevCounters z; memset(&z, 0, sizeof(z)); *cnt = z;
 }
 // The whole of MAACO.py:304-332 in ONE pass over tau: per cell t = tau * (1 - rho) (:305), then the deposits of the ants that
 // visited it in ant order (:306-311; k_tau_deposit's ordered walk of the bit matrix), then the clip (:326-332) -- the same
@@ -1886,7 +1902,7 @@ struct pf_handle {
   int* d_d2wide = nullptr; int wide_W = 0; double* d_penw = nullptr; int penw_n = 0; double penw_min_safe = -1.0;   // min_safe_distance > 15.9
   int edt_radius = 7;      // radius of the obstacle-distance window d2near was built with
   double obst_frac = -1.0; // share of obstacle cells (lazy; picks the plateau kernels on open maps)
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
   float last_ms = 0.f;
   std::string err;
   // MAACO
@@ -1896,6 +1912,9 @@ struct pf_handle {
   bool bits_clean = false;            // the visit-bit matrix is all zero (k_tau_deposit leaves it so)
   int marks_n = 0; const int* marks_cells = nullptr;   // the last walk batch marked its own deposits (for these n ants / this path buffer)
   double* d_mstate = nullptr;         // pf_maaco_iterate's 13 doubles
+  double* h_mstate = nullptr; double* h_mstate_dev = nullptr;   // ... mirrored by the device into pinned host memory (no copy is enqueued)
+  char* d_mctl = nullptr;             // pf_maaco_iterate's own {work counter @0, DevCounters @16}: zeroed by k_maaco_best_take for the next walk
+  bool mctl_clean = false;
   unsigned* d_visit = nullptr; unsigned* d_visit_epoch = nullptr; int maaco_slots = 0;
   unsigned long long* d_bits = nullptr; size_t bits_words = 0; int dep_cap = 0;
   // MPA
@@ -2014,8 +2033,8 @@ extern "C" {
 const char* pf_version(void) { return "pathfit 0.1 (gfx950)"; }
 int pf_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 const char* pf_last_error(pf_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
-void* pf_stream(pf_handle* h) { return (void*)h->stream; }
-int pf_sync(pf_handle* h) { CK(hipStreamSynchronize(h->stream)); return 0; }
+void* pf_stream(pf_handle* h) { return h ? (void*)h->stream : nullptr; }
+int pf_sync(pf_handle* h) { if (!h) return -2; CK(hipStreamSynchronize(h->stream)); return 0; }
 
 __global__ void k_and_mask(uint8_t* dst, const uint8_t* src, int n, unsigned m) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2034,7 +2053,7 @@ int pf_create(const uint8_t* grid, int32_t R, int32_t C, int32_t device, pf_hand
   #define CKC(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fail(nullptr, #call, e_); pf_destroy(h); return -1; } } while (0)
   CKC(hipSetDevice(device));
   CKC(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  CKC(hipEventCreate(&h->ev0)); CKC(hipEventCreate(&h->ev1));
+  CKC(hipEventCreate(&h->ev0)); CKC(hipEventCreate(&h->ev1)); CKC(hipEventCreateWithFlags(&h->ev2, hipEventDisableTiming | hipEventReleaseToSystem));
   h->h_occ.resize(h->RC);
   for (int i = 0; i < h->RC; ++i) h->h_occ[i] = grid[i] == 1 ? 1 : 0;
   CKC(hipMalloc(&h->d_occ, h->RC)); CKC(hipMalloc(&h->d_mm_r1, h->RC)); CKC(hipMalloc(&h->d_mm_r0, h->RC));
@@ -2060,11 +2079,13 @@ void pf_destroy(pf_handle* h) {
   if (h->comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(h->stream); g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
   void* ptrs[] = {h->d_occ, h->d_mm_r1, h->d_mm_r0, h->d_mm_r1_nd, h->d_mm_r0_nd, h->d_d2near, h->d_rec, h->d_slot_state,
                   h->d_work, h->d_cnt, h->d_pen, h->d_tier2, h->d_tau, h->d_taua, h->d_eta, h->d_dep, h->d_tep, h->d_visit, h->d_visit_epoch,
-                  h->d_bits, h->d_mstate, h->d_d2wide, h->d_penw, h->d_tmp, h->d_elite_stats, h->d_init_cells, h->d_init_stats, h->d_est, h->d_est2, h->d_iota, h->d_queue, h->d_sort_tmp, h->d_jobs, h->d_jres, h->d_prop, h->d_doubt, h->d_scan, h->d_scan3, h->d_okey, h->d_okey2, h->d_oval2, h->d_elite_cells, h->d_elite_len, h->d_ga_pool, h->d_st_lab, h->d_st_touched, h->d_st_par, h->d_st_epoch,
+                  h->d_bits, h->d_mstate, h->d_mctl, h->d_d2wide, h->d_penw, h->d_tmp, h->d_elite_stats, h->d_init_cells, h->d_init_stats, h->d_est, h->d_est2, h->d_iota, h->d_queue, h->d_sort_tmp, h->d_jobs, h->d_jres, h->d_prop, h->d_doubt, h->d_scan, h->d_scan3, h->d_okey, h->d_okey2, h->d_oval2, h->d_elite_cells, h->d_elite_len, h->d_ga_pool, h->d_st_lab, h->d_st_touched, h->d_st_par, h->d_st_epoch,
                   h->d_comp[0], h->d_comp[1], h->d_comp[2], h->d_comp[3], h->d_ds, h->d_dt};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->ev2) (void)hipEventDestroy(h->ev2);
+  if (h->h_mstate) (void)hipHostFree(h->h_mstate);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -2094,15 +2115,15 @@ int pf_update_grid(pf_handle* h, const uint8_t* grid) {
   return 0;
 }
 
-int pf_dev_alloc(pf_handle* h, int64_t bytes, void** d_out) { CK(hipSetDevice(h->device)); CK(hipMalloc(d_out, (size_t)(bytes > 0 ? bytes : 1))); return 0; }
-int pf_dev_free(pf_handle* h, void* p) { CK(hipSetDevice(h->device)); CK(hipFree(p)); return 0; }
-int pf_h2d(pf_handle* h, void* d, const void* s, int64_t n) { CK(hipMemcpyAsync(d, s, (size_t)n, hipMemcpyHostToDevice, h->stream)); CK(hipStreamSynchronize(h->stream)); return 0; }
-int pf_d2h(pf_handle* h, void* d, const void* s, int64_t n) { CK(hipMemcpyAsync(d, s, (size_t)n, hipMemcpyDeviceToHost, h->stream)); CK(hipStreamSynchronize(h->stream)); if (n <= 128) h->d2h_small += 1; else { h->d2h_bulk += 1; h->d2h_bulk_bytes += n; } return 0; }
+int pf_dev_alloc(pf_handle* h, int64_t bytes, void** d_out) { if (!h) return -2; if (!d_out || bytes < 0) return failmsg(h, "pf_dev_alloc: bad arguments"); CK(hipSetDevice(h->device)); CK(hipMalloc(d_out, (size_t)(bytes > 0 ? bytes : 1))); return 0; }
+int pf_dev_free(pf_handle* h, void* p) { if (!h) return -2; if (!p) return 0; CK(hipSetDevice(h->device)); CK(hipFree(p)); return 0; }
+int pf_h2d(pf_handle* h, void* d, const void* s, int64_t n) { if (!h) return -2; if (n == 0) return 0; if (!d || !s || n < 0) return failmsg(h, "pf_h2d: bad arguments"); CK(hipMemcpyAsync(d, s, (size_t)n, hipMemcpyHostToDevice, h->stream)); CK(hipStreamSynchronize(h->stream)); return 0; }
+int pf_d2h(pf_handle* h, void* d, const void* s, int64_t n) { if (!h) return -2; if (n == 0) return 0; if (!d || !s || n < 0) return failmsg(h, "pf_d2h: bad arguments"); CK(hipMemcpyAsync(d, s, (size_t)n, hipMemcpyDeviceToHost, h->stream)); CK(hipStreamSynchronize(h->stream)); if (n <= 128) h->d2h_small += 1; else { h->d2h_bulk += 1; h->d2h_bulk_bytes += n; } return 0; }
 int pf_d2h_counts(pf_handle* h, int64_t* small_copies, int64_t* bulk_copies, int64_t* bulk_bytes) { if (!h) return -2; if (small_copies) *small_copies = h->d2h_small; if (bulk_copies) *bulk_copies = h->d2h_bulk; if (bulk_bytes) *bulk_bytes = h->d2h_bulk_bytes; return 0; }
-int pf_d2d(pf_handle* h, void* d, const void* s, int64_t n) { CK(hipMemcpyAsync(d, s, (size_t)n, hipMemcpyDeviceToDevice, h->stream)); CK(hipStreamSynchronize(h->stream)); return 0; }
-int pf_memset(pf_handle* h, void* d, int32_t b, int64_t n) { CK(hipMemsetAsync(d, b, (size_t)n, h->stream)); CK(hipStreamSynchronize(h->stream)); return 0; }
-int pf_get_counters(pf_handle* h, pf_counters* out) { *out = h->last; return 0; }
-float pf_last_kernel_ms(pf_handle* h) { return h->last_ms; }
+int pf_d2d(pf_handle* h, void* d, const void* s, int64_t n) { if (!h) return -2; if (n == 0) return 0; if (!d || !s || n < 0) return failmsg(h, "pf_d2d: bad arguments"); CK(hipMemcpyAsync(d, s, (size_t)n, hipMemcpyDeviceToDevice, h->stream)); CK(hipStreamSynchronize(h->stream)); return 0; }
+int pf_memset(pf_handle* h, void* d, int32_t b, int64_t n) { if (!h) return -2; if (n == 0) return 0; if (!d || n < 0) return failmsg(h, "pf_memset: bad arguments"); CK(hipMemsetAsync(d, b, (size_t)n, h->stream)); CK(hipStreamSynchronize(h->stream)); return 0; }
+int pf_get_counters(pf_handle* h, pf_counters* out) { if (!h || !out) return -2; *out = h->last; return 0; }
+float pf_last_kernel_ms(pf_handle* h) { return h ? h->last_ms : 0.0f; }
 
 }  // extern "C"
 
@@ -2564,6 +2585,7 @@ int pf_maaco_setup(pf_handle* h, const pf_maaco_params* p) {
     CK(hipMemsetAsync(h->d_visit_epoch, 0, sizeof(unsigned) * vs, h->stream));
     CK(hipStreamSynchronize(h->stream));
   }
+  CK(hipFuncSetAttribute((const void*)k_tau_update, hipFuncAttributeMaxDynamicSharedMemorySize, PF_DEP_CHUNK * (int)sizeof(double)));
   h->maaco_ready = true;
   return maaco_refresh_taua(h);
 }
@@ -2588,16 +2610,22 @@ static int maaco_ensure_bits(pf_handle* h, int n) {
     h->bits_words = words;
     h->bits_clean = false;
   }
-  if ((int)(words * 64) > h->dep_cap) { if (h->d_dep) CK(hipFree(h->d_dep)); CK(hipMalloc(&h->d_dep, sizeof(double) * (size_t)words * 64)); h->dep_cap = (int)(words * 64); }
+  if ((int)(words * 64) > h->dep_cap) {
+    if (h->d_dep) CK(hipFree(h->d_dep));
+    CK(hipMalloc(&h->d_dep, sizeof(double) * (size_t)words * 64)); h->dep_cap = (int)(words * 64);
+    CK(hipMemsetAsync(h->d_dep, 0, sizeof(double) * words * 64, h->stream));
+  }
   if (!h->bits_clean)      // (the deposit kernels hand the matrix back zeroed; a fresh buffer, a failed or an abandoned batch does not)
     CK(hipMemsetAsync(h->d_bits, 0, h->bits_words * h->RC * sizeof(unsigned long long), h->stream));
   h->bits_clean = false;
-  CK(hipMemsetAsync(h->d_dep, 0, sizeof(double) * words * 64, h->stream));
+  // (d_dep needs no clearing per batch: the walk kernels / k_visit_bits write the entry of EVERY ant of the batch, 0.0 for a failed
+  // one, and an entry beyond the batch is never read -- its bits are zero)
   return 0;
 }
 // enqueue the walk of ants [ant0, ant0 + n) (nothing waits); the ants mark their own deposits when g_maaco_mark is on
 static int maaco_enqueue_walk(pf_handle* h, int32_t iter, uint64_t seed, int32_t ant0, int32_t n, int32_t path_cap,
-                              int32_t* d_cells, int32_t* d_len, double* d_plen, int32_t* d_turns, int32_t* d_status, bool mark) {
+                              int32_t* d_cells, int32_t* d_len, double* d_plen, int32_t* d_turns, int32_t* d_status, bool mark,
+                              bool own_ctl = false) {
   CK(hipSetDevice(h->device));
   MaacoArgs a;
   a.G = make_grid(h, 1, 1);
@@ -2621,8 +2649,15 @@ static int maaco_enqueue_walk(pf_handle* h, int32_t iter, uint64_t seed, int32_t
   const bool pack8 = n >= g_maaco_pack8_min;
   int grid = pack8 ? h->maaco_slots / 8 : (h->maaco_slots < 8192 ? h->maaco_slots : 8192);
   const int need = pack8 ? (n + 7) / 8 : n; if (grid > need) grid = need;
-  CK(hipMemsetAsync(h->d_work, 0, sizeof(int), h->stream));
-  CK(hipMemsetAsync(h->d_cnt, 0, sizeof(DevCounters), h->stream));
+  if (own_ctl) {                                                    // pf_maaco_iterate: the previous iteration's last reader left the block zeroed
+    if (!h->d_mctl) { CK(hipMalloc(&h->d_mctl, 16 + sizeof(DevCounters))); h->mctl_clean = false; }
+    if (!h->mctl_clean) CK(hipMemsetAsync(h->d_mctl, 0, 16 + sizeof(DevCounters), h->stream));
+    h->mctl_clean = false;
+    a.work = (int*)h->d_mctl; a.cnt = (DevCounters*)(h->d_mctl + 16);
+  } else {
+    CK(hipMemsetAsync(h->d_work, 0, sizeof(int), h->stream));
+    CK(hipMemsetAsync(h->d_cnt, 0, sizeof(DevCounters), h->stream));
+  }
   if (g_tabu_epoch >= 0) {                                          // one-shot: later batches carry on from there
     CK(hipMemsetD32Async((hipDeviceptr_t)h->d_visit_epoch, g_tabu_epoch, (size_t)h->maaco_slots, h->stream));
     g_tabu_epoch = -1;
@@ -2659,19 +2694,26 @@ int pf_maaco_iterate(pf_handle* h, int32_t iter, uint64_t seed, int32_t ant0, in
   if (!h) return -2;
   if (!h->maaco_ready) return failmsg(h, "pf_maaco_iterate: call pf_maaco_setup first");
   if (n <= 0 || path_cap < 2 || !d_cells || !d_len || !d_plen || !d_turns || !d_status || !out13) return failmsg(h, "pf_maaco_iterate: bad arguments");
-  if (maaco_enqueue_walk(h, iter, seed, ant0, n, path_cap, d_cells, d_len, d_plen, d_turns, d_status, true)) return -1;   // (this path always marks)
   if (!h->d_scan3) CK(hipMalloc(&h->d_scan3, 24));
   if (!h->d_mstate) CK(hipMalloc(&h->d_mstate, 16 * sizeof(double)));
-  hipLaunchKernelGGL(k_maaco_best, dim3(1), dim3(1024), 0, h->stream, n, d_plen, d_turns, (double*)h->d_scan3);
-  hipLaunchKernelGGL(k_maaco_take, dim3(1), dim3(1), 0, h->stream, (const double*)h->d_scan3, best_len, best_turns, h->mp.rho, h->R, h->C,
-                     (const DevCounters*)h->d_cnt, h->d_mstate);
+  if (!h->h_mstate) {
+    CK(hipHostMalloc((void**)&h->h_mstate, 16 * sizeof(double), hipHostMallocMapped));
+    CK(hipHostGetDevicePointer((void**)&h->h_mstate_dev, h->h_mstate, 0));
+  }
+  double* hs_dev = h->h_mstate_dev;
+  if (maaco_enqueue_walk(h, iter, seed, ant0, n, path_cap, d_cells, d_len, d_plen, d_turns, d_status, true, true)) return -1;   // (this path always marks)
+  hipLaunchKernelGGL(k_maaco_best_take, dim3(1), dim3(1024), 0, h->stream, n, (const double*)d_plen, (const int*)d_turns, (double*)h->d_scan3,
+                     best_len, best_turns, h->mp.rho, h->R, h->C, (int*)h->d_mctl, (DevCounters*)(h->d_mctl + 16), h->d_mstate, hs_dev);
+  CK(hipEventRecord(h->ev2, h->stream));
   const int words = (n + 63) / 64;
-  CK(hipFuncSetAttribute((const void*)k_tau_update, hipFuncAttributeMaxDynamicSharedMemorySize, PF_DEP_CHUNK * (int)sizeof(double)));
   hipLaunchKernelGGL(k_tau_update, dim3((h->RC + 1023) / 1024), dim3(1024), PF_DEP_CHUNK * sizeof(double), h->stream, h->d_tau, h->d_occ,
                      h->RC, h->d_bits, words, h->d_dep, 1.0 - h->mp.rho, (const double*)h->d_mstate, 0.0, 0.0);
   CK(hipGetLastError());
-  CK(hipMemcpyAsync(out13, h->d_mstate, 13 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  CK(hipStreamSynchronize(h->stream));
+  // the host needs the 13 doubles, not the pheromone: it waits for the take-over test only, the update pass runs on behind the
+  // caller's bookkeeping (everything later on this stream is ordered after it)
+  CK(hipEventSynchronize(h->ev2));
+  memcpy(out13, h->h_mstate, 13 * sizeof(double));
+  h->mctl_clean = true;
   h->d2h_small += 1;
   CK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
   memset(&h->last, 0, sizeof(h->last));
@@ -2725,7 +2767,6 @@ int pf_maaco_update(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_
   const double tmax = (1.0 / (1.0 - h->mp.rho)) * (1.0 / bl);       // :317
   int mx = h->C > h->R ? h->C : h->R; if (mx < 1) mx = 1;
   const double tmin = tmax / (2.0 * mx);                            // :323
-  CK(hipFuncSetAttribute((const void*)k_tau_update, hipFuncAttributeMaxDynamicSharedMemorySize, PF_DEP_CHUNK * (int)sizeof(double)));
   hipLaunchKernelGGL(k_tau_update, dim3((h->RC + 1023) / 1024), dim3(1024), PF_DEP_CHUNK * sizeof(double), h->stream, h->d_tau, h->d_occ,
                      h->RC, h->d_bits, h->dep_words, h->d_dep, 1.0 - h->mp.rho, (const double*)nullptr, tmin, tmax);
   CK(hipGetLastError());

@@ -108,6 +108,7 @@ class Engine:
             raise PathfitError(self.L.pf_last_error(None).decode())
         self.h = h
         self.device = int(device)
+        self._out13 = (C.c_double * 13)()   # pf_maaco_iterate's answer block, reused
         self.klog = None          # a list: every hot-path launch appends (kernel family, its HIP-event ms, its counters)
 
     def update_grid(self, grid):
@@ -298,9 +299,9 @@ class Engine:
     def maaco_iterate(self, it, seed, ant0, n, path_cap, d_cells, d_len, d_plen, d_turns, d_status, best_len, best_turns):
         """One whole iteration (walks, best scan, take-over test, pheromone update) enqueued back to back; one 104-byte copy back.
         -> dict(ib_len, ib_turns, ib_idx, took, best_len, best_turns, skipped, overflow_agents)."""
-        out = np.zeros(13)
+        out = self._out13
         self._ck(self.L.pf_maaco_iterate(self.h, int(it), int(seed), int(ant0), int(n), int(path_cap), d_cells.ptr, d_len.ptr, d_plen.ptr,
-                                         d_turns.ptr, d_status.ptr, float(best_len), float(best_turns), out.ctypes.data))
+                                         d_turns.ptr, d_status.ptr, float(best_len), float(best_turns), C.addressof(out)))
         self._logk("maaco_walk")
         return {"ib_len": float(out[0]), "ib_turns": float(out[1]), "ib_idx": int(out[2]), "took": out[3] != 0.0, "best_len": float(out[4]),
                 "best_turns": float(out[5]), "skipped": out[8] != 0.0, "overflow_agents": int(out[12])}
