@@ -477,6 +477,11 @@ __global__ __launch_bounds__(256) void k_pso_scan(int n, const double* stats, co
 // ===========================================================================
 // K4: MAACO ant walk
 // ===========================================================================
+// Deposit bit matrix, blocked by 64-cell stretch: word (cell, w) -- bit a & 63 set iff successful ant 64 w + (a & 63) visited the
+// cell -- sits at [cell >> 6][w][cell & 63], W words per cell allotted.  The W chunks of a stretch (512 B each) are one contiguous
+// run, which is what the update pass reads: with [w][cell] every chunk of a stretch lay RC * 8 bytes (2 MB at 512^2) from the next,
+// and the pass spent its time in address-translation misses (9 us per batch of eight loads).
+PF_DEV size_t bits_idx(int cell, int w, int W) { return ((size_t)(cell >> 6) * W + w) * 64 + (cell & 63); }
 struct MaacoArgs {
   Grid G;
   const double* tau;      // tau^alpha when alpha != 1 (host-refreshed), else tau
@@ -494,6 +499,9 @@ struct MaacoArgs {
   // [a >> 6][cell]; atomicOr is order independent, so the matrix equals k_visit_bits') and leaves its deposit Q / L in dep[a]
   // (MAACO.py:307-308): the separate pass over all paths is gone
   unsigned long long* bits; double* dep; double Q;
+  // chunk flags of the bit matrix: byte [cell >> 6][word] != 0 whenever some cell of that 64-cell stretch has a bit in that word
+  // (plain stores of the same value; k_tau_update reads only flagged 512-byte chunks and clears the flags it used)
+  uint8_t* flag; int fstride;
 };
 
 __global__ void k_pack_tep(int RC, const double* tau, const double* eta, double* tep) {
@@ -661,9 +669,9 @@ __global__ __launch_bounds__(64) void k_maaco_walk(MaacoArgs p) {
       if (lane == 0) p.dep[a] = good ? p.Q / plen : 0.0;            // :308
       if (good) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // lane 0 wrote the path
-        unsigned long long* w = p.bits + (size_t)(a >> 6) * RC;
         const unsigned long long bit = 1ull << (a & 63);
-        for (int i = lane; i < n; i += 64) atomicOr(&w[out[i]], bit);
+        uint8_t* fl = p.flag + (a >> 6);
+        for (int i = lane; i < n; i += 64) { const int c = out[i]; atomicOr(&p.bits[bits_idx(c, a >> 6, p.fstride)], bit); fl[(size_t)(c >> 6) * p.fstride] = 1; }
       }
     }
     cells_tot += rc == 0 ? n : 0; ovf_tot += rc == 3;
@@ -862,14 +870,17 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
           const int l = __builtin_ctzll(gm);
           const int aa = bcast_i(a, l), nn = bcast_i(n, l);
           const int* oo = p.cells + (size_t)aa * p.path_cap;
-          unsigned long long* w = p.bits + (size_t)(aa >> 6) * RC;
           const unsigned long long bit = 1ull << (aa & 63);
+          uint8_t* fl = p.flag + (aa >> 6);
           for (int i = lane; i < nn; i += 256) {                    // four cell loads in flight, then their (unwaited) atomics
             int c4[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) c4[u] = i + 64 * u < nn ? oo[i + 64 * u] : -1;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) if (c4[u] >= 0) __hip_atomic_fetch_or(&w[c4[u]], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int u = 0; u < 4; ++u) if (c4[u] >= 0) {
+              __hip_atomic_fetch_or(&p.bits[bits_idx(c4[u], aa >> 6, p.fstride)], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              fl[(size_t)(c4[u] >> 6) * p.fstride] = 1;
+            }
           }
         }
       }
@@ -936,15 +947,15 @@ __global__ void k_tau_evaporate(double* tau, int RC, double keep) {
 }
 // visit bit matrix [word][cell]: bit (a & 63) of word a >> 6 set iff successful ant a visited cell
 __global__ __launch_bounds__(64) void k_visit_bits(int n, int path_cap, const int* cells, const int* len, const double* plen,
-                                                   double Q, unsigned long long* bits, int RC, double* dep) {
+                                                   double Q, unsigned long long* bits, int RC, double* dep, uint8_t* flag, int fstride) {
   const int a = blockIdx.x;
   const int L = len[a];
   const bool good = L > 0 && plen[a] != PF_INF && plen[a] > 1e-6;   // MAACO.py:307
   if (threadIdx.x == 0) dep[a] = good ? Q / plen[a] : 0.0;          // :308
   if (!good) return;
-  unsigned long long* w = bits + (size_t)(a >> 6) * RC;
   const unsigned long long bit = 1ull << (a & 63);
-  for (int i = threadIdx.x; i < L; i += blockDim.x) atomicOr(&w[cells[(size_t)a * path_cap + i]], bit);
+  uint8_t* fl = flag + (a >> 6);
+  for (int i = threadIdx.x; i < L; i += blockDim.x) { const int c = cells[(size_t)a * path_cap + i]; atomicOr(&bits[bits_idx(c, a >> 6, fstride)], bit); fl[(size_t)(c >> 6) * fstride] = 1; }
 }
 // per cell: add the deposits of the ants that visited it, in ant order (MAACO.py:306-311
 // is sequential over ants; a cell is visited at most once per ant because of the tabu set)
@@ -953,10 +964,59 @@ __global__ __launch_bounds__(64) void k_visit_bits(int n, int path_cap, const in
 // PF_DEP_CHUNK ants are therefore staged in LDS (128 KB; one 1024-thread block per CU), where a read costs ~64 cycles
 // instead of an L2 round trip.
 #define PF_DEP_CHUNK 16384
+// The ordered deposits of ONE 64-ant word.  Sparse words (the usual case) walk their set bits; when some cell of the wavefront
+// has more than PF_DEP_DENSE of its 64 ants set -- the start, the target and their neighbours collect a deposit from (almost)
+// every ant, and that thread's ordered sum is the kernel's critical path -- all 64 ants are stepped through instead, without
+// count-trailing-zeros or dependent LDS addresses.  Same sums in the same order either way: a clear bit adds exactly nothing.
+#ifndef PF_TAU_PROBE
+#define PF_TAU_PROBE 0   // timing probes only: 1 = no deposits (loads, zeroing stores and the clip stay); 2 = per-wave clocks left in tau (scripts/probe_tau_waves.py)
+#endif
+#ifndef PF_TAU_FLY
+#define PF_TAU_FLY 4        // chunks of a stretch in flight while the previous PF_TAU_FLY are summed (k_tau_update)
+#endif
+#ifndef PF_DEP_DENSE
+#define PF_DEP_DENSE 12
+#endif
+PF_DEV double dep_word(double t, unsigned long long x, const double* dw) {
+  if (__any((int)__builtin_popcountll(x) > PF_DEP_DENSE)) {
+    // per ant three instructions, one of them on the chain: bit -> 0.0 / 1.0 (v_bfe, v_cvt), t = fma(d, bit, t) -- exact: d * 1 = d,
+    // d * 0 = 0 and t + 0 = t.  Measured per step on one wavefront (scripts/ubench/exec.hip, s_memtime ticks): this form 13.1, sign
+    // test + two v_cndmask + add 26.1, a carry-out lane mask moved into EXEC 35.4 (a scalar register written by the VALU is slow to
+    // reach the scalar unit), EXEC <- a mask that is already scalar 9.3 = the bare dependent v_add_f64 (9.4).
+    const unsigned lo = (unsigned)x, hi = (unsigned)(x >> 32);
+    double d[8], e[8];                                              // values read one batch ahead (wave-uniform addresses: LDS broadcasts)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d[k] = dw[k];
+#pragma unroll
+    for (int j0 = 0; j0 < 64; j0 += 8) {
+      if (j0 + 8 < 64) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = dw[j0 + 8 + k];
+      }
+      const unsigned y = j0 < 32 ? lo : hi;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t = __builtin_fma(d[k], (double)((y >> ((j0 + k) & 31)) & 1u), t);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) d[k] = e[k];
+    }
+    return t;
+  }
+  while (x) {
+    // four deposits per trip: the LDS reads go out together, the adds stay in ant order (adding the 0.0 of an
+    // absent ant leaves the positive sum unchanged)
+    const int j0 = __builtin_ctzll(x); x &= x - 1;
+    const bool h1 = x != 0; const int j1 = h1 ? __builtin_ctzll(x) : j0; x &= x - 1;
+    const bool h2 = x != 0; const int j2 = h2 ? __builtin_ctzll(x) : j0; x &= x - 1;
+    const bool h3 = x != 0; const int j3 = h3 ? __builtin_ctzll(x) : j0; x &= x - 1;
+    const double d0 = dw[j0], d1 = dw[j1], d2 = dw[j2], d3 = dw[j3];
+    t += d0; t += h1 ? d1 : 0.0; t += h2 ? d2 : 0.0; t += h3 ? d3 : 0.0;
+  }
+  return t;
+}
 // Every word of the matrix is read here exactly once, so the kernel also leaves it zeroed for the next iteration (a
 // store per non-zero word) instead of the host clearing n/8 bytes per cell -- 512 MB at 16 384 ants on G512 -- every time.
 __global__ __launch_bounds__(1024) void k_tau_deposit(double* tau, const uint8_t* occ, int RC, unsigned long long* bits, int nwords,
-                                                     const double* dep, int cell0, int cell1) {
+                                                     const double* dep, int cell0, int cell1, int W) {
   extern __shared__ __attribute__((aligned(16))) double sdep[];    // [PF_DEP_CHUNK]
   const int i = cell0 + blockIdx.x * blockDim.x + threadIdx.x;     // cells [cell0, cell1): the pipelined multi-GPU fold works on row chunks
   const bool live = i < cell1;
@@ -972,24 +1032,14 @@ __global__ __launch_bounds__(1024) void k_tau_deposit(double* tau, const uint8_t
     for (int w0 = 0; w0 < cw; w0 += 8) {
       unsigned long long b[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) b[u] = (w0 + u < cw) ? bits[(size_t)(c0 + w0 + u) * RC + i] : 0ull;
+      for (int u = 0; u < 8; ++u) b[u] = (w0 + u < cw) ? bits[bits_idx(i, c0 + w0 + u, W)] : 0ull;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) if (b[u]) bits[(size_t)(c0 + w0 + u) * RC + i] = 0ull;
+      for (int u = 0; u < 8; ++u) if (b[u]) bits[bits_idx(i, c0 + w0 + u, W)] = 0ull;
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        unsigned long long x = b[u];
-        const double* dw = sdep + (w0 + u) * 64;
+        const unsigned long long x = b[u];
         touched |= x != 0;
-        while (x) {
-          // four deposits per trip: the LDS reads go out together, the adds stay in ant order (adding the 0.0 of an
-          // absent ant leaves the positive sum unchanged)
-          const int j0 = __builtin_ctzll(x); x &= x - 1;
-          const bool h1 = x != 0; const int j1 = h1 ? __builtin_ctzll(x) : j0; x &= x - 1;
-          const bool h2 = x != 0; const int j2 = h2 ? __builtin_ctzll(x) : j0; x &= x - 1;
-          const bool h3 = x != 0; const int j3 = h3 ? __builtin_ctzll(x) : j0; x &= x - 1;
-          const double d0 = dw[j0], d1 = dw[j1], d2 = dw[j2], d3 = dw[j3];
-          t += d0; t += h1 ? d1 : 0.0; t += h2 ? d2 : 0.0; t += h3 ? d3 : 0.0;
-        }
+        t = dep_word(t, x, sdep + (w0 + u) * 64);
       }
     }
   }
@@ -1040,40 +1090,79 @@ __global__ __launch_bounds__(1024) void k_maaco_best_take(int n, const double* p
 // fp64 operations in the same order as the three kernels, one read and one write of tau instead of three each.  The clip
 // bounds come from `state` (k_maaco_take) or, when state is null, from the arguments.
 __global__ __launch_bounds__(1024) void k_tau_update(double* tau, const uint8_t* occ, int RC, unsigned long long* bits, int nwords,
-                                                    const double* dep, double keep, const double* state, double tmin_a, double tmax_a) {
+                                                    const double* dep, double keep, const double* state, double tmin_a, double tmax_a,
+                                                    uint8_t* flag, int fstride) {
   extern __shared__ __attribute__((aligned(16))) double sdep[];    // [PF_DEP_CHUNK]
   if (state && state[8] != 0.0) return;                            // an ant overflowed: the iteration is redone, tau stays
   const double tmin = state ? state[6] : tmin_a, tmax = state ? state[7] : tmax_a;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = i < RC;
+  // a wavefront owns one 64-cell stretch (512-byte word loads); the 16 wavefronts of a block take stretches gridDim.x apart, so the
+  // few busy parts of the map -- around the start, the target and the corridors every ant uses -- land on different CUs
+  const int lane = threadIdx.x & 63;
+  const int seg = (threadIdx.x >> 6) * gridDim.x + blockIdx.x;
+  const int i = seg * 64 + lane;
+  const bool live = i < RC, seg_live = seg * 64 < RC;              // (seg_live is wave-uniform)
   double t = live ? tau[i] * keep : 0.0;                           // :305
+#if PF_TAU_PROBE == 2
+  const unsigned long long probe_t0 = __builtin_amdgcn_s_memtime();
+  int probe_dense = 0, probe_chunks = 0;
+#endif
+  uint8_t* frow = flag + (size_t)seg * fstride;
   for (int c0 = 0; c0 < nwords; c0 += PF_DEP_CHUNK / 64) {
     const int cw = nwords - c0 < PF_DEP_CHUNK / 64 ? nwords - c0 : PF_DEP_CHUNK / 64;
     __syncthreads();
     for (int k = threadIdx.x; k < cw * 64; k += blockDim.x) sdep[k] = dep[c0 * 64 + k];
     __syncthreads();
-    if (!live) continue;
-    for (int w0 = 0; w0 < cw; w0 += 8) {
-      unsigned long long b[8];
+    if (!seg_live) continue;
+    for (int k0 = 0; k0 < cw; k0 += 64) {
+      // which of the next 64 words have anything in this stretch: one flag byte per lane -> a wave-uniform mask, walked in word
+      // (= ant) order; only those chunks are loaded at all (measured: 23 % of them at 512^2 / 16 384 ants, 14 % at 1024^2 / 8 192)
+      const int wl = c0 + k0 + lane;
+      const bool mine = k0 + lane < cw;
+      const uint8_t f = mine ? frow[wl] : (uint8_t)0;
+      if (f) frow[wl] = 0;
+      unsigned long long m = __ballot(f != 0);
+      // PF_TAU_FLY chunks in flight, the next PF_TAU_FLY requested before these are summed.  The loads are unconditional (an empty slot
+      // re-reads chunk 0 of the stretch and is masked afterwards): loads under a branch make the compiler wait for ALL of them.
+      unsigned long long* cb = bits + (size_t)seg * fstride * 64 + lane;   // bits_idx(i, w, fstride) = cb[w * 64]
+      int idx[PF_TAU_FLY], nidx[PF_TAU_FLY];
+      unsigned long long b[PF_TAU_FLY], nb[PF_TAU_FLY];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) b[u] = (w0 + u < cw) ? bits[(size_t)(c0 + w0 + u) * RC + i] : 0ull;
+      for (int u = 0; u < PF_TAU_FLY; ++u) {
+        idx[u] = m ? c0 + k0 + (int)__builtin_ctzll(m) : -1; m &= m - 1;
+        b[u] = cb[(size_t)(idx[u] < 0 ? 0 : idx[u]) * 64];
+      }
+      while (idx[0] >= 0) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) if (b[u]) bits[(size_t)(c0 + w0 + u) * RC + i] = 0ull;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        unsigned long long x = b[u];
-        const double* dw = sdep + (w0 + u) * 64;
-        while (x) {
-          const int j0 = __builtin_ctzll(x); x &= x - 1;
-          const bool h1 = x != 0; const int j1 = h1 ? __builtin_ctzll(x) : j0; x &= x - 1;
-          const bool h2 = x != 0; const int j2 = h2 ? __builtin_ctzll(x) : j0; x &= x - 1;
-          const bool h3 = x != 0; const int j3 = h3 ? __builtin_ctzll(x) : j0; x &= x - 1;
-          const double d0 = dw[j0], d1 = dw[j1], d2 = dw[j2], d3 = dw[j3];
-          t += d0; t += h1 ? d1 : 0.0; t += h2 ? d2 : 0.0; t += h3 ? d3 : 0.0;
+        for (int u = 0; u < PF_TAU_FLY; ++u) {
+          nidx[u] = m ? c0 + k0 + (int)__builtin_ctzll(m) : -1; m &= m - 1;
+          nb[u] = cb[(size_t)(nidx[u] < 0 ? 0 : nidx[u]) * 64];
         }
+#pragma unroll
+        for (int u = 0; u < PF_TAU_FLY; ++u) {
+          if (idx[u] < 0) break;                                    // (wave-uniform)
+          const unsigned long long x = live ? b[u] : 0ull;
+          // the matrix goes back zeroed; every lane stores (a store under a branch would again cost exact wait counts, and the
+          // flagged chunks are 1/4 of the matrix)
+          cb[(size_t)idx[u] * 64] = 0ull;
+#if PF_TAU_PROBE == 2
+          probe_chunks += 1; probe_dense += __any((int)__builtin_popcountll(x) > PF_DEP_DENSE) ? 1 : 0;
+#endif
+#if PF_TAU_PROBE != 1
+          t = dep_word(t, x, sdep + (idx[u] - c0) * 64);
+#else
+          t += x == 12345ull ? 1.0 : 0.0;
+#endif
+        }
+#pragma unroll
+        for (int u = 0; u < PF_TAU_FLY; ++u) { idx[u] = nidx[u]; b[u] = nb[u]; }
       }
     }
   }
+#if PF_TAU_PROBE == 2
+  // (timing probe, wrong pheromone on purpose: lane 0 leaves the wave's shader clocks, lane 1 its dirty chunks, lane 2 the dense ones)
+  if (live) tau[i] = lane == 0 ? (double)(__builtin_amdgcn_s_memtime() - probe_t0) : lane == 1 ? (double)probe_chunks : lane == 2 ? (double)probe_dense : t;   // (t stays live: the sums must not be optimised away)
+  return;
+#endif
   if (live) tau[i] = occ[i] == 1 ? 1e-9 : fmin(fmax(t, tmin), tmax);   // :326-332 (paths never cross obstacles: their words are empty)
 }
 
@@ -1917,6 +2006,7 @@ struct pf_handle {
   bool mctl_clean = false;
   unsigned* d_visit = nullptr; unsigned* d_visit_epoch = nullptr; int maaco_slots = 0;
   unsigned long long* d_bits = nullptr; size_t bits_words = 0; int dep_cap = 0;
+  uint8_t* d_flag = nullptr;          // chunk flags of d_bits: [(RC + 63) / 64][bits_words] bytes (MaacoArgs::flag)
   // MPA
   bool mpa_ready = false;
   pf_mpa_params mpp = {};
@@ -2079,7 +2169,7 @@ void pf_destroy(pf_handle* h) {
   if (h->comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(h->stream); g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
   void* ptrs[] = {h->d_occ, h->d_mm_r1, h->d_mm_r0, h->d_mm_r1_nd, h->d_mm_r0_nd, h->d_d2near, h->d_rec, h->d_slot_state,
                   h->d_work, h->d_cnt, h->d_pen, h->d_tier2, h->d_tau, h->d_taua, h->d_eta, h->d_dep, h->d_tep, h->d_visit, h->d_visit_epoch,
-                  h->d_bits, h->d_mstate, h->d_mctl, h->d_d2wide, h->d_penw, h->d_tmp, h->d_elite_stats, h->d_init_cells, h->d_init_stats, h->d_est, h->d_est2, h->d_iota, h->d_queue, h->d_sort_tmp, h->d_jobs, h->d_jres, h->d_prop, h->d_doubt, h->d_scan, h->d_scan3, h->d_okey, h->d_okey2, h->d_oval2, h->d_elite_cells, h->d_elite_len, h->d_ga_pool, h->d_st_lab, h->d_st_touched, h->d_st_par, h->d_st_epoch,
+                  h->d_bits, h->d_flag, h->d_mstate, h->d_mctl, h->d_d2wide, h->d_penw, h->d_tmp, h->d_elite_stats, h->d_init_cells, h->d_init_stats, h->d_est, h->d_est2, h->d_iota, h->d_queue, h->d_sort_tmp, h->d_jobs, h->d_jres, h->d_prop, h->d_doubt, h->d_scan, h->d_scan3, h->d_okey, h->d_okey2, h->d_oval2, h->d_elite_cells, h->d_elite_len, h->d_ga_pool, h->d_st_lab, h->d_st_touched, h->d_st_par, h->d_st_epoch,
                   h->d_comp[0], h->d_comp[1], h->d_comp[2], h->d_comp[3], h->d_ds, h->d_dt};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -2606,7 +2696,9 @@ static int maaco_ensure_bits(pf_handle* h, int n) {
   const size_t words = (size_t)(n + 63) / 64;
   if (words > h->bits_words) {
     if (h->d_bits) CK(hipFree(h->d_bits));
-    CK(hipMalloc(&h->d_bits, words * h->RC * sizeof(unsigned long long)));
+    CK(hipMalloc(&h->d_bits, words * (size_t)((h->RC + 63) / 64) * 64 * sizeof(unsigned long long)));   // (bits_idx: whole stretches)
+    if (h->d_flag) CK(hipFree(h->d_flag));
+    CK(hipMalloc(&h->d_flag, words * (size_t)((h->RC + 63) / 64)));
     h->bits_words = words;
     h->bits_clean = false;
   }
@@ -2616,7 +2708,10 @@ static int maaco_ensure_bits(pf_handle* h, int n) {
     CK(hipMemsetAsync(h->d_dep, 0, sizeof(double) * words * 64, h->stream));
   }
   if (!h->bits_clean)      // (the deposit kernels hand the matrix back zeroed; a fresh buffer, a failed or an abandoned batch does not)
-    CK(hipMemsetAsync(h->d_bits, 0, h->bits_words * h->RC * sizeof(unsigned long long), h->stream));
+  {
+    CK(hipMemsetAsync(h->d_bits, 0, h->bits_words * (size_t)((h->RC + 63) / 64) * 64 * sizeof(unsigned long long), h->stream));
+    CK(hipMemsetAsync(h->d_flag, 0, h->bits_words * (size_t)((h->RC + 63) / 64), h->stream));
+  }
   h->bits_clean = false;
   // (d_dep needs no clearing per batch: the walk kernels / k_visit_bits write the entry of EVERY ant of the batch, 0.0 for a failed
   // one, and an entry beyond the batch is never read -- its bits are zero)
@@ -2638,11 +2733,11 @@ static int maaco_enqueue_walk(pf_handle* h, int32_t iter, uint64_t seed, int32_t
   a.q0 = maaco_q0(iter, h->mp.num_iterations, h->mp.q0_initial);
   a.seed = seed; a.ant0 = ant0; a.n = n; a.path_cap = path_cap;
   a.cells = d_cells; a.len = d_len; a.plen = d_plen; a.turns = d_turns; a.status = d_status;
-  a.bits = nullptr; a.dep = nullptr; a.Q = h->mp.Q;
+  a.bits = nullptr; a.dep = nullptr; a.flag = nullptr; a.fstride = 0; a.Q = h->mp.Q;
   h->marks_n = 0; h->marks_cells = nullptr;
   if (mark) {
     if (maaco_ensure_bits(h, n)) return -1;
-    a.bits = h->d_bits; a.dep = h->d_dep;
+    a.bits = h->d_bits; a.dep = h->d_dep; a.flag = h->d_flag; a.fstride = (int)h->bits_words;
     h->marks_n = n; h->marks_cells = d_cells;                       // deposit_begin for exactly this batch finds its marks made
   }
   // eight ants per wavefront (k_maaco_walk8) once the batch can fill the chip that way; else one per wave
@@ -2707,7 +2802,7 @@ int pf_maaco_iterate(pf_handle* h, int32_t iter, uint64_t seed, int32_t ant0, in
   CK(hipEventRecord(h->ev2, h->stream));
   const int words = (n + 63) / 64;
   hipLaunchKernelGGL(k_tau_update, dim3((h->RC + 1023) / 1024), dim3(1024), PF_DEP_CHUNK * sizeof(double), h->stream, h->d_tau, h->d_occ,
-                     h->RC, h->d_bits, words, h->d_dep, 1.0 - h->mp.rho, (const double*)h->d_mstate, 0.0, 0.0);
+                     h->RC, h->d_bits, words, h->d_dep, 1.0 - h->mp.rho, (const double*)h->d_mstate, 0.0, 0.0, h->d_flag, (int)h->bits_words);
   CK(hipGetLastError());
   // the host needs the 13 doubles, not the pheromone: it waits for the take-over test only, the update pass runs on behind the
   // caller's bookkeeping (everything later on this stream is ordered after it)
@@ -2748,7 +2843,7 @@ int pf_maaco_deposit_begin(pf_handle* h, int32_t n, int32_t path_cap, const int3
     h->marks_n = 0;
   } else {
     if (maaco_ensure_bits(h, n)) return -1;
-    hipLaunchKernelGGL(k_visit_bits, dim3(n), dim3(64), 0, h->stream, n, path_cap, d_cells, d_len, d_plen, h->mp.Q, h->d_bits, h->RC, h->d_dep);
+    hipLaunchKernelGGL(k_visit_bits, dim3(n), dim3(64), 0, h->stream, n, path_cap, d_cells, d_len, d_plen, h->mp.Q, h->d_bits, h->RC, h->d_dep, h->d_flag, (int)h->bits_words);
     CK(hipGetLastError());
   }
   h->dep_words = (int)words; h->dep_done = 0;
@@ -2768,7 +2863,7 @@ int pf_maaco_update(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_
   int mx = h->C > h->R ? h->C : h->R; if (mx < 1) mx = 1;
   const double tmin = tmax / (2.0 * mx);                            // :323
   hipLaunchKernelGGL(k_tau_update, dim3((h->RC + 1023) / 1024), dim3(1024), PF_DEP_CHUNK * sizeof(double), h->stream, h->d_tau, h->d_occ,
-                     h->RC, h->d_bits, h->dep_words, h->d_dep, 1.0 - h->mp.rho, (const double*)nullptr, tmin, tmax);
+                     h->RC, h->d_bits, h->dep_words, h->d_dep, 1.0 - h->mp.rho, (const double*)nullptr, tmin, tmax, h->d_flag, (int)h->bits_words);
   CK(hipGetLastError());
   if (h->dep_words) h->bits_clean = true;
   h->dep_words = 0;
@@ -2781,7 +2876,7 @@ int pf_maaco_deposit_cells(pf_handle* h, int32_t cell0, int32_t cell1) {
   CK(hipSetDevice(h->device));
   CK(hipFuncSetAttribute((const void*)k_tau_deposit, hipFuncAttributeMaxDynamicSharedMemorySize, PF_DEP_CHUNK * (int)sizeof(double)));
   hipLaunchKernelGGL(k_tau_deposit, dim3((cell1 - cell0 + 1023) / 1024), dim3(1024), PF_DEP_CHUNK * sizeof(double), h->stream, h->d_tau, h->d_occ,
-                     h->RC, h->d_bits, h->dep_words, h->d_dep, cell0, cell1);
+                     h->RC, h->d_bits, h->dep_words, h->d_dep, cell0, cell1, (int)h->bits_words);
   CK(hipGetLastError());
   h->dep_done += cell1 - cell0;
   if (h->dep_done >= h->RC) h->bits_clean = true;                   // every word has been read and zeroed again
