@@ -176,7 +176,9 @@ int pf_maaco_update(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_
  * best-of-iteration scan (:343-349), take-over test against the caller's overall best (:351-358), one-pass pheromone update.
  * ONE 104-byte copy comes back: out13 = {ib_len, ib_turns, ib_idx, took, best_len, best_turns, tmin, tmax, skipped, steps,
  * candidates, path_cells, overflow_agents}.  overflow_agents > 0: the pheromone was left untouched (skipped = 1); repeat
- * the call with longer path rows. */
+ * the call with longer path rows.  The call returns once the take-over test is known (the device mirrors out13 into pinned
+ * host memory; no copy is enqueued); the pheromone update may still be running -- every later pf_ call on this handle is
+ * ordered after it on the handle's stream, pf_sync waits for it. */
 int pf_maaco_iterate(pf_handle* h, int32_t iter, uint64_t seed, int32_t ant0, int32_t n, int32_t path_cap,
                      int32_t* d_cells, int32_t* d_len, double* d_plen, int32_t* d_turns, int32_t* d_status,
                      double best_len, double best_turns, double* out13);
