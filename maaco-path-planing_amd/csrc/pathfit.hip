@@ -728,6 +728,9 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
   Rng g; g.key = 0; g.ctr = 0;
   int* out = p.cells;
   bool need = true, alive = true;
+#ifdef PF_WALK_PROBE
+  unsigned long long pr_wait = 0, pr_rounds = 0, pr_mark = 0; const unsigned long long pr_t0 = __builtin_amdgcn_s_memtime();
+#endif
   while (__ballot(alive)) {
     if (alive && need) {                                           // fetch + initialise the next ant of this group
       int w = 0;
@@ -768,12 +771,20 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
       // getrandbits at :250 / :254, or numpy's random_sample at :259): both words are mixed here, before the loads below
       // are waited for, and the counter advances only when the step gets that far.
       const uint64_t w1 = g.peek64(1), w2 = g.peek64(2);
+#ifdef PF_WALK_PROBE
+      __builtin_amdgcn_sched_barrier(0); const unsigned long long pr_ta = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+#endif
       if (inb) {
         vw = tl.patch(widx, visit[widx]);
-        // the step is bound by the number of divergent vector loads: tau and eta'[turn] in one
+        // one divergent vector load less per step: tau and eta'[turn] in one
         const pf_d2u te = *(const pf_d2u*)(p.tep + (size_t)nidx * 3 + turn);
         tv = turn ? te.x : te.y; ev = turn ? te.y : te.x;
       }
+#ifdef PF_WALK_PROBE
+      { __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+        pr_wait += __builtin_amdgcn_s_memtime() - pr_ta; }
+#endif
       const bool ok = inb && (M & hbit) && !tabu_test(vw, epoch, nc);
       const unsigned mall = gballot8(ok);
       const int vr = tr - cr, vc = tc - cc;
@@ -857,6 +868,9 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
       cells_tot += rc == 0 ? n : 0; ovf_tot += rc == 3;
       need = true;
     }
+#ifdef PF_WALK_PROBE
+    pr_rounds += 1; const unsigned long long pr_m0 = __builtin_amdgcn_s_memtime();
+#endif
     if (p.bits) {
       // the ants that finished in this round mark their deposits: the WHOLE wave walks each finished path (64 cells a round;
       // the other groups would only wait for a group that marked alone, 8 cells a round)
@@ -885,7 +899,15 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
         }
       }
     }
+#ifdef PF_WALK_PROBE
+    pr_mark += __builtin_amdgcn_s_memtime() - pr_m0;
+#endif
   }
+#ifdef PF_WALK_PROBE
+  // (diagnostic build: wave clocks in the counters the MAACO path leaves unused -- scripts/probe_walk_split.py)
+  if (lane == 0) { atomicAdd(&p.cnt->pops, pr_wait); atomicAdd(&p.cnt->pushes, __builtin_amdgcn_s_memtime() - pr_t0); atomicAdd(&p.cnt->nbr, pr_rounds);
+                   atomicAdd(&p.cnt->deckey, pr_mark); atomicMax(&p.cnt->pruned, __builtin_amdgcn_s_memtime() - pr_t0); }
+#endif
   if (k == 0) {
     p.slot_epoch[slot] = epoch;
     atomicAdd(&p.cnt->steps, steps_tot); atomicAdd(&p.cnt->candidates, cand_tot); atomicAdd(&p.cnt->path_cells, cells_tot);
