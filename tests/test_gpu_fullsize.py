@@ -228,3 +228,57 @@ def test_cfg5_maaco_and_astar_8192_per_gpu_1024():
         return float(np.sqrt((d * d).sum(1).astype(np.float64)).sum())
     for a in np.flatnonzero(st0 == 0)[:512]:
         assert abs(plen_of(p0[a]) - plen_of(p1[a])) < 1e-6, a
+
+
+def test_maaco_one_pass_update_equals_three_kernel_form_and_numpy_at_512():
+    """maaco512 at its bench size: the iteration entry (in-walk marking into the stretch-blocked, flagged bit matrix, one-pass
+    k_tau_update with its dense / sparse word forms) against (a) the three-kernel form the sharded fold uses, on a second
+    handle, and (b) MAACO.py:304-332 restated in numpy over the downloaded paths: per cell the deposits of the visiting
+    ants added one by one in ant order.  Three iterations, so marks, flags and tau carry over."""
+    import pathfit
+    from pathfit import env
+    g = env.bench_grid(512)
+    R = C = 512
+    N = 16384
+    kw = dict(alpha=1.0, beta=7.0, rho=0.1, Q=2.5, a_turn_coef=1.0, wh_max=0.9, wh_min=0.2, k_h_adaptive=0.9, q0_initial=0.5)
+    m1 = pathfit.MAACO(g, N, 100, C0_initial_pheromone=0.1, seed=5, **kw)
+    m2 = pathfit.MAACO(g, N, 100, C0_initial_pheromone=0.1, seed=5, **kw)
+    tau_np = np.array(m1.pheromone_matrix, np.float64).reshape(-1)
+    best = (float("inf"), float("inf"))
+    for it in (1, 2, 3):
+        m1.iterate_dev(it)
+        # (a) the same iteration in separate steps on the other handle
+        m2.walk_iteration_dev(it)
+        dc, dl, dp, dt, ds = m2.walk_bufs()
+        ib_len, ib_turns, ib_idx = m2.engine.maaco_best_dev(N, dp, dt)
+        if ib_len < best[0]:
+            best = (ib_len, ib_turns)
+        elif abs(ib_len - best[0]) < 1e-9 and ib_turns < best[1]:
+            best = (best[0], ib_turns)
+        m2.engine.maaco_evaporate()
+        m2.engine.maaco_deposit(N, m2.path_cap, dc, dl, dp)
+        m2.engine.maaco_clip(best[0])
+        t1, t2 = np.asarray(m1.pheromone_matrix), np.asarray(m2.pheromone_matrix)
+        assert np.array_equal(t1, t2), it
+        assert m1.best_path_length_overall == best[0]
+        # (b) numpy, cell by cell in ant order (a cell is visited at most once per ant)
+        cells, lens, plen = dc.download().reshape(N, -1), dl.download(), dp.download()
+        tau_np = tau_np * (1.0 - kw["rho"])
+        good = np.flatnonzero((lens > 0) & np.isfinite(plen) & (plen > 1e-6))
+        ants = np.repeat(good, lens[good])
+        flat = np.concatenate([cells[a, :lens[a]] for a in good]).astype(np.int64)
+        order = np.lexsort((ants, flat))                                  # by cell, then by ant
+        flat, dep = flat[order], (kw["Q"] / plen)[ants[order]]
+        starts = np.flatnonzero(np.r_[True, flat[1:] != flat[:-1]])
+        ends = np.r_[starts[1:], flat.size]
+        rank = np.arange(flat.size) - np.repeat(starts, ends - starts)    # position of a deposit within its cell
+        o2 = np.argsort(rank, kind="stable")
+        flat, dep = flat[o2], dep[o2]
+        cut = np.r_[0, np.cumsum(np.bincount(rank))]
+        for k in range(cut.size - 1):                                     # round k: every cell's k-th deposit, one add each
+            tau_np[flat[cut[k]:cut[k + 1]]] += dep[cut[k]:cut[k + 1]]
+        bl = best[0] if np.isfinite(best[0]) else float(R + C)
+        tmax = (1.0 / (1.0 - kw["rho"])) * (1.0 / max(bl, 1e-6))
+        tmin = tmax / (2.0 * max(R, C))
+        tau_np = np.where(g.reshape(-1) == 1, 1e-9, np.minimum(np.maximum(tau_np, tmin), tmax))
+        assert np.array_equal(t1.reshape(-1), tau_np), it
