@@ -135,7 +135,7 @@ PF_DEV int count_key_lt(int acc, double f1, double g1, int c1, double f2, double
                : [c1] "v"(c1), [c2] "v"(c2), [gl1] "v"(__double2loint(g1)), [gl2] "v"(__double2loint(g2)), [gh1] "v"(__double2hiint(g1)),
                  [gh2] "v"(__double2hiint(g2)), [fl1] "v"(__double2loint(f1)), [fl2] "v"(__double2loint(f2)), [fh1] "v"(__double2hiint(f1)),
                  [fh2] "v"(__double2hiint(f2)), [en] "s"(en)
-               : "vcc");
+               : "vcc", "scc");                                  // (s_and_b64 writes SCC: a scalar compare must not be kept live across this)
   return acc;
 }
 #ifndef PF_SORT_UNROLL
