@@ -259,3 +259,21 @@ def test_sharded_mpa_two_ranks_equals_single(tmp_path):
     for it in range(1, 13):
         m.step(it)
     assert np.array_equal(m.d_stats.download()[m.order], ref_stats[sm.gorder])
+
+
+def test_maaco_engine_reused_with_other_ant_counts_and_abandoned_marks():
+    """One engine, several colonies in a row with different ant counts (the deposit bit matrix and its chunk flags keep the
+    capacity of the largest; a smaller colony uses a prefix of every stretch's words), one of them abandoned after a walk
+    that marked its deposits but never updated: each colony must still equal the oracle's loop bit for bit."""
+    import pathfit, pf_oracle as po, pf_loops
+    g, s, t = gio.grid("fig7")
+    kw = dict(alpha=1.0, beta=7.0, rho=0.1, Q=2.5, a_turn_coef=1.0, wh_max=0.9, wh_min=0.2, k_h_adaptive=0.9, q0_initial=0.5)
+    eng = pathfit.Engine(g)
+    for n_ants, iters, abandon in ((200, 3, False), (70, 4, True), (130, 3, False), (64, 2, False), (1, 3, False), (333, 2, False)):
+        m = pathfit.MAACO(g, n_ants, iters, C0_initial_pheromone=0.1, seed=11, engine=eng, **kw)
+        path, length, turns = m.solve_path_planning()
+        ref = pf_loops.maaco_solve(po.Oracle(g), s, t, n_ants, iters, C0=0.1, seed=11, **kw)
+        assert [r * 20 + c for r, c in path] == list(ref["path"]) and length == ref["length"] and turns == ref["turns"], n_ants
+        assert np.array_equal(m.pheromone_matrix, ref["tau"]), n_ants
+        if abandon:
+            m.walk_iteration_dev(iters + 1)          # marks made, no update: the next colony must not see them
