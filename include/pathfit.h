@@ -174,7 +174,7 @@ int pf_maaco_update(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_
                     double best_len_overall);
 /* One whole iteration of MAACO.solve_path_planning (MAACO.py:340-359) for the ants of one GPU, enqueued back to back: walks,
  * best-of-iteration scan (:343-349), take-over test against the caller's overall best (:351-358), one-pass pheromone update.
- * ONE 104-byte copy comes back: out13 = {ib_len, ib_turns, ib_idx, took, best_len, best_turns, tmin, tmax, skipped, steps,
+ * ONE 104-byte block comes back: out13 = {ib_len, ib_turns, ib_idx, took, best_len, best_turns, tmin, tmax, skipped, steps,
  * candidates, path_cells, overflow_agents}.  overflow_agents > 0: the pheromone was left untouched (skipped = 1); repeat
  * the call with longer path rows.  The call returns once the take-over test is known (the device mirrors out13 into pinned
  * host memory; no copy is enqueued); the pheromone update may still be running -- every later pf_ call on this handle is

@@ -297,7 +297,8 @@ class Engine:
         self._ck(self.L.pf_maaco_update(self.h, n, path_cap, d_cells.ptr, d_len.ptr, d_plen.ptr, float(best_len_overall)))
 
     def maaco_iterate(self, it, seed, ant0, n, path_cap, d_cells, d_len, d_plen, d_turns, d_status, best_len, best_turns):
-        """One whole iteration (walks, best scan, take-over test, pheromone update) enqueued back to back; one 104-byte copy back.
+        """One whole iteration (walks, best scan, take-over test, pheromone update) enqueued back to back; one 104-byte block back
+        (mirrored by the device into pinned host memory: the call returns once the take-over test is known).
         -> dict(ib_len, ib_turns, ib_idx, took, best_len, best_turns, skipped, overflow_agents)."""
         out = self._out13
         self._ck(self.L.pf_maaco_iterate(self.h, int(it), int(seed), int(ant0), int(n), int(path_cap), d_cells.ptr, d_len.ptr, d_plen.ptr,
