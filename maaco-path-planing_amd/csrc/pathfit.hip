@@ -729,7 +729,7 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
   int* out = p.cells;
   bool need = true, alive = true;
 #ifdef PF_WALK_PROBE
-  unsigned long long pr_wait = 0, pr_rounds = 0, pr_mark = 0; const unsigned long long pr_t0 = __builtin_amdgcn_s_memtime();
+  unsigned long long pr_wait = 0, pr_rounds = 0, pr_mark = 0, pr_sel0 = 0, pr_sel1 = 0, pr_head = 0, pr_emit = 0, pr_upd = 0, pr_loop = 0, pr_end = 0, pr_act = 0; const unsigned long long pr_t0 = __builtin_amdgcn_s_memtime();
 #endif
   while (__ballot(alive)) {
     if (alive && need) {                                           // fetch + initialise the next ant of this group
@@ -758,6 +758,11 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
       }
     }
     bool done = alive && ((cr == tr && cc == tc) || steps >= max_steps);
+#ifdef PF_WALK_PROBE
+    __builtin_amdgcn_sched_barrier(0); const unsigned long long pr_r0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+    bool pr_stepped = false; unsigned long long pr_u0 = 0;
+    if (pr_end) pr_loop += pr_r0 - pr_end;
+#endif
     if (alive && !done) {
       const int cur = cr * C + cc;
       const int nr = cr + mdr, nc = cc + mdc;
@@ -773,6 +778,7 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
       const uint64_t w1 = g.peek64(1), w2 = g.peek64(2);
 #ifdef PF_WALK_PROBE
       __builtin_amdgcn_sched_barrier(0); const unsigned long long pr_ta = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+      pr_head += pr_ta - pr_r0; pr_stepped = true; pr_act += 1;   // (per-lane copies: lane 0 reports, so the in-step stamps cover the rounds in which group 0 stepped)
 #endif
       if (inb) {
         vw = tl.patch(widx, visit[widx]);
@@ -802,6 +808,10 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
         const double q = Rng::to_unit(w1);                          // :232
         const double attr = cmine ? tv * ev : 0.0;                  // :238; the other lanes add an exact zero to the ordered sums below
         int pick = 0;
+#ifdef PF_WALK_PROBE
+        __builtin_amdgcn_sched_barrier(0); const unsigned long long pr_s0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+        pr_sel0 += pr_s0 - pr_ta;
+#endif
         if (q <= p.q0) {
           // :241-250, the running maximum with its absolute tolerance, in closed form: the tie set restarts at the FIRST
           // occurrence of the maximum M (`attr > max` drops every earlier member there) and from then on collects the
@@ -839,6 +849,10 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
             pick = gnth8(cand, idx, k);
           }
         }
+#ifdef PF_WALK_PROBE
+        int t_ = pick; asm volatile("" : "+v"(t_)); __builtin_amdgcn_sched_barrier(0); const unsigned long long pr_s1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+        pr_sel1 += pr_s1 - pr_s0; pr_u0 = pr_s1;
+#endif
         if (!done) {
           plen += ((0xA5u >> pick) & 1u) ? PF_SQRT2 : 1.0;         // :293 (moves 0, 2, 5, 7 are the diagonals)
           if (prev_k >= 0 && pick != prev_k) nturn += 1;
@@ -856,6 +870,10 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
         }
       }
     }
+#ifdef PF_WALK_PROBE
+    __builtin_amdgcn_sched_barrier(0); const unsigned long long pr_e0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+    if (pr_u0) pr_upd += pr_e0 - pr_u0;
+#endif
     if (alive && done) {                                            // emit, then fetch a new ant next round
       if (rc == 0 && !(cr == tr && cc == tc)) rc = 2;               // :301-302 step cap
       steps_tot += (unsigned long long)steps;
@@ -869,7 +887,7 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
       need = true;
     }
 #ifdef PF_WALK_PROBE
-    pr_rounds += 1; const unsigned long long pr_m0 = __builtin_amdgcn_s_memtime();
+    pr_rounds += 1; const unsigned long long pr_m0 = __builtin_amdgcn_s_memtime(); pr_emit += pr_m0 - pr_e0;
 #endif
     if (p.bits) {
       // the ants that finished in this round mark their deposits: the WHOLE wave walks each finished path (64 cells a round;
@@ -900,18 +918,22 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
       }
     }
 #ifdef PF_WALK_PROBE
-    pr_mark += __builtin_amdgcn_s_memtime() - pr_m0;
+    pr_end = __builtin_amdgcn_s_memtime(); pr_mark += pr_end - pr_m0;
 #endif
   }
 #ifdef PF_WALK_PROBE
   // (diagnostic build: wave clocks in the counters the MAACO path leaves unused -- scripts/probe_walk_split.py)
   if (lane == 0) { atomicAdd(&p.cnt->pops, pr_wait); atomicAdd(&p.cnt->pushes, __builtin_amdgcn_s_memtime() - pr_t0); atomicAdd(&p.cnt->nbr, pr_rounds);
-                   atomicAdd(&p.cnt->deckey, pr_mark); atomicMax(&p.cnt->pruned, __builtin_amdgcn_s_memtime() - pr_t0); }
+                   atomicAdd(&p.cnt->deckey, pr_mark); atomicMax(&p.cnt->pruned, __builtin_amdgcn_s_memtime() - pr_t0);
+                   atomicAdd(&p.cnt->settled, pr_sel0); atomicAdd(&p.cnt->sequential, pr_sel1);
+                   atomicAdd(&p.cnt->candidates, pr_head); atomicAdd(&p.cnt->path_cells, pr_act); (void)pr_emit; atomicAdd(&p.cnt->steps, pr_upd); atomicAdd(&p.cnt->overflow, pr_loop); }
 #endif
   if (k == 0) {
     p.slot_epoch[slot] = epoch;
-    atomicAdd(&p.cnt->steps, steps_tot); atomicAdd(&p.cnt->candidates, cand_tot); atomicAdd(&p.cnt->path_cells, cells_tot);
+#ifndef PF_WALK_PROBE
+    atomicAdd(&p.cnt->candidates, cand_tot); atomicAdd(&p.cnt->path_cells, cells_tot); atomicAdd(&p.cnt->steps, steps_tot);
     if (ovf_tot) atomicAdd(&p.cnt->overflow, ovf_tot);
+#endif
   }
 }
 

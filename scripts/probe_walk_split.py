@@ -18,5 +18,10 @@ for it in (1, 2, 3):
     c = m.engine.counters()
     waves = (N + 7) // 8
     rounds, total, wait, mark, longest = c["nbr_examined"], c["pushes"], c["pops"], c["decrease_keys"], c["pruned_rebuilds"]
-    print(f"it {it}: kernel {m.engine.last_kernel_ms():.3f} ms; {waves} wavefronts, {rounds / waves:.0f} rounds each, longest wavefront {longest} clocks; "
-          f"per round: {total / rounds:.0f} clocks = wait for the loads {wait / rounds:.0f} + marking {mark / rounds:.0f} + rest {(total - wait - mark) / rounds:.0f}", flush=True)
+    act = max(c["path_cells"], 1)          # rounds in which group 0 of a wavefront stepped: the in-step stamps are lane 0's
+    sel0, sel1, head, upd, loop = c["settled_searches"], c["sequential_searches"], c["candidates"], c["steps"], c["overflow_agents"]
+    step = (head + sel0 + sel1 + upd) / act
+    print(f"it {it}: kernel {m.engine.last_kernel_ms():.3f} ms; {waves} wavefronts, {rounds / waves:.0f} rounds each, longest wavefront {longest} clocks, {total / rounds:.0f} clocks per round")
+    print(f"   a step ({step:.0f}): cell / addresses / move mask {head / act:.0f}; issue of the three loads + wait {wait / act:.0f}; candidate masks, RNG, q {(sel0 - wait) / act:.0f}; "
+          f"selection (greedy and roulette branches) {sel1 / act:.0f}; move, tabu word, path store {upd / act:.0f}")
+    print(f"   around it, per round: marking of finished paths {mark / rounds:.0f}; loop test + fetch test {loop / rounds:.0f}; emit + stamps {total / rounds - step - (mark + loop) / rounds:.0f}", flush=True)
