@@ -874,7 +874,9 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
     __builtin_amdgcn_sched_barrier(0); const unsigned long long pr_e0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
     if (pr_u0) pr_upd += pr_e0 - pr_u0;
 #endif
-    if (alive && done) {                                            // emit, then fetch a new ant next round
+    // an ant finishes in about one round of a hundred: everything that only a finished ant needs sits behind ONE wave-uniform test
+    const bool any_fin = __ballot(alive && done) != 0ull;
+    if (any_fin && alive && done) {                                 // emit, then fetch a new ant next round
       if (rc == 0 && !(cr == tr && cc == tc)) rc = 2;               // :301-302 step cap
       steps_tot += (unsigned long long)steps;
       if (k == 0) {
@@ -889,7 +891,7 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
 #ifdef PF_WALK_PROBE
     pr_rounds += 1; const unsigned long long pr_m0 = __builtin_amdgcn_s_memtime(); pr_emit += pr_m0 - pr_e0;
 #endif
-    if (p.bits) {
+    if (any_fin && p.bits) {
       // the ants that finished in this round mark their deposits: the WHOLE wave walks each finished path (64 cells a round;
       // the other groups would only wait for a group that marked alone, 8 cells a round)
       const bool fin = alive && done;
