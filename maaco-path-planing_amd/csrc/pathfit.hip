@@ -780,10 +780,13 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
       __builtin_amdgcn_sched_barrier(0); const unsigned long long pr_ta = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
       pr_head += pr_ta - pr_r0; pr_stepped = true; pr_act += 1;   // (per-lane copies: lane 0 reports, so the in-step stamps cover the rounds in which group 0 stepped)
 #endif
-      if (inb) {
-        vw = tl.patch(widx, visit[widx]);
+      {
+        // unconditional loads (a move that leaves the map reads cell 0 and is rejected by `inb` below): a branch around them costs
+        // a scalar round trip on the mask, and loads under a branch keep the compiler from counting them
+        const int widx_c = inb ? widx : 0, nidx_c = inb ? nidx : 0;
+        vw = tl.patch(widx_c, visit[widx_c]);
         // one divergent vector load less per step: tau and eta'[turn] in one
-        const pf_d2u te = *(const pf_d2u*)(p.tep + (size_t)nidx * 3 + turn);
+        const pf_d2u te = *(const pf_d2u*)(p.tep + (size_t)nidx_c * 3 + turn);
         tv = turn ? te.x : te.y; ev = turn ? te.y : te.x;
       }
 #ifdef PF_WALK_PROBE
@@ -859,13 +862,15 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
           prev_k = pick;
           cr += (int)((0xA940u >> (2 * pick)) & 3u) - 1;            // AM_DR[pick] + 1, two bits a move
           cc += (int)((0x9224u >> (2 * pick)) & 3u) - 1;            // AM_DC[pick] + 1
-          if (n >= p.path_cap) { rc = 3; done = true; }
-          else {
+          {
+            // a full path row (rc 3) is the exception: predicated, not a branch of its own
+            const bool ovf = n >= p.path_cap;
+            rc = ovf ? 3 : rc; done = ovf;
             const int wi = cr * WPR + (cc >> 4);                   // = lane `pick`'s word, which it holds up to date
             const unsigned wv = tabu_set((unsigned)gbcast8_i((int)vw, pick), epoch, cc);
-            if (k == 0) { out[n] = cr * C + cc; visit[wi] = wv; }
-            tl.stored(wi, wv);
-            n += 1; steps += 1;
+            if (k == 0 && !ovf) { out[n] = cr * C + cc; visit[wi] = wv; }
+            if (!ovf) tl.stored(wi, wv);
+            n += ovf ? 0 : 1; steps += ovf ? 0 : 1;
           }
         }
       }
