@@ -391,7 +391,7 @@ __global__ void k_pso_update(PsoArgs p) {
   if (t >= p.n * p.W) return;
   const int part = t / p.W, d = t - part * p.W;
   Rng g; g.init(p.seed, DOM_PSO, p.iter, p.agent0 + (unsigned long long)part);
-  g.ctr = 4ull * (unsigned long long)d;
+  g.set_ctr(4ull * (unsigned long long)d);
   for (int ax = 0; ax < 2; ++ax) {
     const size_t i = ((size_t)part * p.W + d) * 2 + ax;
     const double hi = ax == 0 ? (double)(p.R - 1) : (double)(p.C - 1);
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
   int a = -1, cr = 0, cc = 0, n = 0, prev_k = -1, nturn = 0, rc = 0;
   long long steps = 0;
   double plen = 0.0;
-  Rng g; g.key = 0; g.ctr = 0;
+  Rng g; g.key = 0; g.ctr = 0; g.kc = 0;
   int* out = p.cells;
   bool need = true, alive = true;
 #ifdef PF_WALK_PROBE
@@ -807,7 +807,7 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
         const int ncand = __builtin_popcount(cand);
         cand_tot += ncand;
         const bool cmine = (cand >> k) & 1u;
-        g.ctr += 2;
+        g.advance(2);
         const double q = Rng::to_unit(w1);                          // :232
         const double attr = cmine ? tv * ev : 0.0;                  // :238; the other lanes add an exact zero to the ordered sums below
         int pick = 0;

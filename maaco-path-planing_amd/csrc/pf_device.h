@@ -127,15 +127,19 @@ PF_DEV uint64_t mix64(uint64_t z) {
 }
 struct Rng {
   uint64_t key, ctr;
+  uint64_t kc;      // key + ctr * GOLDEN, kept by addition: word i of the stream is mix64(key + i * GOLDEN), and a 64-bit multiply per draw
+                    // (four quarter-rate 32-bit multiplies) is what the counter form costs
   PF_DEV void init(uint64_t seed, uint64_t dom, uint64_t it, uint64_t agent) {
     uint64_t k = mix64(seed + 0x9E3779B97F4A7C15ULL * (dom + 1));
     k = mix64(k + 0xD1B54A32D192ED03ULL * (it + 1));
     k = mix64(k + 0x8CB92BA72F3D8DD7ULL * (agent + 1));
-    key = k; ctr = 0;
+    key = k; ctr = 0; kc = k;
   }
-  PF_DEV uint64_t next64() { ctr += 1; return mix64(key + ctr * 0x9E3779B97F4A7C15ULL); }
-  // the word `ahead` draws from now, without consuming it (callers that mix ahead of a decision advance ctr themselves)
-  PF_DEV uint64_t peek64(uint64_t ahead) const { return mix64(key + (ctr + ahead) * 0x9E3779B97F4A7C15ULL); }
+  PF_DEV void set_ctr(uint64_t c) { ctr = c; kc = key + c * 0x9E3779B97F4A7C15ULL; }
+  PF_DEV void advance(uint64_t n) { ctr += n; kc += n * 0x9E3779B97F4A7C15ULL; }   // (n is a literal at every call site)
+  PF_DEV uint64_t next64() { ctr += 1; kc += 0x9E3779B97F4A7C15ULL; return mix64(kc); }
+  // the word `ahead` draws from now, without consuming it (callers that mix ahead of a decision advance() themselves)
+  PF_DEV uint64_t peek64(uint64_t ahead) const { return mix64(kc + ahead * 0x9E3779B97F4A7C15ULL); }
   static PF_DEV double to_unit(uint64_t w) { return (double)(w >> 11) * (1.0 / 9007199254740992.0); }
   PF_DEV double random() { return to_unit(next64()); }
   // random.py _randbelow_with_getrandbits (n >= 1): draws even when n == 1
