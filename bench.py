@@ -271,28 +271,46 @@ def launch_ranks(n, argv, worker=None, env_extra=None, timeout=None):
     Returns (exit code, the JSON line or None)."""
     import subprocess
     cmd = list(worker) if worker else [sys.executable, os.path.abspath(__file__)]
-    port = _free_port()
+    port, retry_port = _free_port(), _free_port()
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PF_BENCH_RETRY_PORT=str(retry_port))
         env.update(env_extra or {})
         procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
     line, rcs = None, []
     t_end = None if timeout is None else time.monotonic() + timeout
+    # rank 0's stdout is drained by a thread while ALL ranks are polled: a rank that dies at import or in init_process_group ends the
+    # run at once (the survivors are killed) instead of leaving rank 0 inside torch's rendezvous until its own 10-30 minute timeout
+    import threading
+    out0 = []
+    rd = threading.Thread(target=lambda: out0.extend(procs[0].stdout.readlines()), daemon=True)
+    rd.start()
     try:
-        out0, _ = procs[0].communicate(timeout=timeout)
-        for ln in out0.splitlines():
-            if ln.startswith("{") and '"metric"' in ln:
-                line = ln
-        for pr in procs:
-            rcs.append(pr.wait(timeout=None if t_end is None else max(1.0, t_end - time.monotonic())))
-    except subprocess.TimeoutExpired:
-        rcs = [124]
+        while True:
+            codes = [pr.poll() for pr in procs]
+            if any(c not in (None, 0) for c in codes) or all(c is not None for c in codes):
+                break
+            if t_end is not None and time.monotonic() > t_end:
+                codes = [124 if c is None else c for c in codes]
+                break
+            time.sleep(0.05)
+        failed = [c for c in codes if c not in (None, 0)]
+        # a rank still running when another one failed is killed below and reported as -9; the failing rank's own code comes first
+        rcs = failed[:1] + [(-9 if c is None else c) for c in codes] if failed else list(codes)
     finally:
         for pr in procs:                      # exactly the processes started here, by pid
             if pr.poll() is None:
                 pr.kill()
+        for pr in procs:
+            try:
+                pr.wait(timeout=10)
+            except Exception:
+                pass
+    rd.join(timeout=10)
+    for ln in out0:
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln.rstrip("\n")
     if any(rc != 0 for rc in rcs):
         print(f"[bench launcher] rank exit codes {rcs}", file=sys.stderr)
         return (next(rc for rc in rcs if rc != 0) or 1), line
@@ -314,11 +332,22 @@ def _retry_host_staged(a):
     be used again.  Every rank reached the same verdict (attach_checked all-reduces it), so every rank starts ONE fresh child
     process of itself with PF_BENCH_TRANSPORT=torch on the next port, relays its output and exits with its code."""
     import subprocess
-    env = dict(os.environ, PF_BENCH_TRANSPORT="torch", PF_BENCH_RETRIED="1",
-               MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 1))
-    rc = subprocess.call([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env)
+    # (a fresh child process, never a re-exec: this process has initialised the GPU)
+    rc = subprocess.call([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=retry_env(os.environ))
     sys.stdout.flush(); sys.stderr.flush()
     os._exit(rc)              # (the stuck thread would hold a normal interpreter exit up)
+
+
+def retry_env(environ):
+    """Environment of the host-staged retry child.  Every rank derives the SAME rendezvous port from the original one
+    (PF_BENCH_RETRY_PORT if the launcher reserved one, else MASTER_PORT + 1), and everything torch.distributed.run's agent
+    left behind is dropped: with TORCHELASTIC_USE_AGENT_STORE=True inherited, every rank -- rank 0 included -- would connect
+    to the agent's store as a CLIENT on the new port, where nobody listens.  Without it rank 0 hosts the store itself."""
+    env = {k: v for k, v in environ.items() if not k.startswith("TORCHELASTIC_") and k != "TORCH_NCCL_ASYNC_ERROR_HANDLING"}
+    port = environ.get("PF_BENCH_RETRY_PORT") or str(int(environ.get("MASTER_PORT", "29500")) + 1)
+    env.update(PF_BENCH_TRANSPORT="torch", PF_BENCH_RETRIED="1", MASTER_PORT=str(port), MASTER_ADDR=environ.get("MASTER_ADDR", "127.0.0.1"))
+    env.pop("PF_BENCH_RETRY_PORT", None)
+    return env
 
 
 def main():
@@ -340,9 +369,9 @@ def main():
     ap.add_argument("--cpu-worker", default="", help=argparse.SUPPRESS)   # internal: "workload:lo:hi" slice for the all-cores CPU leg
     a = ap.parse_args()
     if a.cpu_worker:                                                       # a child of cpu_baseline(): no GPU, no torch
-        wl, lo, hi = a.cpu_worker.split(":")
+        wl, lo, hi, k_ = a.cpu_worker.split(":")
         from pathfit import env as env_
-        print(json.dumps(_cpu_slice(wl, env_.bench_grid(gsize_of(wl)), a.seed, int(lo), int(hi), a.cpu_seconds)), flush=True)
+        print(json.dumps(_cpu_slice(wl, env_.bench_grid(gsize_of(wl)), a.seed, int(lo), int(hi), a.cpu_seconds, K=int(k_))), flush=True)
         return
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:                      # not under torchrun: start the N ranks ourselves
         rc, line = launch_ranks(a.gpus, sys.argv[1:])
@@ -432,7 +461,11 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu:      # the CPU baseline is an N=1 figure (the other ranks would only wait for it)
-        cpu = cpu_baseline(a.workload, grid, a.seed, a.cpu_seconds)
+        check = os.environ.get("PF_BENCH_CHECK") == "1"
+        kept = [] if check else None
+        cpu = cpu_baseline(a.workload, grid, a.seed, a.cpu_seconds, K=max(K, 1), keep=kept)
+        if check:       # the oracle's sample is not thrown away: it must BE what the device computes for the same agents
+            cpu["checked_against_device"] = check_sample(a.workload, grid, eng, a.seed, max(K, 1), kept)
 
     extra = None
     if world == 1 and rank == 0 and a.workload == "mpa512" and not a.no_extra and not a.agents:
@@ -467,6 +500,41 @@ def main():
         dist.destroy_process_group()
 
 
+def check_sample(workload, grid, eng, seed, K, kept):
+    """PF_BENCH_CHECK=1: the agents the cpu_baseline leg evaluated with the oracle (iteration 1 of the same workload, same seed and
+    parameters) against a fresh device instance's iteration 1 -- fitness / length bit for bit, paths by length and crc32.
+    Raises on the first mismatch; returns how many agents were compared.  (The checker reads the product's result, never the
+    other way round.)"""
+    import zlib
+    import pathfit
+    if not kept:
+        return 0
+    if workload == "mpa512":
+        m = pathfit.MPA(grid, 4096, K, engine=eng, seed=seed, **MPA_MAIN)
+        m._sort()
+        order = m.order.copy()
+        m.step(1)
+        cells, lens, stats = m.d_cells.download(), m.d_len.download(), m.d_stats.download()
+        for n, fit, ln, crc in kept:
+            sl = order[n]
+            got = (float(stats[sl, 4]), int(lens[sl]), zlib.crc32(np.ascontiguousarray(cells[sl, :lens[sl]], np.int32).tobytes()))
+            if got != (fit, ln, crc):
+                raise AssertionError(f"PF_BENCH_CHECK: predator {n} of iteration 1: device {got} != oracle {(fit, ln, crc)}")
+    elif workload.startswith("maaco"):
+        n_ants = CPU_TOTAL[workload]
+        m = pathfit.MAACO(grid, n_ants, 100, engine=eng, seed=seed, **MAACO_MAIN)
+        m.iterate_dev(1)
+        dc, dl, dp, _, _ = m.walk_bufs()
+        cells, lens, plen = dc.download().reshape(n_ants, -1), dl.download(), dp.download()
+        for n, L, ln, crc in kept:
+            got = (float(plen[n]), int(lens[n]), zlib.crc32(np.ascontiguousarray(cells[n, :lens[n]], np.int32).tobytes()))
+            if got != (L, ln, crc):
+                raise AssertionError(f"PF_BENCH_CHECK: ant {n} of iteration 1: device {got} != oracle {(L, ln, crc)}")
+    else:
+        return 0
+    return len(kept)
+
+
 CPU_TOTAL = {"mpa512": 4096, "maaco128": 256, "maaco512": 16384, "maaco1024": 8192, "astar1024": 8192, "ga512": 2048, "pso512": 2048}
 
 
@@ -484,59 +552,79 @@ def cpu_info():
     return {"model": model, "hardware_concurrency": os.cpu_count(), "usable_cores": usable}
 
 
-def _cpu_slice(workload, grid, seed, lo, hi, budget_s):
+CPU_MIN_SECONDS = 0.5      # a sample shorter than this is below timer / start-up noise: small workloads wrap around until it is reached
+
+
+def _cpu_slice(workload, grid, seed, lo, hi, budget_s, K=15, keep=None):
     """Agents [lo, hi) of the workload's first step on the CPU oracle (the C port of the reference's algorithm; checker
-    code), at most budget_s seconds -> {count, seconds, what}."""
+    code), at most budget_s seconds -> {count, seconds, what}.  A slice that is done in less than CPU_MIN_SECONDS starts over
+    (the same agents again) until that much time has passed, so that no rate is quoted from a few milliseconds.  `keep`
+    (a list) receives, for the agents of the FIRST pass, what PF_BENCH_CHECK=1 compares with the device: (agent, fitness,
+    path length, crc32 of the cell path)."""
+    import zlib
     import pf_oracle as po
     import pf_loops
     orc = po.Oracle(grid)
     s, t = 0, grid.size - 1
-    n = lo
+    span = hi - lo
+
+    def loop(fn):
+        k = 0
+        t0 = time.perf_counter()
+        while span > 0:
+            el = time.perf_counter() - t0
+            if el >= budget_s or (k >= span and el >= CPU_MIN_SECONDS):
+                break
+            fn(lo + k % span, k < span)
+            k += 1
+        return k, time.perf_counter() - t0
+
     if workload == "mpa512":
-        ref = pf_loops.MpaOracle(orc, s, t, 4096, 15, FADs_rate=0.2, P_const=0.5, levy_beta=2.0, w_turn=0.1, w_safe=0.8,
+        ref = pf_loops.MpaOracle(orc, s, t, 4096, K, FADs_rate=0.2, P_const=0.5, levy_beta=2.0, w_turn=0.1, w_safe=0.8,
                                  min_safe=1.8, diag_pen=100.0, seed=seed)
         ref._sort()
         elite = ref.pop[0]
-        CF = (1.0 - 1 / 15) ** (2.0 / 15)
-        t0 = time.perf_counter()
-        while time.perf_counter() - t0 < budget_s and n < hi:
+        CF = (1.0 - 1 / K) ** (2.0 / K)
+
+        def one(n, first):
             cand = ref.phase_candidate(1, n, elite, CF)
             ind = cand if cand[1][4] < ref.pop[n][1][4] else ref.pop[n]
-            ref.fads(1, n, ind, CF)
-            n += 1
-        what = "predators of iteration 1 (phase sweep + memory + FADs)"
+            ind = ref.fads(1, n, ind, CF)
+            if keep is not None and first:
+                keep.append((n, float(ind[1][4]), int(len(ind[0])), zlib.crc32(np.ascontiguousarray(ind[0], np.int32).tobytes())))
+        what = f"predators of iteration 1 of a {K}-iteration run (phase sweep + memory + FADs)"
     elif workload.startswith("maaco"):
         P = po.MaacoParams(alpha=1.0, beta=7.0, rho=0.1, Q=2.5, a_turn=1.0, wh_max=0.9, wh_min=0.2, k_h=0.9, q0_initial=0.5,
                            C0=0.1, num_iterations=100)
         tau, dist = orc.maaco_init(s, t, 0.1)
-        t0 = time.perf_counter()
-        while time.perf_counter() - t0 < budget_s and n < hi:
-            orc.maaco_walk(s, t, P, tau, dist, 1, seed, n)
-            n += 1
+
+        def one(n, first):
+            p, L, _, _ = orc.maaco_walk(s, t, P, tau, dist, 1, seed, n)
+            if keep is not None and first:
+                keep.append((n, float(L), int(len(p)), zlib.crc32(np.ascontiguousarray(p, np.int32).tobytes())))
         what = "ant walks of iteration 1"
     elif workload == "astar1024":
         rng = np.random.default_rng(seed)
         free = np.flatnonzero(grid.reshape(-1) != 1)
         ss, tt = rng.choice(free, 8192), rng.choice(free, 8192)
-        t0 = time.perf_counter()
-        while time.perf_counter() - t0 < budget_s and n < hi:
+
+        def one(n, first):
             orc.astar(int(ss[n]), int(tt[n]), None, 0)
-            n += 1
         what = "pairs (AStarSolver connector)"
     else:
         rng = np.random.default_rng(seed)
         free = np.flatnonzero(grid.reshape(-1) != 1)
         wp = rng.choice(free, (2048, 5)).astype(np.int32)
-        t0 = time.perf_counter()
-        while time.perf_counter() - t0 < budget_s and n < hi:
+
+        def one(n, first):
             p, _ = orc.decode(s, t, wp[n])
             orc.score(p, 0, 0.3, 0.8, 1.8, True, 100.0)
-            n += 1
         what = "chromosomes (W=5 decode + score)"
-    return {"count": n - lo, "seconds": time.perf_counter() - t0, "what": what}
+    count, secs = loop(one)
+    return {"count": count, "seconds": secs, "what": what, "wrapped": count > span}
 
 
-def _cpu_all_cores(workload, seed, budget_s):
+def _cpu_all_cores(workload, seed, budget_s, K=15):
     """The same sample spread over every host core this process may use: one child process per core (fresh
     interpreters, no GPU), each taking a contiguous slice of the workload's agents."""
     import subprocess
@@ -548,25 +636,28 @@ def _cpu_all_cores(workload, seed, budget_s):
         lo, hi = k * per, min(total, (k + 1) * per)
         if lo >= hi:
             break
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", f"{workload}:{lo}:{hi}", "--seed", str(seed),
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", f"{workload}:{lo}:{hi}:{K}", "--seed", str(seed),
                                        "--cpu-seconds", str(budget_s)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
     tot, secs = 0, 0.0
     for pr in procs:
         out, _ = pr.communicate(timeout=budget_s * 4 + 180)
         r = json.loads(out.strip().splitlines()[-1])
         tot += r["count"]; secs = max(secs, r["seconds"])
-    return {"value": round(tot / secs, 3), "cores": len(procs), "sample": f"{tot} agents in {len(procs)} processes"}
+    return {"value": round(tot / secs, 3), "cores": len(procs), "seconds": round(secs, 2),
+            "sample": f"{tot} evaluations in {len(procs)} processes (each its slice of the agents, repeated while shorter than {CPU_MIN_SECONDS} s)"}
 
 
-def cpu_baseline(workload, grid, seed, budget_s, all_cores=True):
+def cpu_baseline(workload, grid, seed, budget_s, all_cores=True, K=15, keep=None):
     """Time the CPU oracle (the C port of the reference's algorithm; checker code, kind 'port') on a bounded sample of the
     SAME workload: single thread and -- SURVEY.md 8d -- on all host cores, with the CPU model and core counts."""
-    r = _cpu_slice(workload, grid, seed, 0, CPU_TOTAL[workload], budget_s)
+    r = _cpu_slice(workload, grid, seed, 0, CPU_TOTAL[workload], budget_s, K=K, keep=keep)
     out = {"value": round(r["count"] / r["seconds"], 3), "unit": "evals/s", "cores": 1, "kind": "port",
-           "sample": f"first {r['count']} {r['what']}, same grid/params/seed", "seconds": round(r["seconds"], 2), "cpu": cpu_info()}
+           "sample": (f"all {CPU_TOTAL[workload]} {r['what']}, repeated to {r['count']} evaluations (>= {CPU_MIN_SECONDS} s)" if r["wrapped"] else
+                      f"first {r['count']} {r['what']}") + ", same grid/params/seed",
+           "seconds": round(r["seconds"], 2), "cpu": cpu_info()}
     if all_cores:
         try:
-            out["all_cores"] = _cpu_all_cores(workload, seed, min(budget_s, 8.0))
+            out["all_cores"] = _cpu_all_cores(workload, seed, min(budget_s, 8.0), K)
         except Exception as e:                      # the single-core figure stands on its own
             out["all_cores"] = {"error": repr(e)[:200]}
     return out

@@ -256,7 +256,8 @@ int pf_mpa_memory(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_sl
  * (default 2048);
  * "mpa_prune" 0/1 exact bound pruning of MPA rebuilds (default 1); "two_wave" 0/1 MPA._a_star searches (pf_mpa_iter_batch,
  * pf_astar_batch variant 1) on two-wavefront workgroups -- a pop wave and a pool wave, csrc/pf_astar_pr.h -- default 0:
- * identical pops, measured 0.9x; "astar_settle" 0/1 closed-set searches (AStarSolver
+ * identical pops, measured 0.9x; compiled only with -DPF_TWO_WAVE (PF_EXTRA_FLAGS of build.py), otherwise
+ * setting it to 1 is an error; "astar_settle" 0/1 closed-set searches (AStarSolver
  * / Dijkstra / GA / PSO decodes) try the parallel label-settling engine first: -1 (default) the Dijkstra variant
  * always (it is always certified) and the A* searches of the decodes at the head of a batch's longest-first queue
  * ("astar_settle_top", per mille of the batch, default 0 since r03; a decode is a chain of W + 1 searches, so a fallback costs

@@ -3,7 +3,9 @@
     python maaco-path-planing_amd/build.py [--force]
 
 hipcc cross-compiles gfx950 without a GPU; the .so travels to the GPU box with
-the repo snapshot.  -ffp-contract=off: the reference's arithmetic is unfused
+the repo snapshot.  PF_EXTRA_FLAGS adds compiler flags: -DPF_TWO_WAVE compiles the
+two-wavefronts-per-search engine (csrc/pf_astar_pr.h; off by default, measured 0.90x),
+-DPF_TRACE / -DPF_STAMPS / -DPF_WALK_PROBE the diagnostic builds of scripts/.  -ffp-contract=off: the reference's arithmetic is unfused
 IEEE double and bit-exact path parity depends on it.
 """
 import os
@@ -24,7 +26,7 @@ def build(force=False, verbose=False):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
-    cmd = [HIPCC] + FLAGS + ["-o", OUT, SRC]
+    cmd = [HIPCC] + FLAGS + os.environ.get("PF_EXTRA_FLAGS", "").split() + ["-o", OUT, SRC]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -228,6 +228,7 @@ __global__ __launch_bounds__(PR ? 128 : 64) __attribute__((amdgpu_waves_per_eu(P
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = lane_id();
   const int RC = p.c.G.R * p.c.G.C;
+#ifdef PF_TWO_WAVE
   if (PR) {                                                       // two wavefronts per search (pf_astar_pr.h): wave 1 owns the bucket pool
     const int wave = (int)(threadIdx.x >> 6);
     if (wave == 0) pr_init_ctl(smem, lane);
@@ -237,7 +238,12 @@ __global__ __launch_bounds__(PR ? 128 : 64) __attribute__((amdgpu_waves_per_eu(P
       return;
     }
   }
-  PrLink link = pr_link(smem);
+  PrLink link = {};
+  if (PR) link = pr_link(smem);                                   // (single-wave kernels never touch the link's LDS block: it lies beyond their allocation)
+#else
+  static_assert(!PR, "two-wave searches need -DPF_TWO_WAVE");
+  PrLink link = {};
+#endif
   PrLink* const L = &link;
   Open O = make_open(smem, p.c.S, p.c.tier2);
   Slot s = slot_load(p.c, RC);
@@ -275,7 +281,9 @@ __global__ __launch_bounds__(PR ? 128 : 64) __attribute__((amdgpu_waves_per_eu(P
     tot.settled += st.settled; tot.sequential += st.sequential;
     cells += rc == 0 ? n : 0; ovf += rc == 3;
   }
+#ifdef PF_TWO_WAVE
   if (PR) pr_exit(smem, lane);
+#endif
   slot_store(p.c, s, lane);
   flush_counters(p.c.cnt, tot, cells, ovf, lane);
 }
@@ -1683,6 +1691,7 @@ __global__ __launch_bounds__(PR ? 128 : 64) __attribute__((amdgpu_waves_per_eu(3
   const int lane = lane_id();
   const Grid& G = p.c.G;
   const int RC = G.R * G.C;
+#ifdef PF_TWO_WAVE
   if (PR) {
     const int wave = (int)(threadIdx.x >> 6);
     if (wave == 0) pr_init_ctl(smem, lane);
@@ -1692,7 +1701,12 @@ __global__ __launch_bounds__(PR ? 128 : 64) __attribute__((amdgpu_waves_per_eu(3
       return;
     }
   }
-  PrLink link = pr_link(smem);
+  PrLink link = {};
+  if (PR) link = pr_link(smem);
+#else
+  static_assert(!PR, "two-wave searches need -DPF_TWO_WAVE");
+  PrLink link = {};
+#endif
   PrLink* const L = &link;
   Open O = make_open(smem, p.c.S, p.c.tier2);
   Slot s = slot_load(p.c, RC);
@@ -1750,7 +1764,9 @@ __global__ __launch_bounds__(PR ? 128 : 64) __attribute__((amdgpu_waves_per_eu(3
     }
 #endif
   }
+#ifdef PF_TWO_WAVE
   if (PR) pr_exit(smem, lane);
+#endif
   slot_store(p.c, s, lane);
   flush_counters(p.c.cnt, tot, 0, ovf, lane);
 }
@@ -2272,7 +2288,10 @@ float pf_last_kernel_ms(pf_handle* h) { return h ? h->last_ms : 0.0f; }
 // resident agent slots per CU and LDS bin capacity; PF_SLOTS_PER_CU / PF_LDS_S override for experiments
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; }
 static const int kSlotsPerCU = env_int("PF_SLOTS_PER_CU", 8);   // search slots (record / pool scratch) per CU = resident one-agent waves per CU at most
+#ifdef PF_TWO_WAVE
 static int g_two_wave = env_int("PF_TWO_WAVE", 0);   // MPA searches on two-wave workgroups: pop wave + pool wave (pf_astar_pr.h; pf_set_option "two_wave")
+#endif                                               // (the two-wave engine is compiled only with -DPF_TWO_WAVE: measured 0.90x, DESIGN.md 4.2 -- and the
+                                                     // pop loop's speed depends on what else its kernel carries)
 static const int kWavesPerCU = env_int("PF_WAVES_PER_CU", kSlotsPerCU);   // resident one-agent waves per CU (LDS permitting)
 static int g_mpa_prune = 1;   // exact bound pruning of MPA rebuilds (pf_set_option "mpa_prune")
 static int g_settle_top = env_int("PF_SETTLE_TOP", 0);  // auto mode ("astar_settle" -1): per mille of a DECODE batch, from the head of the longest-first queue, whose A* searches
@@ -2389,7 +2408,11 @@ static int launch_with_retry(pf_handle* h, Kern kern, KArgs& args, int n, bool t
   if (n <= 0) return 0;
   const int S = kLdsS;
   args.c.S = S; args.c.retry = 0;
+#ifdef PF_TWO_WAVE
   const size_t lds = two_wave ? (size_t)PF_PR_LDS_BYTES : open_bytes(S);
+#else
+  const size_t lds = open_bytes(S);
+#endif
   CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = (int)((160 * 1024) / lds); if (per_cu > kWavesPerCU) per_cu = kWavesPerCU; if (per_cu < 1) per_cu = 1;
   int grid = (h->nslots / kSlotsPerCU) * per_cu; if (grid > n) grid = n; if (grid > h->nslots) grid = h->nslots;
@@ -2489,7 +2512,10 @@ int pf_astar_batch(pf_handle* h, int32_t variant, int32_t allow_diag, int32_t re
   if (variant == PF_ASTAR_REF) return plat ? launch_with_retry(h, k_astar_batch<0, true>, a, n) : launch_with_retry(h, k_astar_batch<0, false>, a, n);
   if (variant == PF_ASTAR_MPA) {
     if (plat) return launch_with_retry(h, k_astar_batch<1, true>, a, n);
-    return g_two_wave ? launch_with_retry(h, k_astar_batch<1, false, true>, a, n, true) : launch_with_retry(h, k_astar_batch<1, false>, a, n);
+#ifdef PF_TWO_WAVE
+    if (g_two_wave) return launch_with_retry(h, k_astar_batch<1, false, true>, a, n, true);
+#endif
+    return launch_with_retry(h, k_astar_batch<1, false>, a, n);
   }
   if (variant == PF_ASTAR_DIJKSTRA) return plat ? launch_with_retry(h, k_astar_batch<2, true>, a, n) : launch_with_retry(h, k_astar_batch<2, false>, a, n);
   return failmsg(h, "pf_astar_batch: unknown variant");
@@ -2632,7 +2658,11 @@ int pf_set_option(pf_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "astar_step_cap")) { g_step_cap = value > 0 ? (long long)value : 0; return 0; }
   if (!strcmp(name, "maaco_pack8_min")) { g_maaco_pack8_min = (int)value; return 0; }
   if (!strcmp(name, "mpa_prune")) { g_mpa_prune = value != 0; return 0; }
+#ifdef PF_TWO_WAVE
   if (!strcmp(name, "two_wave")) { g_two_wave = value != 0; return 0; }
+#else
+  if (!strcmp(name, "two_wave")) { if (value == 0) return 0; return failmsg(h, "pf_set_option: two_wave is not built in (compile with -DPF_TWO_WAVE)"); }
+#endif
   if (!strcmp(name, "maaco_mark_in_walk")) { g_maaco_mark = value != 0; return 0; }
   if (!strcmp(name, "astar_settle")) { g_settle = value < 0 ? -1 : (value != 0); return 0; }
   if (!strcmp(name, "astar_settle_tail")) { g_settle_tail = value < 0 ? 0 : (value > 1000 ? 1000 : (int)value); return 0; }
@@ -2893,6 +2923,7 @@ int pf_maaco_deposit_begin(pf_handle* h, int32_t n, int32_t path_cap, const int3
     // the walk batch that produced exactly these paths has marked them already (pf_set_option "maaco_mark_in_walk")
     h->marks_n = 0;
   } else {
+    h->marks_n = 0; h->marks_cells = nullptr;                       // whatever an earlier walk marked is wiped / replaced below: never trusted again
     if (maaco_ensure_bits(h, n)) return -1;
     hipLaunchKernelGGL(k_visit_bits, dim3(n), dim3(64), 0, h->stream, n, path_cap, d_cells, d_len, d_plen, h->mp.Q, h->d_bits, h->RC, h->d_dep, h->d_flag, (int)h->bits_words);
     CK(hipGetLastError());
@@ -3391,10 +3422,15 @@ int pf_mpa_iter_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uint
   MpaJob* jobs = (MpaJob*)h->d_jobs; MpaRes* jres = (MpaRes*)h->d_jres;
   MpaSearchArgs sa;
   sa.c = a.ph.c; sa.jobs = jobs; sa.res = jres; sa.n_items = 2 * n; sa.path_cap = path_cap; sa.ph_cells = d_c1_cells; sa.fd_cells = d_c2_cells; sa.n = n;
+#ifdef PF_TWO_WAVE
   const bool pr = g_two_wave != 0 && !plateau_map(h);               // two wavefronts per search (pf_astar_pr.h)
   const size_t lds = pr ? (size_t)PF_PR_LDS_BYTES : open_bytes(S);
   if (pr) CK(hipFuncSetAttribute((const void*)k_mpa_search<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  else CK(hipFuncSetAttribute((const void*)k_mpa_search<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  else
+#else
+  const size_t lds = open_bytes(S);
+#endif
+  CK(hipFuncSetAttribute((const void*)k_mpa_search<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = (int)((160 * 1024) / lds); if (per_cu > kWavesPerCU) per_cu = kWavesPerCU; if (per_cu < 1) per_cu = 1;
   int grid = (h->nslots / kSlotsPerCU) * per_cu; if (grid > 2 * n) grid = 2 * n; if (grid > h->nslots) grid = h->nslots;
   CK(hipMemsetAsync(h->d_work, 0, sizeof(int), h->stream));
@@ -3402,8 +3438,11 @@ int pf_mpa_iter_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uint
   hipLaunchKernelGGL(k_mpa_plan, dim3(2 * n), dim3(64), 0, h->stream, a, jobs, jres);
   CK(hipGetLastError());
   CK(hipEventRecord(h->ev0, h->stream));
+#ifdef PF_TWO_WAVE
   if (pr) hipLaunchKernelGGL(k_mpa_search<true>, dim3(grid), dim3(128), lds, h->stream, sa);
-  else hipLaunchKernelGGL(k_mpa_search<false>, dim3(grid), dim3(64), lds, h->stream, sa);
+  else
+#endif
+  hipLaunchKernelGGL(k_mpa_search<false>, dim3(grid), dim3(64), lds, h->stream, sa);
   CK(hipGetLastError());
   CK(hipEventRecord(h->ev1, h->stream));
   hipLaunchKernelGGL(k_mpa_finish, dim3(2 * n), dim3(64), 0, h->stream, a, (const MpaJob*)jobs, (const MpaRes*)jres);

@@ -76,7 +76,19 @@ PF_DEV int move_dc(int d) { return (int)((0x2252u >> (2 * d)) & 3u) - 1; }   // 
 
 }  // namespace pf
 #include "pf_astar_sw.h"
-#include "pf_astar_pr.h"
+#ifdef PF_TWO_WAVE
+#include "pf_astar_pr.h"     // two wavefronts per search (off by default and measured 0.90x: compiled only on request)
+#else
+namespace pf {               // PR is false in every instantiation of this build: the pop wave's link functions are never called
+PF_DEV void pr_search_start(PrLink&, int, int, int, bool, int) {}
+PF_DEV bool pr_search_stop(PrLink&, unsigned&, bool&, int) { return true; }
+PF_DEV void pr_request(PrLink&, int, int) {}
+PF_DEV int pr_take(PrLink&, SwWin&, int) { return 0; }
+PF_DEV void pr_publish(PrLink&, int) {}
+PF_DEV bool pr_wait_room(PrLink&) { return true; }
+PF_DEV int pr_ld(const int*) { return 0; }
+}  // namespace pf
+#endif
 #include "pf_settle.h"
 namespace pf {
 

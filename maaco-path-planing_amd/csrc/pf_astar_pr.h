@@ -291,14 +291,17 @@ __device__ __noinline__ void pool_wave(char* lds, char* tier2_slot, const Rec* r
     if (lane == 0) for (int i = 0; i < 6; ++i) atomicAdd(&g_stamps[16 + i], rs[i]);
 #endif
     // ---- STOP (or EXIT): report, acknowledge ----
+    // Entries P published but this search no longer needs are skipped: the next search starts from P's tail.  TAIL is final here
+    // (P published it BEFORE it wrote CMD = STOP) and must be read -- and HEAD stored -- BEFORE the acknowledgement: STOPACK
+    // releases P, which may start the next search, push to the ring and publish a new TAIL at once; a TAIL read after that would
+    // skip the new search's first entries.
+    head = (unsigned)pr_ld(ctl + PR_TAIL);
     if (lane == 0) {
+      pr_st(ctl + PR_HEAD, (int)head);
       ctl[PR_SPILLS] = (int)spills; ctl[PR_FLAGS] = flags;
       PF_LDS_ORDER();
       pr_st(ctl + PR_STOPACK, seen);
     }
-    // entries P published but this search no longer needs are skipped: the next search starts from P's tail
-    head = (unsigned)pr_ld(ctl + PR_TAIL);
-    if (lane == 0) pr_st(ctl + PR_HEAD, (int)head);
     PF_LDS_ORDER();
   }
 }

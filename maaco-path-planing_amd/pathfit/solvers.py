@@ -610,7 +610,9 @@ class PSOSolver(_WaypointSolver):
         every rank must call it (finish() does); reading `gbest_particle_data` never communicates."""
         d = getattr(self, "_gbest_dev", None)
         c = self.comm
-        if d is None or c is None or c.world == 1 or self._gowner < 0:
+        # (every term of this test is the same on all ranks: _gowner is the TRUE owner everywhere, and the flag is set and
+        # cleared by collective steps only -- so either every rank enters the broadcasts below, with the same root, or none does)
+        if d is None or c is None or c.world == 1 or self._gowner < 0 or self._gbest_everywhere:
             return
         e = self.engine
         hdr = self._d.setdefault("ghdr", e.buf(8, np.float64))
@@ -621,7 +623,7 @@ class PSOSolver(_WaypointSolver):
         L = int(self._d["gpath"].read(0, 1)[0])
         c.broadcast(self._d["gpath"], 1, L, self._gowner)
         self._gbest_dev = dict(d, stats=hdr.read(0, 5), len=L)
-        self._gowner = c.rank                                            # every rank holds the row now
+        self._gbest_everywhere = True                                    # every rank holds the row now (until a sweep moves the gbest)
 
     @property
     def gbest_particle_data(self):
@@ -629,11 +631,15 @@ class PSOSolver(_WaypointSolver):
             d = self._gbest_dev
             e, c = self.engine, self.comm
             pos = e.read(self._d["gb"].ptr, self.num_waypoints * 2, np.float64).reshape(-1, 2)   # (every rank holds the position)
-            if c is not None and c.world > 1 and c.rank != self._gowner:
+            if c is not None and c.world > 1 and c.rank != self._gowner and not self._gbest_everywhere:
                 # purely local view: the path row and the stats live on the owner until fetch_gbest() (a collective) is called
                 return {"fitness": float(d["fitness"]), "position": pos.tolist(), "path": None, "index": d["idx"], "owner_rank": self._gowner}
-            cells = self._d["gpath"].read(1, d["len"])
-            self._set_gbest(d["idx"], pos, CellPath(cells, self.cols), d["stats"])
+            if not d.get("host"):
+                cells = self._d["gpath"].read(1, d["len"])
+                self._set_gbest(d["idx"], pos, CellPath(cells, self.cols), d["stats"])
+                # the device-side record stays: whether fetch_gbest() has anything to do must not depend on which ranks happened to
+                # READ the property (a monitoring rank would otherwise leave the collective the others still enter)
+                self._gbest_dev = dict(d, host=True)
         return self._gbest
 
     @gbest_particle_data.setter
@@ -714,6 +720,7 @@ class PSOSolver(_WaypointSolver):
             d["pb_cells"].upload(cur); d["pb_len"].upload(ln)
         self._d = d
         self._gowner = -1                     # rank whose d["gpath"] holds the gbest path (-1: the host copy from the initialisation)
+        self._gbest_everywhere = False        # fetch_gbest() has brought the owner's row to every rank and no sweep has moved the gbest since
         self._particles_stale = False
         return True
 
@@ -786,6 +793,7 @@ class PSOSolver(_WaypointSolver):
                 if world > 1:
                     c.broadcast(d["gb"], 0, W * 2, r_star)                 # the new gbest position: W x 16 B
                 self._gowner = r_star
+                self._gbest_everywhere = False
                 gfit = f_star
             if m and upto < top - 1:                                       # roll back my evaluated but not yet final particles
                 r0 = max(upto + 1, a0) - lo

@@ -6,7 +6,12 @@ The grids are the bench grids (pathfit.env.bench_grid: np.kron 2x / 4x of the re
 here from the reference's own array and compared by hash.  Captured: AStarSolver.solve (astar.py:33-101) and MPA._a_star
 (MPA.py:106-151) on pairs of G512 and G1024 -- nearby pairs, path-prefix avoid sets as MPA builds them, and the corner-to-corner
 search of each grid -- with paths and heap pop / push counts; GASolver._reconstruct_path_from_chromosome + stats (ga_solver.py:58-93)
-with 3 and 5 waypoints on G512; MPA._reconstruct_path_segment (MPA.py:284-318) of the reference's own initial path on G512.  Data only (inputs and the reference's outputs), never reference source text.
+with 3 and 5 waypoints on G512; MPA._reconstruct_path_segment (MPA.py:284-318) of the reference's own initial path on G512;
+MAACO._construct_ant_solution_maaco + _update_pheromone_trails_maaco (MAACO.py:278-332) on G512 (8 ants x 2 iterations, beta 7 and
+beta 2) and G1024 (4 ants x 1 iteration) with the per-agent-keyed streams: every ant's path / length / turns and the pheromone
+matrix after each update.  Data only (inputs and the reference's outputs), never reference source text.
+
+    python oracle/capture_golden_big.py maaco      (re-capture only the MAACO keys, ~2 minutes; the other keys are kept)
 """
 import os
 import platform
@@ -55,7 +60,51 @@ def harness_grid(g):
     raise RuntimeError("no adjacent free pair")
 
 
+def cap_maaco_big():
+    """MAACO walks and pheromone updates of the unmodified reference at the bench sizes (main.py:34-38 parameters).  The
+    pheromone matrices are stored in full: after the first update nearly every free cell sits on a clip bound (MAACO.py:317-331:
+    tau_max = 1 / (0.9 L_best) is far below the initial C0 * d(S,T) / (d(S,i) + d(i,T))), so they compress to a few KB."""
+    base = dict(alpha=1.0, rho=0.1, Q=2.5, a_turn_coef=1.0, wh_max=0.9, wh_min=0.2, k_h_adaptive=0.9,
+                q0_initial=0.5, C0_initial_pheromone=0.1)
+    d = {}
+    plan = [(2, 7.0, 8, 2, 100, 2001), (2, 2.0, 8, 2, 100, 2002), (4, 7.0, 4, 1, 100, 2003)]
+    for ri, (k, beta, n_ants, n_it, K, seed) in enumerate(plan):
+        g = big_grid(k)
+        R, C = g.shape
+        t0 = time.time()
+        ma = rh.make_maaco(g, num_ants=n_ants, num_iterations=K, beta=beta, **base)
+        paths, lens, turns, draws, taus = [], [], [], [], []
+        best = float("inf")
+        for it in range(1, n_it + 1):
+            it_paths = []
+            for ant in range(n_ants):
+                pc, L, T, nd = rh.maaco_walk(ma, it, seed, ant)
+                paths.append(pc); lens.append(L); turns.append(T if T != float("inf") else -1); draws.append(nd)
+                it_paths.append((rh.to_rc(pc, C), L, T))
+                best = min(best, L)
+            ma.best_path_length_overall = best                    # MAACO.py:351-352 precedes :359
+            ma._update_pheromone_trails_maaco(it_paths, None)
+            taus.append(ma.pheromone_matrix.copy())
+        po_, pf = csr(paths)
+        d[f"maaco{ri}_path_off"], d[f"maaco{ri}_path"] = po_, pf
+        d[f"maaco{ri}_len"] = np.array(lens); d[f"maaco{ri}_turns"] = np.array(turns); d[f"maaco{ri}_draws"] = np.array(draws)
+        d[f"maaco{ri}_tau"] = np.array(taus)
+        d[f"maaco{ri}_cfg"] = np.array([R, beta, n_ants, n_it, K, seed], np.float64)
+        print(f"maaco big run {ri}: G{R} beta {beta}: {sum(np.isfinite(lens))} / {len(lens)} ants arrive, longest walk "
+              f"{max(len(p) for p in paths)} cells, {time.time() - t0:.0f} s", flush=True)
+    d["maaco_base_params"] = np.array([base[k] for k in ("alpha", "rho", "Q", "a_turn_coef", "wh_max", "wh_min",
+                                                         "k_h_adaptive", "q0_initial", "C0_initial_pheromone")])
+    d["maaco_runs"] = np.array(len(plan))
+    return d
+
+
 def main():
+    if sys.argv[1:] == ["maaco"]:                                 # only the MAACO keys: the rest of the file is kept as captured
+        z = np.load(os.path.join(OUT, "big_cases.npz"), allow_pickle=False)
+        keep = {k: z[k] for k in z.files if not k.startswith("maaco")}
+        keep.update(cap_maaco_big())
+        np.savez_compressed(os.path.join(OUT, "big_cases.npz"), **keep)
+        return
     rnd = random.Random(4242)
     rows, dec = [], []
     t00 = time.time()
@@ -136,7 +185,7 @@ def main():
         reb_idx=np.array([r["idx"] for r in reb]), reb_is_levy=np.array([r["is_levy"] for r in reb]),
         reb_scale=np.array([r["scale"] for r in reb]), reb_agent=np.array([r["agent"] for r in reb]), reb_draws=np.array([r["draws"] for r in reb]),
         reb_out_off=ro, reb_out=rf, reb_stats=np.array([r["stats"] for r in reb], np.float64), reb_seed_it=np.array([777, 3]),
-        reb_sigma=np.array([rh.levy_sigma(2.0)]),
+        reb_sigma=np.array([rh.levy_sigma(2.0)]), **cap_maaco_big(),
         **{"meta_" + k: v for k, v in META.items()})
     print("big cases", len(rows), "decodes", len(dec), "rebuilds", len(reb), f"{time.time() - t00:.0f} s")
 

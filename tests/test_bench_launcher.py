@@ -63,3 +63,41 @@ def test_bench_main_takes_the_launcher_branch_before_any_gpu_import(tmp_path):
                          "--no-extra", "--backend", "gloo"], env=env, capture_output=True, text=True, timeout=600)
     assert pr.returncode != 0
     assert "[bench launcher]" in pr.stderr
+
+
+def test_a_rank_that_dies_early_ends_the_run_at_once(tmp_path):
+    """Rank 1 dies at start-up while rank 0 would wait (here: sleep) for minutes, as in a rendezvous nobody else joins: the
+    launcher polls all ranks, reports rank 1's code and kills rank 0 within seconds."""
+    import time
+    import bench
+    w = _stub(tmp_path, """
+        import os, sys, time
+        if int(os.environ["RANK"]) == 1:
+            sys.exit(9)
+        time.sleep(300)
+    """)
+    t0 = time.monotonic()
+    rc, line = bench.launch_ranks(2, [], worker=w, timeout=120)
+    assert rc == 9 and line is None and time.monotonic() - t0 < 30
+
+
+def test_host_staged_retry_env_drops_the_elastic_agent_store(tmp_path):
+    """The retry child after a stuck RCCL bootstrap: under torch.distributed.run the parent's environment carries
+    TORCHELASTIC_USE_AGENT_STORE=True, with which every rank would be a TCPStore CLIENT on the new port (nobody listens).  The
+    child's environment must not inherit it, and every rank must derive the same port."""
+    import bench
+    base = {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29511", "RANK": "1", "WORLD_SIZE": "2", "TORCHELASTIC_USE_AGENT_STORE": "True",
+            "TORCHELASTIC_RUN_ID": "x", "TORCHELASTIC_RESTART_COUNT": "0", "TORCHELASTIC_MAX_RESTARTS": "0", "PATH": os.environ.get("PATH", "")}
+    e0, e1 = bench.retry_env(dict(base, RANK="0")), bench.retry_env(base)
+    for e in (e0, e1):
+        assert not any(k.startswith("TORCHELASTIC_") for k in e)
+        assert e["PF_BENCH_TRANSPORT"] == "torch" and e["PF_BENCH_RETRIED"] == "1" and e["WORLD_SIZE"] == "2"
+    assert e0["MASTER_PORT"] == e1["MASTER_PORT"] == "29512" and e0["RANK"] == "0" and e1["RANK"] == "1"
+    e2 = bench.retry_env(dict(base, PF_BENCH_RETRY_PORT="40123"))            # the launcher's own ranks: a port it reserved
+    assert e2["MASTER_PORT"] == "40123" and "PF_BENCH_RETRY_PORT" not in e2
+    # the child really is a store HOST on rank 0: with the agent's variable gone torch's env:// rendezvous starts a TCPStore server
+    code = ("import os, torch.distributed as d; d.init_process_group('gloo', rank=0, world_size=1); "
+            "print('ok', d.get_world_size()); d.destroy_process_group()")
+    env = dict(bench.retry_env(dict(base, RANK="0", WORLD_SIZE="1", MASTER_PORT=str(bench._free_port() - 1))), PYTHONPATH=os.environ.get("PYTHONPATH", ""))
+    pr = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert pr.returncode == 0 and "ok 1" in pr.stdout, pr.stderr[-500:]

@@ -180,7 +180,18 @@ def _worker(rank, world, port, out_dir, what):
         out = dict(path=np.array(res[0]), stats=np.array(res[1:], float), curve=np.array(sm.local.convergence_curve_data, float))
     elif what == "pso":
         ps = ShardedPSO(comm, g, engine=eng, seed=6, **PSO_KW)
-        res = ps.solve()
+        # solve() = begin, sweeps, finish -- with what a monitoring caller does in between: fetch_gbest() (a collective) twice in a
+        # row and once more inside finish(), with no sweep moving the gbest in between.  Every rank must take the same path through
+        # the broadcasts (the owner stays the owner; a second fetch is a no-op everywhere), or the ranks hang or disagree.
+        assert ps.begin()
+        for _ in range(ps.num_iterations):
+            ps.sweep()
+        ps.fetch_gbest(); ps.fetch_gbest()
+        mid = ps.gbest_particle_data
+        assert mid["path"] is not None
+        mid_fit, mid_path = mid["fitness"], np.array(mid["path"].tolist() if hasattr(mid["path"], "tolist") else mid["path"])
+        res = ps.finish()
+        assert res[5] == mid_fit and np.array_equal(np.array(res[0]), mid_path)
         out = dict(path=np.array(res[0]), stats=np.array(res[1:], float), curve=np.array(ps.convergence_curve), pos=ps._pos,
                    pbf=ps._pbest_fit)
     elif what == "ga":

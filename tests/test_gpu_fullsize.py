@@ -282,3 +282,101 @@ def test_maaco_one_pass_update_equals_three_kernel_form_and_numpy_at_512():
         tmin = tmax / (2.0 * max(R, C))
         tau_np = np.where(g.reshape(-1) == 1, 1e-9, np.minimum(np.maximum(tau_np, tmin), tmax))
         assert np.array_equal(t1.reshape(-1), tau_np), it
+
+
+MAACO_KW = dict(alpha=1.0, beta=7.0, rho=0.1, Q=2.5, a_turn_coef=1.0, wh_max=0.9, wh_min=0.2, k_h_adaptive=0.9, q0_initial=0.5)
+
+
+@pytest.mark.parametrize("G,N,seed,pack8_min", [(512, 16384, 0, None), (1024, 8192, 0, None), (1024, 8192, 3, 1), (512, 16384, 4, 1 << 30)])
+def test_maaco_full_bench_batches_vs_oracle(G, N, seed, pack8_min):
+    """The bench batches themselves (maaco512: 16 384 ants on G512; maaco1024 = BASELINE configs[4]'s per-GPU share: 8 192 ants on
+    G1024), iterations 1-3 through the one-enqueue iteration entry (pf_maaco_iterate), against the oracle restatement of
+    MAACO.py:278-332 -- EVERY ant of every iteration, cell for cell: the oracle walks the same (seed, iteration, ant) streams over the
+    pheromone matrix downloaded before the iteration, so a wrong-but-legal selection (a tie set, a roulette index, a q0 branch)
+    anywhere in 600-1 700 steps shows.  The pheromone after each update must equal the oracle's sequential update over all paths.
+    pack8_min None = the library's own choice of kernel for the batch; 1 / 2^30 force the packed / one-ant-per-wave kernels."""
+    import pathfit
+    from pathfit import env
+    import pf_oracle as po
+    g = env.bench_grid(G)
+    o = po.Oracle(g)
+    s, t = 0, G * G - 1
+    m = pathfit.MAACO(g, N, 100, C0_initial_pheromone=0.1, seed=seed, **MAACO_KW)
+    if pack8_min is not None:
+        m.engine.set_option("maaco_pack8_min", pack8_min)
+    try:
+        P = po.MaacoParams(alpha=1.0, beta=7.0, rho=0.1, Q=2.5, a_turn=1.0, wh_max=0.9, wh_min=0.2, k_h=0.9, q0_initial=0.5, C0=0.1,
+                           num_iterations=100)
+        tau0, dist = o.maaco_init(s, t, 0.1)
+        assert np.array_equal(tau0.reshape(G, G), m.pheromone_matrix)
+        best = float("inf")
+        dead = longest = 0
+        for it in (1, 2, 3):
+            tau = np.ascontiguousarray(np.asarray(m.pheromone_matrix, np.float64).reshape(-1))
+            m.iterate_dev(it)
+            dc, dl, dp, dt, ds = m.walk_bufs()
+            cells, lens, plen, turns, st = dc.download().reshape(N, -1), dl.download(), dp.download(), dt.download(), ds.download()
+            paths, olens = [], []
+            for ant in range(N):
+                p, L, T, _ = o.maaco_walk(s, t, P, tau, dist, it, seed, ant)
+                if len(p) == 0:
+                    assert lens[ant] == 0 and st[ant] in (1, 2) and np.isinf(plen[ant]) and turns[ant] == -1, (it, ant, st[ant])
+                    dead += 1
+                else:
+                    assert lens[ant] == len(p) and np.array_equal(cells[ant, :len(p)], p), (it, ant)
+                    assert plen[ant] == L and turns[ant] == T and st[ant] == 0, (it, ant)
+                    longest = max(longest, len(p))
+                paths.append(p); olens.append(L)
+            best = min(best, min(olens))
+            o.maaco_update(tau, 0.1, 2.5, paths, olens, best)
+            assert m.best_path_length_overall == best
+            assert np.array_equal(np.asarray(m.pheromone_matrix).reshape(-1), tau), it
+        assert dead > N // 10 and longest > 1.5 * G        # ants that die in dead ends and walks far longer than the diagonal both occur
+    finally:
+        m.engine.set_option("maaco_pack8_min", 2048)
+
+
+def test_cfg3_mpa_sweeps_4096_512_vs_oracle():
+    """BASELINE configs[2] at full size against the oracle: a 6-iteration run of 4 096 predators on G512 (phases 1, 2 and 3 of
+    MPA.py:339-377 execute, main.py:44-52 parameters).  Before every iteration the sorted population is downloaded and handed to
+    the oracle's restatement of the loop body; for a sample of 112 predators per iteration -- strided over the sorted list plus the
+    first and the last sixteen -- the candidate of the phase sweep (path, five stats; wherever the device did not prove it
+    rejected), and the individual after memory + FADs (path, five stats) must be the oracle's, bit for bit."""
+    import pathfit
+    from pathfit import env
+    import pf_oracle as po
+    import pf_loops
+    g = env.bench_grid(512)
+    N, K, seed = 4096, 6, 1
+    S, T = 0, 512 * 512 - 1
+    m = pathfit.MPA(g, N, K, FADs_rate=0.2, P_const=0.5, levy_beta=2.0, turn_penalty_factor=0.1, safety_penalty_factor=0.8,
+                    min_safe_distance=1.8, diagonal_obstacle_penalty=100.0, seed=seed)
+    o = po.Oracle(g)
+    ref = pf_loops.MpaOracle(o, S, T, N, K, FADs_rate=0.2, P_const=0.5, levy_beta=2.0, w_turn=0.1, w_safe=0.8, min_safe=1.8,
+                             diag_pen=100.0, seed=seed)
+    sample = sorted(set(list(range(16)) + list(range(N - 16, N)) + list(range(5, N, 51))))
+    rebuilt = changed = 0
+    for it in range(1, K + 1):
+        m._sort()                                             # (idempotent: step() starts with the same stable sort, MPA.py:333)
+        order = m.order.copy()
+        cells, lens, stats = m.d_cells.download(), m.d_len.download(), m.d_stats.download()
+        ref.pop = [(cells[sl, :lens[sl]].copy(), stats[sl].copy()) for sl in order]
+        elite = ref.pop[0]
+        ratio = it / K
+        CF = 0.0 if ratio >= 1.0 else (1.0 - ratio) ** (2.0 * ratio)
+        m.step(it)
+        c_len, c_cells, c_stats, c_st = m.d_cand_len.download(), m.d_cand_cells.download(), m.d_cand_stats.download(), m.d_status.download()
+        cells2, lens2, stats2 = m.d_cells.download(), m.d_len.download(), m.d_stats.download()
+        for i in sample:
+            cand = ref.phase_candidate(it, i, elite, CF)
+            if c_st[i] == 0:                                  # rebuilt on the device: the candidate itself is compared
+                assert np.array_equal(c_cells[i, :c_len[i]], cand[0]) and np.array_equal(c_stats[i], cand[1]), (it, i)
+                rebuilt += 1
+            else:                                             # unmodified, failed or proven rejected: the oracle's candidate must not be accepted either
+                assert c_st[i] == 4 and not (cand[1][4] < ref.pop[i][1][4]) or np.array_equal(c_cells[i, :c_len[i]], cand[0]), (it, i, c_st[i])
+            ind = cand if cand[1][4] < ref.pop[i][1][4] else ref.pop[i]          # memory, MPA.py:381-384
+            ind = ref.fads(it, i, ind, CF)                                        # FADs, :387-410
+            sl = order[i]
+            assert np.array_equal(cells2[sl, :lens2[sl]], ind[0]) and np.array_equal(stats2[sl], ind[1]), (it, i)
+            changed += not np.array_equal(ind[0], ref.pop[i][0])
+    assert rebuilt > 100 and changed > 20, (rebuilt, changed)

@@ -391,6 +391,42 @@ def test_maaco_golden_walks_and_pheromone():
             assert np.array_equal(np.array([m.sum(), m.max(), m.min()]), z[f"r{ri}_tau_sum"])
 
 
+@pytest.mark.parametrize("pack8_min", [1, 1 << 30])
+def test_big_maaco_golden_at_bench_sizes(pack8_min):
+    """HIP == the UNMODIFIED reference's MAACO (MAACO.py:278-332) on G512 (8 ants x 2 iterations, beta 7 and beta 2) and G1024
+    (4 ants): every ant's walk, length and turns, and the WHOLE pheromone matrix after each update -- with eight ants per
+    wavefront (k_maaco_walk8) and one (k_maaco_walk), through the one-pass update (k_tau_update)."""
+    from pathfit._lib import MaacoParams
+    z = gio.load("big_cases")
+    bp = z["maaco_base_params"]
+    e0 = eng("fig7")[0]
+    e0.set_option("maaco_pack8_min", pack8_min)
+    try:
+        for ri in range(int(z["maaco_runs"])):
+            R, beta, n_ants, n_it, K, seed = z[f"maaco{ri}_cfg"]
+            R, n_ants, n_it, K, seed = int(R), int(n_ants), int(n_it), int(K), int(seed)
+            e = eng(f"up{R // 256}:g256")[0]
+            s, t = 0, R * R - 1
+            e.maaco_setup(MaacoParams(bp[0], beta, bp[1], bp[2], bp[3], bp[4], bp[5], bp[6], bp[7], bp[8], K, s, t))
+            cap = 6 * (R + R) + 64
+            dc, dl, dp, dt, ds = e.buf((n_ants, cap), np.int32), e.buf(n_ants, np.int32), e.buf(n_ants, np.float64), \
+                e.buf(n_ants, np.int32), e.buf(n_ants, np.int32)
+            best, k = math.inf, 0
+            for it in range(1, n_it + 1):
+                e.maaco_walk(it, seed, 0, n_ants, cap, dc, dl, dp, dt, ds)
+                cells, lens, plen, turns, st = dc.download(), dl.download(), dp.download(), dt.download(), ds.download()
+                for ant in range(n_ants):
+                    want = gio.csr_get(z[f"maaco{ri}_path_off"], z[f"maaco{ri}_path"], k)
+                    assert st[ant] == (1 if len(want) == 0 else 0) and np.array_equal(cells[ant, :lens[ant]], want), (ri, it, ant)
+                    assert plen[ant] == z[f"maaco{ri}_len"][k] and turns[ant] == z[f"maaco{ri}_turns"][k], (ri, it, ant)
+                    k += 1
+                best = min(best, plen.min())
+                e.maaco_update(n_ants, cap, dc, dl, dp, best)
+                assert np.array_equal(e.maaco_get_pheromone(), z[f"maaco{ri}_tau"][it - 1]), (ri, it)
+    finally:
+        e0.set_option("maaco_pack8_min", 2048)
+
+
 def test_mpa_rebuild_golden():
     from pathfit._lib import MpaParams
     from pathfit.engine import score_params

@@ -97,6 +97,34 @@ def test_big_cases_at_bench_sizes():
         assert np.array_equal(o.score(out, 1, 0.1, 0.8, 1.8, True, 100.0), z["reb_stats"][i]), i
 
 
+def test_big_maaco_walks_and_pheromone_at_bench_sizes():
+    """MAACO.py:278-332 of the unmodified reference on G512 (8 ants x 2 iterations, beta 7 and beta 2) and G1024 (4 ants):
+    every ant's walk, length and turn count, and the whole pheromone matrix after every update."""
+    z = gio.load("big_cases")
+    bp = z["maaco_base_params"]
+    branches = np.zeros(3, np.int64)
+    for ri in range(int(z["maaco_runs"])):
+        R, beta, n_ants, n_it, K, seed = z[f"maaco{ri}_cfg"]
+        R, n_ants, n_it, K, seed = int(R), int(n_ants), int(n_it), int(K), int(seed)
+        o = po.Oracle(gio.upsample(gio.grid("g256")[0], R // 256))
+        s, t = 0, R * R - 1
+        P = po.MaacoParams(alpha=bp[0], beta=beta, rho=bp[1], Q=bp[2], a_turn=bp[3], wh_max=bp[4], wh_min=bp[5],
+                           k_h=bp[6], q0_initial=bp[7], C0=bp[8], num_iterations=K)
+        tau, dist = o.maaco_init(s, t, bp[8])
+        best = float("inf"); k = 0
+        for it in range(1, n_it + 1):
+            paths, lens = [], []
+            for ant in range(n_ants):
+                p, L, T, cnt = o.maaco_walk(s, t, P, tau, dist, it, seed, ant)
+                assert np.array_equal(p, gio.csr_get(z[f"maaco{ri}_path_off"], z[f"maaco{ri}_path"], k)), (ri, it, ant)
+                assert L == z[f"maaco{ri}_len"][k] and (T if T != float("inf") else -1) == z[f"maaco{ri}_turns"][k], (ri, it, ant)
+                branches += cnt[2:5]
+                paths.append(p); lens.append(L); best = min(best, L); k += 1
+            o.maaco_update(tau, bp[1], bp[2], paths, lens, best)
+            assert np.array_equal(tau.reshape(R, R), z[f"maaco{ri}_tau"][it - 1]), (ri, it)
+    assert branches[0] > 1000 and branches[1] + branches[2] > 1000      # greedy and non-greedy steps both occur (MAACO.py:241 / :251)
+
+
 def test_dijkstra_solver():
     """DijkstraSolver.solve (dijkstra.py:32-97) = variant 2 of the restated connector."""
     z = gio.load("dijkstra_cases")
