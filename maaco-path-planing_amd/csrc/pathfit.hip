@@ -1,7 +1,6 @@
 // pathfit.hip -- kernels K0..K7 and the C-ABI of libpathfit.so (gfx950 / MI355X).
 // See include/pathfit.h for the boundary and DESIGN.md for the data layout.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <math.h>
@@ -54,34 +53,37 @@ struct Common {
                          // chip is mostly idle by then and what is left are the long chains the batch ends on
 };
 
-PF_DEV Open make_open(char* smem, int /*S*/, char* tier2) {
+PF_DEV Open make_open(char* smem, int /*S*/, char* tier2, int slot) {
   Open O;
   O.lf = (double*)smem;
   O.sx = smem + PF_SX_OFF;
   static_assert(PF_GEO_OFF >= (PF_FLOOD_TAB + PF_FLOOD_K) * 4 && PF_GEO_OFF + sizeof(GeoTab) <= PF_SX_OFF, "LDS layout");
   geo_to_lds(smem, lane_id());                    // the replay's source-lane table (pf_astar_sw.h), once per wave
-  O.of = (double*)(tier2 + (size_t)blockIdx.x * PF_POOL_STRIDE);
+  O.of = (double*)(tier2 + (size_t)slot * PF_POOL_STRIDE);
   return O;
 }
+PF_DEV Open make_open(char* smem, int S, char* tier2) { return make_open(smem, S, tier2, (int)blockIdx.x); }
 static size_t open_bytes(int /*S*/) { return (size_t)PF_LDS_BYTES; }
 
-PF_DEV Slot slot_load(const Common& c, int RC) {
+PF_DEV Slot slot_load(const Common& c, int RC, int slot) {
   Slot s;
-  s.rec = c.rec + (size_t)blockIdx.x * RC;
+  s.rec = c.rec + (size_t)slot * RC;
   s.mm = c.G.mm;
-  s.tag = c.slot_state[2 * blockIdx.x];
-  s.avoid_ep = c.slot_state[2 * blockIdx.x + 1];
-  s.sm.lab = c.st_lab ? c.st_lab + (size_t)blockIdx.x * RC : nullptr;
-  s.sm.touched = c.st_lab ? c.st_touched + (size_t)blockIdx.x * 2 * RC : nullptr;
-  s.sm.par = c.st_lab ? c.st_par + (size_t)blockIdx.x * RC : nullptr;
-  s.sm.epoch = c.st_lab ? c.st_epoch + blockIdx.x : nullptr;
+  s.tag = c.slot_state[2 * slot];
+  s.avoid_ep = c.slot_state[2 * slot + 1];
+  s.sm.lab = c.st_lab ? c.st_lab + (size_t)slot * RC : nullptr;
+  s.sm.touched = c.st_lab ? c.st_touched + (size_t)slot * 2 * RC : nullptr;
+  s.sm.par = c.st_lab ? c.st_par + (size_t)slot * RC : nullptr;
+  s.sm.epoch = c.st_lab ? c.st_epoch + slot : nullptr;
   s.sm.touched_cap = 2 * RC;
   s.sm.astar_too = c.st_astar;
   return s;
 }
-PF_DEV void slot_store(const Common& c, const Slot& s, int lane) {
-  if (lane == 0) { c.slot_state[2 * blockIdx.x] = s.tag; c.slot_state[2 * blockIdx.x + 1] = s.avoid_ep; }
+PF_DEV Slot slot_load(const Common& c, int RC) { return slot_load(c, RC, (int)blockIdx.x); }
+PF_DEV void slot_store(const Common& c, const Slot& s, int lane, int slot) {
+  if (lane == 0) { c.slot_state[2 * slot] = s.tag; c.slot_state[2 * slot + 1] = s.avoid_ep; }
 }
+PF_DEV void slot_store(const Common& c, const Slot& s, int lane) { slot_store(c, s, lane, (int)blockIdx.x); }
 // new agent evaluation: fresh avoid epoch; wipe the slot before an epoch can wrap.  One evaluation runs at most
 // PF_MAX_SEARCHES_PER_EVAL searches (each takes a fresh 24-bit tag): pf_decode_batch rejects W beyond it, the other
 // callers run one or two.
@@ -1682,7 +1684,12 @@ __global__ __launch_bounds__(64) void k_mpa_plan(MpaSweepArgs q, MpaJob* jobs, M
   }
 }
 
-struct MpaSearchArgs { Common c; const MpaJob* jobs; MpaRes* res; int n_items, path_cap; int* ph_cells; int* fd_cells; int n; };
+// Partitioned sweep (pf_set_option "mpa_long_cus"): the same kernel is launched twice, concurrently, on two streams with disjoint
+// CU masks.  Launch A -- one wave per SIMD on its CUs -- takes queue positions [0, n_first), the longest-expected searches (the
+// ones the sweep ends on), then helps with the rest; launch B takes [n_first, n_items) on the other CUs at full occupancy.
+// slot_base: first search slot (record / pool scratch) of this launch; work2: the OTHER partition's counter, or null.
+struct MpaSearchArgs { Common c; const MpaJob* jobs; MpaRes* res; int n_items, path_cap; int* ph_cells; int* fd_cells; int n;
+                       int slot_base, n_first; int* work2; };
 
 // PR = two wavefronts per search (pf_astar_pr.h): wave 0 pops, wave 1 owns the bucket pool.  128-thread workgroups, one per slot.
 template <bool PR>
@@ -1708,12 +1715,16 @@ __global__ __launch_bounds__(PR ? 128 : 64) __attribute__((amdgpu_waves_per_eu(3
   PrLink link = {};
 #endif
   PrLink* const L = &link;
-  Open O = make_open(smem, p.c.S, p.c.tier2);
-  Slot s = slot_load(p.c, RC);
+  const int slot_i = (int)blockIdx.x + p.slot_base;
+  Open O = make_open(smem, p.c.S, p.c.tier2, slot_i);
+  Slot s = slot_load(p.c, RC, slot_i);
   AStat tot = {0, 0, 0, 0, 0, 0};
   unsigned long long ovf = 0;
+  bool own = true;                                                  // my partition's counter still has positions
   for (;;) {
-    const int item = next_agent(p.c, p.n_items, lane);
+    int item = -1;
+    if (own) { const int w = next_work(p.c.work, lane); if (w < p.n_first) item = p.c.queue[w]; else own = false; }
+    if (!own && p.work2) { const int w = next_work(p.work2, lane); if (w < p.n_items) item = p.c.queue[w]; }
     if (item < 0) break;
     const MpaJob j = p.jobs[item];
     if (first_i(j.kind) == 0) continue;
@@ -1767,7 +1778,7 @@ __global__ __launch_bounds__(PR ? 128 : 64) __attribute__((amdgpu_waves_per_eu(3
 #ifdef PF_TWO_WAVE
   if (PR) pr_exit(smem, lane);
 #endif
-  slot_store(p.c, s, lane);
+  slot_store(p.c, s, lane, slot_i);
   flush_counters(p.c.cnt, tot, 0, ovf, lane);
 }
 
@@ -1870,11 +1881,62 @@ __global__ __launch_bounds__(64) void k_mpa_memory(int n, int path_cap, const in
   if (threadIdx.x == 0) pop_len[slot] = L;
 }
 
-// ---- device-resident iteration control: sort keys, elite pick, local view ----------------------
-// key[pos] = vals[order[pos] * stride + offset]: list.sort(key=fitness) is a stable sort of the CURRENT list order
-__global__ void k_sort_keys(int n, const double* vals, int stride, int offset, const int* order, double* keys) {
+// ---- device-resident iteration control: stable sort, elite pick, local view ----------------------
+// K8: the stable sort behind list.sort(key=fitness) (MPA.py:321,333,412, ga_solver.py:209) and the longest-first work queue --
+// hand-written, three launches, no library.  A RANK sort: every element's final position is the number of elements that sort
+// before it under the total order (key, current position) -- stable by construction, no passes over digits, no scratch that
+// depends on the key width, any n.  The keys are the order-preserving u64 images of the fp64 (or fp32) values, so one 64-bit
+// unsigned compare decides a pair.
+//   k_sort_prep    key image of every element (through the current list order for list.sort), its payload saved, rank <- 0;
+//   k_rank_count   a wavefront owns 64 elements (one per lane) and a slice of the others: the other key is wave-uniform -- a
+//                  scalar load -- so a pair costs a compare and an add-with-carry; elements known to lie before / after the
+//                  wave's own 64 need no tie-break at all (<= / <); partial counts meet in one atomicAdd per element;
+//   k_rank_scatter out[rank[i]] = payload[i].
+// Work is n^2 / 64 wave-iterations spread over the whole chip (n = 4 096: 0.26 M, a few microseconds; 16 384: 4.2 M; 65 536:
+// 67 M ~ 0.1 ms -- every batch this orders runs for tens of milliseconds).
+PF_DEV unsigned long long key_image_f64(double v) {
+  unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  if (b == 0x8000000000000000ull) b = 0;                           // -0.0 == 0.0 for list.sort
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);             // negatives reversed below the positives; +inf last
+}
+// mode 0: key[pos] = image(vals[order[pos] * stride + offset]), payload[pos] = order[pos]   (list.sort of the CURRENT order)
+// mode 1: key[i] = ~image(est[i]) (descending), payload[i] = i                              (longest-expected-first queue)
+__global__ void k_sort_prep(int n, int mode, const double* vals, int stride, int offset, const int* order, const float* est,
+                            unsigned long long* key, int* payload, unsigned* rank) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) keys[i] = vals[(size_t)order[i] * stride + offset];
+  if (i >= n) return;
+  if (mode == 0) { const int id = order[i]; key[i] = key_image_f64(vals[(size_t)id * stride + offset]); payload[i] = id; }
+  else { key[i] = ~key_image_f64((double)est[i]); payload[i] = i; }
+  rank[i] = 0u;
+}
+__global__ __launch_bounds__(64) void k_rank_count(int n, int jsplit, int jchunk, const unsigned long long* __restrict__ key,
+                                                   unsigned* __restrict__ rank) {
+  const int lane = lane_id();
+  const int tile = (int)(blockIdx.x / (unsigned)jsplit), sp = (int)(blockIdx.x - (unsigned)tile * (unsigned)jsplit);
+  const int t0 = tile * 64, i = t0 + lane;
+  const unsigned long long ki = i < n ? key[i] : ~0ull;
+  int j = sp * jchunk;
+  int j1 = j + jchunk; if (j1 > n) j1 = n;
+  const int a1 = j1 < t0 ? j1 : t0, b1 = j1 < t0 + 64 ? j1 : t0 + 64;
+  unsigned cnt = 0;
+  // eight keys per scalar load (one s_load_dwordx16), then eight compare + add-with-carry pairs: a load per key would leave the
+  // wave waiting ~200 clocks for every single compare
+#define PF_RANK_RUN(END, TEST)                                                                  \
+  for (; j + 8 <= (END); j += 8) {                                                              \
+    unsigned long long kk[8];                                                                   \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) kk[u] = key[j + u];                           \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) { const unsigned long long kj = kk[u]; const int jj = j + u; (void)jj; cnt += (TEST) ? 1u : 0u; } \
+  }                                                                                             \
+  for (; j < (END); ++j) { const unsigned long long kj = key[j]; const int jj = j; (void)jj; cnt += (TEST) ? 1u : 0u; }
+  PF_RANK_RUN(a1, kj <= ki)                                         // every j here is an earlier position: a tie sorts before me
+  PF_RANK_RUN(b1, kj < ki || (kj == ki && jj < i))                  // my own 64: the full order (key, position)
+  PF_RANK_RUN(j1, kj < ki)                                          // later positions: only strictly smaller keys
+#undef PF_RANK_RUN
+  if (i < n && cnt) atomicAdd(&rank[i], cnt);
+}
+__global__ void k_rank_scatter(int n, const unsigned* rank, const int* payload, int* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[rank[i]] = payload[i];
 }
 __global__ void k_gather_col(int n, const double* src, int stride, int offset, double* dst) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2082,13 +2144,14 @@ struct pf_handle {
   double* d_elite_stats = nullptr;
   int* d_init_cells = nullptr; int init_len = 0; int init_cap = 0; double* d_init_stats = nullptr;
   double* d_ds = nullptr; double* d_dt = nullptr;   // static shortest distances from the start / to the target (pruning bounds)
-  float* d_est = nullptr; float* d_est2 = nullptr; int* d_iota = nullptr; int* d_queue = nullptr; int est_cap = 0;
-  void* d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
+  float* d_est = nullptr; int* d_queue = nullptr; int est_cap = 0;   // work estimates and the longest-first queue of a batch
+  hipStream_t s_long = nullptr, s_rest = nullptr; int long_cus = 0;   // CU-masked streams of the partitioned MPA sweep (lazily created)
+  hipEvent_t ev_fork = nullptr, ev_long = nullptr, ev_rest = nullptr; int* d_work2 = nullptr;
   void* d_jobs = nullptr; void* d_jres = nullptr; int job_cap = 0;   // the sweep's search jobs / results (k_mpa_plan -> k_mpa_search -> k_mpa_finish)
   int2* d_prop = nullptr; int* d_doubt = nullptr; int prop_cap = 0;   // MPA proposals {idx, target cell}; doubt list [0] = count, [1..] = predators
   long long doubts_resolved = 0;
   void* d_scan = nullptr; void* d_scan3 = nullptr;   // results of the small device scans
-  double* d_okey = nullptr; double* d_okey2 = nullptr; int* d_oval2 = nullptr; int okey_cap = 0;   // pf_sort_order_by_key scratch
+  unsigned long long* d_okey = nullptr; int* d_opay = nullptr; unsigned* d_orank = nullptr; int okey_cap = 0;   // rank_sort scratch: key images, payloads, ranks
   int* d_elite_cells = nullptr; int* d_elite_len = nullptr;   // the elite of the iteration (MPA.py:334), device resident
   int* d_ga_pool = nullptr; int ga_pool_cap = 0;              // random.sample's pool copy (small populations)
   unsigned long long* d_st_lab = nullptr; int* d_st_touched = nullptr; unsigned char* d_st_par = nullptr; unsigned* d_st_epoch = nullptr;   // pf_settle.h scratch
@@ -2236,12 +2299,15 @@ void pf_destroy(pf_handle* h) {
   if (h->comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(h->stream); g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
   void* ptrs[] = {h->d_occ, h->d_mm_r1, h->d_mm_r0, h->d_mm_r1_nd, h->d_mm_r0_nd, h->d_d2near, h->d_rec, h->d_slot_state,
                   h->d_work, h->d_cnt, h->d_pen, h->d_tier2, h->d_tau, h->d_taua, h->d_eta, h->d_dep, h->d_tep, h->d_visit, h->d_visit_epoch,
-                  h->d_bits, h->d_flag, h->d_mstate, h->d_mctl, h->d_d2wide, h->d_penw, h->d_tmp, h->d_elite_stats, h->d_init_cells, h->d_init_stats, h->d_est, h->d_est2, h->d_iota, h->d_queue, h->d_sort_tmp, h->d_jobs, h->d_jres, h->d_prop, h->d_doubt, h->d_scan, h->d_scan3, h->d_okey, h->d_okey2, h->d_oval2, h->d_elite_cells, h->d_elite_len, h->d_ga_pool, h->d_st_lab, h->d_st_touched, h->d_st_par, h->d_st_epoch,
+                  h->d_bits, h->d_flag, h->d_mstate, h->d_mctl, h->d_d2wide, h->d_penw, h->d_tmp, h->d_elite_stats, h->d_init_cells, h->d_init_stats, h->d_est, h->d_queue, h->d_jobs, h->d_jres, h->d_prop, h->d_doubt, h->d_scan, h->d_scan3, h->d_okey, h->d_opay, h->d_orank, h->d_elite_cells, h->d_elite_len, h->d_ga_pool, h->d_st_lab, h->d_st_touched, h->d_st_par, h->d_st_epoch,
                   h->d_comp[0], h->d_comp[1], h->d_comp[2], h->d_comp[3], h->d_ds, h->d_dt};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->ev2) (void)hipEventDestroy(h->ev2);
+  for (hipEvent_t e : {h->ev_fork, h->ev_long, h->ev_rest}) if (e) (void)hipEventDestroy(e);
+  for (hipStream_t q : {h->s_long, h->s_rest}) if (q) (void)hipStreamDestroy(q);
+  if (h->d_work2) (void)hipFree(h->d_work2);
   if (h->h_mstate) (void)hipHostFree(h->h_mstate);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -2294,6 +2360,8 @@ static int g_two_wave = env_int("PF_TWO_WAVE", 0);   // MPA searches on two-wave
                                                      // pop loop's speed depends on what else its kernel carries)
 static const int kWavesPerCU = env_int("PF_WAVES_PER_CU", kSlotsPerCU);   // resident one-agent waves per CU (LDS permitting)
 static int g_mpa_prune = 1;   // exact bound pruning of MPA rebuilds (pf_set_option "mpa_prune")
+static int g_mpa_long_cus = env_int("PF_MPA_LONG_CUS", 0);   // > 0: the MPA sweep's longest-expected searches run one per SIMD on this many CUs of their own
+                                                              // (CU-masked stream), the rest on the other CUs (pf_set_option "mpa_long_cus")
 static int g_settle_top = env_int("PF_SETTLE_TOP", 0);  // auto mode ("astar_settle" -1): per mille of a DECODE batch, from the head of the longest-first queue, whose A* searches
                                                          // also try the engine (pf_set_option "astar_settle_top")
 static int g_settle_tail = env_int("PF_SETTLE_TAIL", 600);   // auto mode: per mille of the SEARCH SLOTS; once no more agents of a decode batch than this are unfinished, every search that starts
@@ -2378,29 +2446,41 @@ static int end_batch(pf_handle* h, DevCounters* dc) {
   return 0;
 }
 
+// The stable rank sort (K8: k_sort_prep / k_rank_count / k_rank_scatter) of n elements, enqueued on the handle's stream.
+// mode 0: d_out[] = the list order d_order[] re-sorted by vals[id * stride + offset] ascending (d_out may be d_order itself: the
+// payload is saved before anything is written); mode 1: d_out[] = indices 0..n-1 by est[] descending.
+static int rank_sort(pf_handle* h, int n, int mode, const double* d_vals, int stride, int offset, const int* d_order, const float* d_est, int* d_out) {
+  if (n > h->okey_cap) {
+    for (void* q : {(void*)h->d_okey, (void*)h->d_opay, (void*)h->d_orank}) if (q) CK(hipFree(q));
+    CK(hipMalloc(&h->d_okey, sizeof(unsigned long long) * (size_t)n)); CK(hipMalloc(&h->d_opay, sizeof(int) * (size_t)n));
+    CK(hipMalloc(&h->d_orank, sizeof(unsigned) * (size_t)n));
+    h->okey_cap = n;
+  }
+  const int nb = (n + 255) / 256;
+  hipLaunchKernelGGL(k_sort_prep, dim3(nb), dim3(256), 0, h->stream, n, mode, d_vals, stride, offset, d_order, d_est, h->d_okey, h->d_opay, h->d_orank);
+  // ~8192 wavefronts per launch when there is that much work; a slice of the other keys is never shorter than 256
+  const int tiles = (n + 63) / 64;
+  int jsplit = 8192 / tiles; const int jmax = (n + 255) / 256; if (jsplit > jmax) jsplit = jmax; if (jsplit < 1) jsplit = 1;
+  const int jchunk = (n + jsplit - 1) / jsplit;
+  hipLaunchKernelGGL(k_rank_count, dim3((unsigned)tiles * (unsigned)jsplit), dim3(64), 0, h->stream, n, jsplit, jchunk, (const unsigned long long*)h->d_okey, h->d_orank);
+  hipLaunchKernelGGL(k_rank_scatter, dim3(nb), dim3(256), 0, h->stream, n, (const unsigned*)h->d_orank, (const int*)h->d_opay, d_out);
+  CK(hipGetLastError());
+  return 0;
+}
+
 // Sort the batch longest-expected-first from per-agent estimates produced by `plan` (a functor that launches plan
-// kernels writing h->d_est[0..n)): a stable device radix sort (hipCUB) of (estimate, index) pairs, descending.  Nothing
+// kernels writing h->d_est[0..n)): the stable rank sort of (estimate, index) pairs, descending.  Nothing
 // crosses PCIe and nothing waits: the sweep is queued behind it on the same stream.
-__global__ void k_iota(int* v, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) v[i] = i; }
 template <typename Plan>
 static int make_queue(pf_handle* h, int n, Plan plan) {
   if (n > h->est_cap) {
-    for (void* q : {(void*)h->d_est, (void*)h->d_est2, (void*)h->d_iota, (void*)h->d_queue}) if (q) CK(hipFree(q));
-    CK(hipMalloc(&h->d_est, sizeof(float) * (size_t)n)); CK(hipMalloc(&h->d_est2, sizeof(float) * (size_t)n));
-    CK(hipMalloc(&h->d_iota, sizeof(int) * (size_t)n)); CK(hipMalloc(&h->d_queue, sizeof(int) * (size_t)n));
-    hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_iota, n);
+    for (void* q : {(void*)h->d_est, (void*)h->d_queue}) if (q) CK(hipFree(q));
+    CK(hipMalloc(&h->d_est, sizeof(float) * (size_t)n)); CK(hipMalloc(&h->d_queue, sizeof(int) * (size_t)n));
     h->est_cap = n;
   }
   plan(h->d_est);
   CK(hipGetLastError());
-  size_t need = 0;
-  CK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, need, h->d_est, h->d_est2, h->d_iota, h->d_queue, n, 0, 32, h->stream));
-  if (need > h->sort_tmp_bytes) {
-    if (h->d_sort_tmp) CK(hipFree(h->d_sort_tmp));
-    CK(hipMalloc(&h->d_sort_tmp, need)); h->sort_tmp_bytes = need;
-  }
-  CK(hipcub::DeviceRadixSort::SortPairsDescending(h->d_sort_tmp, need, h->d_est, h->d_est2, h->d_iota, h->d_queue, n, 0, 32, h->stream));
-  return 0;
+  return rank_sort(h, n, 1, nullptr, 0, 0, nullptr, h->d_est, h->d_queue);
 }
 
 template <typename KArgs, typename Kern>
@@ -2658,6 +2738,7 @@ int pf_set_option(pf_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "astar_step_cap")) { g_step_cap = value > 0 ? (long long)value : 0; return 0; }
   if (!strcmp(name, "maaco_pack8_min")) { g_maaco_pack8_min = (int)value; return 0; }
   if (!strcmp(name, "mpa_prune")) { g_mpa_prune = value != 0; return 0; }
+  if (!strcmp(name, "mpa_long_cus")) { g_mpa_long_cus = value < 0 ? 0 : (int)value; return 0; }
 #ifdef PF_TWO_WAVE
   if (!strcmp(name, "two_wave")) { g_two_wave = value != 0; return 0; }
 #else
@@ -3377,6 +3458,25 @@ int pf_mpa_fads_batch(pf_handle* h, double CF, int32_t iter, uint64_t seed, int3
   return launch_with_retry(h, k_mpa_fads, a, n);
 }
 
+// two streams with complementary CU masks: the first `long_cus` CUs (mask bit order) and the rest
+static int ensure_cu_streams(pf_handle* h, int long_cus, int cus) {
+  if (h->s_long && h->long_cus == long_cus) return 0;
+  CK(hipSetDevice(h->device));
+  for (hipStream_t* q : {&h->s_long, &h->s_rest}) if (*q) { CK(hipStreamSynchronize(*q)); CK(hipStreamDestroy(*q)); *q = nullptr; }
+  const int words = (cus + 31) / 32;
+  std::vector<uint32_t> ma((size_t)words, 0u), mb((size_t)words, 0u);
+  for (int i = 0; i < cus; ++i) (i < long_cus ? ma : mb)[(size_t)i / 32] |= 1u << (i & 31);
+  CK(hipExtStreamCreateWithCUMask(&h->s_long, (uint32_t)words, ma.data()));
+  CK(hipExtStreamCreateWithCUMask(&h->s_rest, (uint32_t)words, mb.data()));
+  if (!h->ev_fork) {
+    CK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&h->ev_long, hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&h->ev_rest, hipEventDisableTiming));
+  }
+  if (!h->d_work2) CK(hipMalloc(&h->d_work2, sizeof(int)));
+  h->long_cus = long_cus;
+  return 0;
+}
+
 int pf_mpa_iter_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uint64_t seed, int32_t n, int32_t path_cap,
                       int32_t* d_pop_cells, int32_t* d_pop_len, double* d_pop_stats, const int32_t* d_gidx,
                       const int32_t* d_slot, const int32_t* d_elite_cells, int32_t elite_len, const double* d_elite_stats,
@@ -3422,6 +3522,7 @@ int pf_mpa_iter_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uint
   MpaJob* jobs = (MpaJob*)h->d_jobs; MpaRes* jres = (MpaRes*)h->d_jres;
   MpaSearchArgs sa;
   sa.c = a.ph.c; sa.jobs = jobs; sa.res = jres; sa.n_items = 2 * n; sa.path_cap = path_cap; sa.ph_cells = d_c1_cells; sa.fd_cells = d_c2_cells; sa.n = n;
+  sa.slot_base = 0; sa.n_first = 2 * n; sa.work2 = nullptr;
 #ifdef PF_TWO_WAVE
   const bool pr = g_two_wave != 0 && !plateau_map(h);               // two wavefronts per search (pf_astar_pr.h)
   const size_t lds = pr ? (size_t)PF_PR_LDS_BYTES : open_bytes(S);
@@ -3438,12 +3539,42 @@ int pf_mpa_iter_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uint
   hipLaunchKernelGGL(k_mpa_plan, dim3(2 * n), dim3(64), 0, h->stream, a, jobs, jres);
   CK(hipGetLastError());
   CK(hipEventRecord(h->ev0, h->stream));
+  const int cus = h->nslots / kSlotsPerCU;
+  const bool split = g_mpa_long_cus > 0 && g_mpa_long_cus < cus && 2 * n > 4 * g_mpa_long_cus && per_cu >= 2
+#ifdef PF_TWO_WAVE
+                     && !pr
+#endif
+      ;
+  if (split) {
+    // Partitioned sweep: the sweep ends on its ~300 longest searches (78-96 k pops each), every one of them a
+    // dependency chain that runs slower beside the waves it shares a SIMD with.  They get SIMDs of their own: launch A = one wave
+    // per SIMD (an LDS-size occupancy cap of four workgroups per CU) on `long_cus` CUs, the first 4 x long_cus positions of the
+    // longest-first queue; launch B = everything else on the other CUs at the usual occupancy.  Disjoint slots, one counter each;
+    // an A wave that has finished its long search helps with B's queue (still alone on its SIMD).  Same items, same searches.
+    if (ensure_cu_streams(h, g_mpa_long_cus, cus)) return -1;
+    const int gridA = 4 * g_mpa_long_cus;
+    int gridB = (cus - g_mpa_long_cus) * per_cu; if (gridB > h->nslots - gridA) gridB = h->nslots - gridA;
+    const size_t ldsA = (size_t)(160 * 1024 / 4);                   // four workgroups fill a CU's LDS: one per SIMD
+    CK(hipFuncSetAttribute((const void*)k_mpa_search<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA));
+    CK(hipMemsetD32Async((hipDeviceptr_t)h->d_work2, gridA, 1, h->stream));   // B's counter starts behind A's positions
+    CK(hipEventRecord(h->ev_fork, h->stream));
+    CK(hipStreamWaitEvent(h->s_long, h->ev_fork, 0)); CK(hipStreamWaitEvent(h->s_rest, h->ev_fork, 0));
+    MpaSearchArgs sb = sa;
+    sa.slot_base = 0; sa.n_first = gridA; sa.work2 = h->d_work2;
+    sb.slot_base = gridA; sb.n_first = 2 * n; sb.c.work = h->d_work2; sb.work2 = nullptr;
+    hipLaunchKernelGGL(k_mpa_search<false>, dim3(gridA), dim3(64), ldsA, h->s_long, sa);
+    hipLaunchKernelGGL(k_mpa_search<false>, dim3(gridB), dim3(64), lds, h->s_rest, sb);
+    CK(hipGetLastError());
+    CK(hipEventRecord(h->ev_long, h->s_long)); CK(hipEventRecord(h->ev_rest, h->s_rest));
+    CK(hipStreamWaitEvent(h->stream, h->ev_long, 0)); CK(hipStreamWaitEvent(h->stream, h->ev_rest, 0));
+  } else {
 #ifdef PF_TWO_WAVE
   if (pr) hipLaunchKernelGGL(k_mpa_search<true>, dim3(grid), dim3(128), lds, h->stream, sa);
   else
 #endif
   hipLaunchKernelGGL(k_mpa_search<false>, dim3(grid), dim3(64), lds, h->stream, sa);
   CK(hipGetLastError());
+  }
   CK(hipEventRecord(h->ev1, h->stream));
   hipLaunchKernelGGL(k_mpa_finish, dim3(2 * n), dim3(64), 0, h->stream, a, (const MpaJob*)jobs, (const MpaRes*)jres);
   CK(hipGetLastError());
@@ -3502,24 +3633,8 @@ int pf_sort_order_by_key(pf_handle* h, int32_t n, const double* d_vals, int32_t 
   if (n < 0 || !d_vals || !d_order || stride < 1 || offset < 0 || offset >= stride) return failmsg(h, "pf_sort_order_by_key: bad arguments");
   if (n <= 1) return 0;
   CK(hipSetDevice(h->device));
-  if (n > h->okey_cap) {
-    for (void* q : {(void*)h->d_okey, (void*)h->d_okey2, (void*)h->d_oval2}) if (q) CK(hipFree(q));
-    CK(hipMalloc(&h->d_okey, sizeof(double) * (size_t)n)); CK(hipMalloc(&h->d_okey2, sizeof(double) * (size_t)n));
-    CK(hipMalloc(&h->d_oval2, sizeof(int) * (size_t)n));
-    h->okey_cap = n;
-  }
-  hipLaunchKernelGGL(k_sort_keys, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, d_vals, stride, offset, d_order, h->d_okey);
-  CK(hipGetLastError());
-  size_t need = 0;
-  CK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, h->d_okey, h->d_okey2, d_order, h->d_oval2, n, 0, 64, h->stream));
-  if (need > h->sort_tmp_bytes) {
-    if (h->d_sort_tmp) CK(hipFree(h->d_sort_tmp));
-    CK(hipMalloc(&h->d_sort_tmp, need)); h->sort_tmp_bytes = need;
-  }
-  // radix sort: stable, and doubles order as list.sort(key=...) orders them (inf last; the fitness is never NaN)
-  CK(hipcub::DeviceRadixSort::SortPairs(h->d_sort_tmp, need, h->d_okey, h->d_okey2, d_order, h->d_oval2, n, 0, 64, h->stream));
-  CK(hipMemcpyAsync(d_order, h->d_oval2, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, h->stream));
-  return 0;
+  // stable, and doubles order as list.sort(key=...) orders them (inf last; the fitness is never NaN)
+  return rank_sort(h, n, 0, d_vals, stride, offset, d_order, nullptr, d_order);
 }
 // the head of a sorted list in ONE small copy: out2 = {d_order[0], d_vals[d_order[0] * stride + offset]}
 __global__ void k_sorted_head(const int* order, const double* vals, int stride, int offset, double* out2) {

@@ -33,14 +33,29 @@ def test_device_sort_scan_view_helpers():
     e, g, s, t = _engine()
     rnd = np.random.default_rng(0)
     # list.sort(key=fitness): stable, from the CURRENT list order; plenty of exact ties and +inf
-    for n in (1, 2, 33, 1000, 4096):
-        vals = np.round(rnd.random((n, 5)) * 8) / 4.0
-        vals[rnd.integers(0, n, max(1, n // 10)), 4] = np.inf
-        order = rnd.permutation(n).astype(np.int32)
-        d_v, d_o = e.put(vals), e.put(order)
-        e.sort_order_by_key(n, d_v, 5, 4, d_o)
-        want = order[np.argsort(vals[order, 4], kind="stable")]
-        assert np.array_equal(d_o.download(), want), n
+    # (the hand-written rank sort: k_sort_prep / k_rank_count / k_rank_scatter.  Sizes around the 64-element tiles and the 8-key
+    # scalar loads, beyond one 16 384-element LDS-sized block, few distinct keys -- long runs of equal keys whose order must be the
+    # CURRENT list order --, all keys equal, negative values, -0.0 == 0.0, +inf last)
+    for n in (1, 2, 7, 8, 9, 33, 63, 64, 65, 127, 129, 1000, 4096, 8191, 16384, 20000):
+        for kind in ("ties", "two", "same", "signed", "distinct"):
+            vals = rnd.random((n, 5))
+            if kind == "ties":
+                vals[:, 4] = np.round(rnd.random(n) * 8) / 4.0
+                vals[rnd.integers(0, n, max(1, n // 10)), 4] = np.inf
+            elif kind == "two":
+                vals[:, 4] = rnd.integers(0, 2, n) * 3.5
+            elif kind == "same":
+                vals[:, 4] = 815.0458
+            elif kind == "signed":
+                vals[:, 4] = np.round(rnd.standard_normal(n) * 2) / 2.0
+                vals[rnd.integers(0, n, max(1, n // 8)), 4] = -0.0
+                vals[rnd.integers(0, n, max(1, n // 8)), 4] = 0.0
+                vals[rnd.integers(0, n, max(1, n // 16)), 4] = -np.inf
+            order = rnd.permutation(n).astype(np.int32)
+            d_v, d_o = e.put(vals), e.put(order)
+            e.sort_order_by_key(n, d_v, 5, 4, d_o)
+            want = order[np.argsort(vals[order, 4], kind="stable")]
+            assert np.array_equal(d_o.download(), want), (n, kind)
     # MAACO.py:343-349 on the device == the sequential scan (near-ties within 1e-9, failed ants, nobody arrives)
     for trial in range(60):
         n = int(rnd.integers(1, 3000))
