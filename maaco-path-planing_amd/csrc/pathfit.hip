@@ -53,37 +53,34 @@ struct Common {
                          // chip is mostly idle by then and what is left are the long chains the batch ends on
 };
 
-PF_DEV Open make_open(char* smem, int /*S*/, char* tier2, int slot) {
+PF_DEV Open make_open(char* smem, int /*S*/, char* tier2) {
   Open O;
   O.lf = (double*)smem;
   O.sx = smem + PF_SX_OFF;
   static_assert(PF_GEO_OFF >= (PF_FLOOD_TAB + PF_FLOOD_K) * 4 && PF_GEO_OFF + sizeof(GeoTab) <= PF_SX_OFF, "LDS layout");
   geo_to_lds(smem, lane_id());                    // the replay's source-lane table (pf_astar_sw.h), once per wave
-  O.of = (double*)(tier2 + (size_t)slot * PF_POOL_STRIDE);
+  O.of = (double*)(tier2 + (size_t)blockIdx.x * PF_POOL_STRIDE);
   return O;
 }
-PF_DEV Open make_open(char* smem, int S, char* tier2) { return make_open(smem, S, tier2, (int)blockIdx.x); }
 static size_t open_bytes(int /*S*/) { return (size_t)PF_LDS_BYTES; }
 
-PF_DEV Slot slot_load(const Common& c, int RC, int slot) {
+PF_DEV Slot slot_load(const Common& c, int RC) {
   Slot s;
-  s.rec = c.rec + (size_t)slot * RC;
+  s.rec = c.rec + (size_t)blockIdx.x * RC;
   s.mm = c.G.mm;
-  s.tag = c.slot_state[2 * slot];
-  s.avoid_ep = c.slot_state[2 * slot + 1];
-  s.sm.lab = c.st_lab ? c.st_lab + (size_t)slot * RC : nullptr;
-  s.sm.touched = c.st_lab ? c.st_touched + (size_t)slot * 2 * RC : nullptr;
-  s.sm.par = c.st_lab ? c.st_par + (size_t)slot * RC : nullptr;
-  s.sm.epoch = c.st_lab ? c.st_epoch + slot : nullptr;
+  s.tag = c.slot_state[2 * blockIdx.x];
+  s.avoid_ep = c.slot_state[2 * blockIdx.x + 1];
+  s.sm.lab = c.st_lab ? c.st_lab + (size_t)blockIdx.x * RC : nullptr;
+  s.sm.touched = c.st_lab ? c.st_touched + (size_t)blockIdx.x * 2 * RC : nullptr;
+  s.sm.par = c.st_lab ? c.st_par + (size_t)blockIdx.x * RC : nullptr;
+  s.sm.epoch = c.st_lab ? c.st_epoch + blockIdx.x : nullptr;
   s.sm.touched_cap = 2 * RC;
   s.sm.astar_too = c.st_astar;
   return s;
 }
-PF_DEV Slot slot_load(const Common& c, int RC) { return slot_load(c, RC, (int)blockIdx.x); }
-PF_DEV void slot_store(const Common& c, const Slot& s, int lane, int slot) {
-  if (lane == 0) { c.slot_state[2 * slot] = s.tag; c.slot_state[2 * slot + 1] = s.avoid_ep; }
+PF_DEV void slot_store(const Common& c, const Slot& s, int lane) {
+  if (lane == 0) { c.slot_state[2 * blockIdx.x] = s.tag; c.slot_state[2 * blockIdx.x + 1] = s.avoid_ep; }
 }
-PF_DEV void slot_store(const Common& c, const Slot& s, int lane) { slot_store(c, s, lane, (int)blockIdx.x); }
 // new agent evaluation: fresh avoid epoch; wipe the slot before an epoch can wrap.  One evaluation runs at most
 // PF_MAX_SEARCHES_PER_EVAL searches (each takes a fresh 24-bit tag): pf_decode_batch rejects W beyond it, the other
 // callers run one or two.
@@ -1684,12 +1681,7 @@ __global__ __launch_bounds__(64) void k_mpa_plan(MpaSweepArgs q, MpaJob* jobs, M
   }
 }
 
-// Partitioned sweep (pf_set_option "mpa_long_cus"): the same kernel is launched twice, concurrently, on two streams with disjoint
-// CU masks.  Launch A -- one wave per SIMD on its CUs -- takes queue positions [0, n_first), the longest-expected searches (the
-// ones the sweep ends on), then helps with the rest; launch B takes [n_first, n_items) on the other CUs at full occupancy.
-// slot_base: first search slot (record / pool scratch) of this launch; work2: the OTHER partition's counter, or null.
-struct MpaSearchArgs { Common c; const MpaJob* jobs; MpaRes* res; int n_items, path_cap; int* ph_cells; int* fd_cells; int n;
-                       int slot_base, n_first; int* work2; };
+struct MpaSearchArgs { Common c; const MpaJob* jobs; MpaRes* res; int n_items, path_cap; int* ph_cells; int* fd_cells; int n; };
 
 // PR = two wavefronts per search (pf_astar_pr.h): wave 0 pops, wave 1 owns the bucket pool.  128-thread workgroups, one per slot.
 template <bool PR>
@@ -1715,16 +1707,12 @@ __global__ __launch_bounds__(PR ? 128 : 64) __attribute__((amdgpu_waves_per_eu(3
   PrLink link = {};
 #endif
   PrLink* const L = &link;
-  const int slot_i = (int)blockIdx.x + p.slot_base;
-  Open O = make_open(smem, p.c.S, p.c.tier2, slot_i);
-  Slot s = slot_load(p.c, RC, slot_i);
+  Open O = make_open(smem, p.c.S, p.c.tier2);
+  Slot s = slot_load(p.c, RC);
   AStat tot = {0, 0, 0, 0, 0, 0};
   unsigned long long ovf = 0;
-  bool own = true;                                                  // my partition's counter still has positions
   for (;;) {
-    int item = -1;
-    if (own) { const int w = next_work(p.c.work, lane); if (w < p.n_first) item = p.c.queue[w]; else own = false; }
-    if (!own && p.work2) { const int w = next_work(p.work2, lane); if (w < p.n_items) item = p.c.queue[w]; }
+    const int item = next_agent(p.c, p.n_items, lane);
     if (item < 0) break;
     const MpaJob j = p.jobs[item];
     if (first_i(j.kind) == 0) continue;
@@ -1778,7 +1766,7 @@ __global__ __launch_bounds__(PR ? 128 : 64) __attribute__((amdgpu_waves_per_eu(3
 #ifdef PF_TWO_WAVE
   if (PR) pr_exit(smem, lane);
 #endif
-  slot_store(p.c, s, lane, slot_i);
+  slot_store(p.c, s, lane);
   flush_counters(p.c.cnt, tot, 0, ovf, lane);
 }
 
@@ -2145,8 +2133,6 @@ struct pf_handle {
   int* d_init_cells = nullptr; int init_len = 0; int init_cap = 0; double* d_init_stats = nullptr;
   double* d_ds = nullptr; double* d_dt = nullptr;   // static shortest distances from the start / to the target (pruning bounds)
   float* d_est = nullptr; int* d_queue = nullptr; int est_cap = 0;   // work estimates and the longest-first queue of a batch
-  hipStream_t s_long = nullptr, s_rest = nullptr; int long_cus = 0;   // CU-masked streams of the partitioned MPA sweep (lazily created)
-  hipEvent_t ev_fork = nullptr, ev_long = nullptr, ev_rest = nullptr; int* d_work2 = nullptr;
   void* d_jobs = nullptr; void* d_jres = nullptr; int job_cap = 0;   // the sweep's search jobs / results (k_mpa_plan -> k_mpa_search -> k_mpa_finish)
   int2* d_prop = nullptr; int* d_doubt = nullptr; int prop_cap = 0;   // MPA proposals {idx, target cell}; doubt list [0] = count, [1..] = predators
   long long doubts_resolved = 0;
@@ -2305,9 +2291,6 @@ void pf_destroy(pf_handle* h) {
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->ev2) (void)hipEventDestroy(h->ev2);
-  for (hipEvent_t e : {h->ev_fork, h->ev_long, h->ev_rest}) if (e) (void)hipEventDestroy(e);
-  for (hipStream_t q : {h->s_long, h->s_rest}) if (q) (void)hipStreamDestroy(q);
-  if (h->d_work2) (void)hipFree(h->d_work2);
   if (h->h_mstate) (void)hipHostFree(h->h_mstate);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -2360,8 +2343,6 @@ static int g_two_wave = env_int("PF_TWO_WAVE", 0);   // MPA searches on two-wave
                                                      // pop loop's speed depends on what else its kernel carries)
 static const int kWavesPerCU = env_int("PF_WAVES_PER_CU", kSlotsPerCU);   // resident one-agent waves per CU (LDS permitting)
 static int g_mpa_prune = 1;   // exact bound pruning of MPA rebuilds (pf_set_option "mpa_prune")
-static int g_mpa_long_cus = env_int("PF_MPA_LONG_CUS", 0);   // > 0: the MPA sweep's longest-expected searches run one per SIMD on this many CUs of their own
-                                                              // (CU-masked stream), the rest on the other CUs (pf_set_option "mpa_long_cus")
 static int g_settle_top = env_int("PF_SETTLE_TOP", 0);  // auto mode ("astar_settle" -1): per mille of a DECODE batch, from the head of the longest-first queue, whose A* searches
                                                          // also try the engine (pf_set_option "astar_settle_top")
 static int g_settle_tail = env_int("PF_SETTLE_TAIL", 600);   // auto mode: per mille of the SEARCH SLOTS; once no more agents of a decode batch than this are unfinished, every search that starts
@@ -2738,7 +2719,6 @@ int pf_set_option(pf_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "astar_step_cap")) { g_step_cap = value > 0 ? (long long)value : 0; return 0; }
   if (!strcmp(name, "maaco_pack8_min")) { g_maaco_pack8_min = (int)value; return 0; }
   if (!strcmp(name, "mpa_prune")) { g_mpa_prune = value != 0; return 0; }
-  if (!strcmp(name, "mpa_long_cus")) { g_mpa_long_cus = value < 0 ? 0 : (int)value; return 0; }
 #ifdef PF_TWO_WAVE
   if (!strcmp(name, "two_wave")) { g_two_wave = value != 0; return 0; }
 #else
@@ -3458,25 +3438,6 @@ int pf_mpa_fads_batch(pf_handle* h, double CF, int32_t iter, uint64_t seed, int3
   return launch_with_retry(h, k_mpa_fads, a, n);
 }
 
-// two streams with complementary CU masks: the first `long_cus` CUs (mask bit order) and the rest
-static int ensure_cu_streams(pf_handle* h, int long_cus, int cus) {
-  if (h->s_long && h->long_cus == long_cus) return 0;
-  CK(hipSetDevice(h->device));
-  for (hipStream_t* q : {&h->s_long, &h->s_rest}) if (*q) { CK(hipStreamSynchronize(*q)); CK(hipStreamDestroy(*q)); *q = nullptr; }
-  const int words = (cus + 31) / 32;
-  std::vector<uint32_t> ma((size_t)words, 0u), mb((size_t)words, 0u);
-  for (int i = 0; i < cus; ++i) (i < long_cus ? ma : mb)[(size_t)i / 32] |= 1u << (i & 31);
-  CK(hipExtStreamCreateWithCUMask(&h->s_long, (uint32_t)words, ma.data()));
-  CK(hipExtStreamCreateWithCUMask(&h->s_rest, (uint32_t)words, mb.data()));
-  if (!h->ev_fork) {
-    CK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&h->ev_long, hipEventDisableTiming));
-    CK(hipEventCreateWithFlags(&h->ev_rest, hipEventDisableTiming));
-  }
-  if (!h->d_work2) CK(hipMalloc(&h->d_work2, sizeof(int)));
-  h->long_cus = long_cus;
-  return 0;
-}
-
 int pf_mpa_iter_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uint64_t seed, int32_t n, int32_t path_cap,
                       int32_t* d_pop_cells, int32_t* d_pop_len, double* d_pop_stats, const int32_t* d_gidx,
                       const int32_t* d_slot, const int32_t* d_elite_cells, int32_t elite_len, const double* d_elite_stats,
@@ -3522,7 +3483,6 @@ int pf_mpa_iter_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uint
   MpaJob* jobs = (MpaJob*)h->d_jobs; MpaRes* jres = (MpaRes*)h->d_jres;
   MpaSearchArgs sa;
   sa.c = a.ph.c; sa.jobs = jobs; sa.res = jres; sa.n_items = 2 * n; sa.path_cap = path_cap; sa.ph_cells = d_c1_cells; sa.fd_cells = d_c2_cells; sa.n = n;
-  sa.slot_base = 0; sa.n_first = 2 * n; sa.work2 = nullptr;
 #ifdef PF_TWO_WAVE
   const bool pr = g_two_wave != 0 && !plateau_map(h);               // two wavefronts per search (pf_astar_pr.h)
   const size_t lds = pr ? (size_t)PF_PR_LDS_BYTES : open_bytes(S);
@@ -3539,42 +3499,12 @@ int pf_mpa_iter_batch(pf_handle* h, int32_t phase, double CF, int32_t iter, uint
   hipLaunchKernelGGL(k_mpa_plan, dim3(2 * n), dim3(64), 0, h->stream, a, jobs, jres);
   CK(hipGetLastError());
   CK(hipEventRecord(h->ev0, h->stream));
-  const int cus = h->nslots / kSlotsPerCU;
-  const bool split = g_mpa_long_cus > 0 && g_mpa_long_cus < cus && 2 * n > 4 * g_mpa_long_cus && per_cu >= 2
-#ifdef PF_TWO_WAVE
-                     && !pr
-#endif
-      ;
-  if (split) {
-    // Partitioned sweep: the sweep ends on its ~300 longest searches (78-96 k pops each), every one of them a
-    // dependency chain that runs slower beside the waves it shares a SIMD with.  They get SIMDs of their own: launch A = one wave
-    // per SIMD (an LDS-size occupancy cap of four workgroups per CU) on `long_cus` CUs, the first 4 x long_cus positions of the
-    // longest-first queue; launch B = everything else on the other CUs at the usual occupancy.  Disjoint slots, one counter each;
-    // an A wave that has finished its long search helps with B's queue (still alone on its SIMD).  Same items, same searches.
-    if (ensure_cu_streams(h, g_mpa_long_cus, cus)) return -1;
-    const int gridA = 4 * g_mpa_long_cus;
-    int gridB = (cus - g_mpa_long_cus) * per_cu; if (gridB > h->nslots - gridA) gridB = h->nslots - gridA;
-    const size_t ldsA = (size_t)(160 * 1024 / 4);                   // four workgroups fill a CU's LDS: one per SIMD
-    CK(hipFuncSetAttribute((const void*)k_mpa_search<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA));
-    CK(hipMemsetD32Async((hipDeviceptr_t)h->d_work2, gridA, 1, h->stream));   // B's counter starts behind A's positions
-    CK(hipEventRecord(h->ev_fork, h->stream));
-    CK(hipStreamWaitEvent(h->s_long, h->ev_fork, 0)); CK(hipStreamWaitEvent(h->s_rest, h->ev_fork, 0));
-    MpaSearchArgs sb = sa;
-    sa.slot_base = 0; sa.n_first = gridA; sa.work2 = h->d_work2;
-    sb.slot_base = gridA; sb.n_first = 2 * n; sb.c.work = h->d_work2; sb.work2 = nullptr;
-    hipLaunchKernelGGL(k_mpa_search<false>, dim3(gridA), dim3(64), ldsA, h->s_long, sa);
-    hipLaunchKernelGGL(k_mpa_search<false>, dim3(gridB), dim3(64), lds, h->s_rest, sb);
-    CK(hipGetLastError());
-    CK(hipEventRecord(h->ev_long, h->s_long)); CK(hipEventRecord(h->ev_rest, h->s_rest));
-    CK(hipStreamWaitEvent(h->stream, h->ev_long, 0)); CK(hipStreamWaitEvent(h->stream, h->ev_rest, 0));
-  } else {
 #ifdef PF_TWO_WAVE
   if (pr) hipLaunchKernelGGL(k_mpa_search<true>, dim3(grid), dim3(128), lds, h->stream, sa);
   else
 #endif
   hipLaunchKernelGGL(k_mpa_search<false>, dim3(grid), dim3(64), lds, h->stream, sa);
   CK(hipGetLastError());
-  }
   CK(hipEventRecord(h->ev1, h->stream));
   hipLaunchKernelGGL(k_mpa_finish, dim3(2 * n), dim3(64), 0, h->stream, a, (const MpaJob*)jobs, (const MpaRes*)jres);
   CK(hipGetLastError());
