@@ -373,6 +373,14 @@ int pf_pso_scan(pf_handle* h, int32_t n, const double* d_stats, const int32_t* d
  * bytes of the larger ones (the solver loops keep populations in HBM: SURVEY.md 8 f1/f2). */
 int pf_d2h_counts(pf_handle* h, int64_t* small_copies, int64_t* bulk_copies, int64_t* bulk_bytes);
 
+/* Spans: HIP-event timed stretches of work on the handle's stream (kernels, pf_comm_* collectives), recorded without
+ * synchronising.  pf_span_begin / pf_span_end bracket one stretch (not nested); pf_span_total synchronises the stream and
+ * returns the summed duration (ms) and the number of spans since the last reset.  Measurement only (bench.py times the
+ * per-iteration exchange of the sharded solvers with it: SURVEY.md 8e); no reference counterpart. */
+int pf_span_begin(pf_handle* h);
+int pf_span_end(pf_handle* h);
+int pf_span_total(pf_handle* h, double* ms_out, int64_t* count_out, int32_t reset);
+
 /* Target-cell proposals of MPA._get_levy_target_node / _get_brownian_target_node (MPA.py:250-282) for n keyed streams
  * (seed, DOM_MPA, 0, i) from cells d_cur[i] (and elite cells d_elite[i], < 0 = None): the device arithmetic, with the
  * proposals whose accept test / rounding lies within the libm-disagreement margin recomputed by the host's glibc

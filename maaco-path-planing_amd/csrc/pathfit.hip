@@ -2143,6 +2143,7 @@ struct pf_handle {
   unsigned long long* d_st_lab = nullptr; int* d_st_touched = nullptr; unsigned char* d_st_par = nullptr; unsigned* d_st_epoch = nullptr;   // pf_settle.h scratch
   int dep_words = 0; long long dep_done = 0;   // MAACO deposit in progress: words of the bit matrix, cells already folded
   ncclComm_t comm = nullptr; int comm_rank = 0, comm_world = 1;   // RCCL communicator over xGMI (pf_comm_init); collectives run on `stream`
+  std::vector<hipEvent_t> span_ev; int span_n = 0; bool span_open = false; double span_ms = 0.0; long long span_cnt = 0;   // pf_span_*: HIP-event timed spans on `stream`
   long long d2h_small = 0, d2h_bulk = 0, d2h_bulk_bytes = 0;   // device-to-host copies the library made (f1/f2 accounting): <= 128 B / larger
 };
 
@@ -2288,6 +2289,7 @@ void pf_destroy(pf_handle* h) {
                   h->d_bits, h->d_flag, h->d_mstate, h->d_mctl, h->d_d2wide, h->d_penw, h->d_tmp, h->d_elite_stats, h->d_init_cells, h->d_init_stats, h->d_est, h->d_queue, h->d_jobs, h->d_jres, h->d_prop, h->d_doubt, h->d_scan, h->d_scan3, h->d_okey, h->d_opay, h->d_orank, h->d_elite_cells, h->d_elite_len, h->d_ga_pool, h->d_st_lab, h->d_st_touched, h->d_st_par, h->d_st_epoch,
                   h->d_comp[0], h->d_comp[1], h->d_comp[2], h->d_comp[3], h->d_ds, h->d_dt};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (hipEvent_t e : h->span_ev) (void)hipEventDestroy(e);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->ev2) (void)hipEventDestroy(h->ev2);
@@ -3763,6 +3765,48 @@ int pf_comm_sendrecv(pf_handle* h, const void* d_send, int64_t send_bytes, int32
   if (r3 != ncclSuccess) return nccl_fail(h, "ncclGroupEnd (pf_comm_sendrecv)", r3);
   return 0;
 }
+// ---- spans: time stretches of work on the handle's stream with HIP events, without synchronising while they are recorded ----
+// (what bench.py brackets the collectives of an iteration with: the exchange runs on the same stream as the kernels, so
+// torch.cuda.Event -- torch's current stream -- cannot see it, and a host clock around an asynchronous enqueue sees nothing)
+#define PF_SPAN_MAX 512
+static int span_fold(pf_handle* h) {                                // synchronise, add up the closed spans, recycle their events
+  CK(hipStreamSynchronize(h->stream));
+  for (int i = 0; i + 1 < h->span_n; i += 2) {
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, h->span_ev[(size_t)i], h->span_ev[(size_t)i + 1]));
+    h->span_ms += ms; h->span_cnt += 1;
+  }
+  h->span_n = 0;
+  return 0;
+}
+int pf_span_begin(pf_handle* h) {
+  if (!h) return -2;
+  if (h->span_open) return failmsg(h, "pf_span_begin: the previous span is still open");
+  CK(hipSetDevice(h->device));
+  if (h->span_n + 2 > 2 * PF_SPAN_MAX && span_fold(h)) return -1;
+  while ((int)h->span_ev.size() < h->span_n + 2) { hipEvent_t e; CK(hipEventCreate(&e)); h->span_ev.push_back(e); }
+  CK(hipEventRecord(h->span_ev[(size_t)h->span_n], h->stream));
+  h->span_open = true;
+  return 0;
+}
+int pf_span_end(pf_handle* h) {
+  if (!h) return -2;
+  if (!h->span_open) return failmsg(h, "pf_span_end: no span is open");
+  CK(hipEventRecord(h->span_ev[(size_t)h->span_n + 1], h->stream));
+  h->span_n += 2; h->span_open = false;
+  return 0;
+}
+int pf_span_total(pf_handle* h, double* ms_out, int64_t* count_out, int32_t reset) {
+  if (!h) return -2;
+  if (h->span_open) return failmsg(h, "pf_span_total: a span is still open");
+  CK(hipSetDevice(h->device));
+  if (span_fold(h)) return -1;
+  if (ms_out) *ms_out = h->span_ms;
+  if (count_out) *count_out = h->span_cnt;
+  if (reset) { h->span_ms = 0.0; h->span_cnt = 0; }
+  return 0;
+}
+
 int pf_comm_rank(pf_handle* h) { return h ? h->comm_rank : 0; }
 int pf_comm_world(pf_handle* h) { return h && h->comm ? h->comm_world : 1; }
 

@@ -115,6 +115,9 @@ SYMBOLS = {
     "pf_pso_pbest_paths": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "pf_pso_scan": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _dbl, _i32, C.POINTER(_i32), C.POINTER(_dbl), C.POINTER(_i32)]),
     "pf_d2h_counts": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "pf_span_begin": (C.c_int, [_vp]),
+    "pf_span_end": (C.c_int, [_vp]),
+    "pf_span_total": (C.c_int, [_vp, C.POINTER(_dbl), C.POINTER(_i64), _i32]),
     "pf_selftest_mpa_targets": (C.c_int, [_vp, _u64, _i32, _i32, _dbl, _dbl, _dbl, _vp, _vp, _vp, C.POINTER(_i64)]),
     "pf_mpa_doubts_resolved": (C.c_longlong, [_vp]),
     "pf_mpa_memory": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

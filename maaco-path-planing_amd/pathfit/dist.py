@@ -117,6 +117,8 @@ class Comm:
         self.transport = transport or ("gloo" if dist is not None else None)
         self.bytes_moved = 0                      # per-rank bytes handed to the transport (accounting for DESIGN.md 6)
         self.calls = 0
+        self.timed = False                        # bench.py: time every collective (HIP-event spans on the engine's stream for the
+        self.host_s = 0.0                         # rccl transport -- nothing synchronises --, the host clock for the host-staged ones)
         if engine is not None and self.transport == "rccl":
             self.attach(engine)
 
@@ -223,7 +225,7 @@ class Comm:
         return t.cpu().numpy()
 
     # ---- collectives ----
-    def all_gather(self, src, src_off, dst, counts, row_elems=1):
+    def _all_gather_impl(self, src, src_off, dst, counts, row_elems=1):
         """dst[offsets[r] * row_elems ...] = rank r's src[src_off ... + counts[r] * row_elems): the concatenation in
         rank order of per-rank blocks of counts[r] rows."""
         mine = counts[self.rank] * row_elems
@@ -255,7 +257,7 @@ class Comm:
         for r in range(self.world):
             dst.write(int(offs[r]), self._n(outs[r])[: counts[r] * row_elems])
 
-    def broadcast(self, buf, off, count, root):
+    def _broadcast_impl(self, buf, off, count, root):
         if (self.world == 1 and not (self.loopback and self.transport == "rccl")) or count == 0:
             return
         isz = np.dtype(buf.dtype).itemsize
@@ -269,7 +271,7 @@ class Comm:
         if self.rank != root:
             buf.write(off, self._n(t))
 
-    def send(self, buf, off, count, peer):
+    def _send_impl(self, buf, off, count, peer):
         isz = np.dtype(buf.dtype).itemsize
         self._acct(count * isz)
         if self.transport == "rccl":
@@ -278,7 +280,7 @@ class Comm:
             return
         self.dist.send(self._t(buf.read(off, count)), peer)
 
-    def recv(self, buf, off, count, peer):
+    def _recv_impl(self, buf, off, count, peer):
         isz = np.dtype(buf.dtype).itemsize
         if self.transport == "rccl":
             e = self.engine
@@ -288,7 +290,7 @@ class Comm:
         self.dist.recv(t, peer)
         buf.write(off, self._n(t))
 
-    def all_reduce_sum_f64(self, buf, off, count):
+    def _all_reduce_sum_f64_impl(self, buf, off, count):
         if self.world == 1 and not (self.loopback and self.transport == "rccl"):
             return
         self._acct(2 * count * 8)
@@ -300,7 +302,7 @@ class Comm:
         self.dist.all_reduce(t)
         buf.write(off, self._n(t))
 
-    def all_gather_host(self, arr):
+    def _all_gather_host_impl(self, arr):
         """A few host scalars per rank (e.g. PSO's per-round (first improver, fitness)) -> [world][k] float64."""
         a = np.ascontiguousarray(arr, np.float64).reshape(-1)
         if self.world == 1 and not (self.loopback and self.transport == "rccl"):
@@ -323,6 +325,50 @@ class Comm:
     def barrier(self):
         if self.world > 1 and self.dist is not None:
             self.dist.barrier()
+
+    # ---- the public collectives: the implementations above, timed on request ----
+    def _timed(self, fn, *a, **k):
+        if not self.timed or self.world == 1:
+            return fn(*a, **k)
+        if self.transport == "rccl" and self.engine is not None:
+            self.engine.span_begin()
+            try:
+                return fn(*a, **k)
+            finally:
+                self.engine.span_end()
+        t0 = time.perf_counter()
+        try:
+            return fn(*a, **k)
+        finally:
+            self.host_s += time.perf_counter() - t0
+
+    def all_gather(self, *a, **k):
+        return self._timed(self._all_gather_impl, *a, **k)
+
+    def broadcast(self, *a, **k):
+        return self._timed(self._broadcast_impl, *a, **k)
+
+    def send(self, *a, **k):
+        return self._timed(self._send_impl, *a, **k)
+
+    def recv(self, *a, **k):
+        return self._timed(self._recv_impl, *a, **k)
+
+    def all_reduce_sum_f64(self, *a, **k):
+        return self._timed(self._all_reduce_sum_f64_impl, *a, **k)
+
+    def all_gather_host(self, *a, **k):
+        return self._timed(self._all_gather_host_impl, *a, **k)
+
+    def exchange_ms(self, reset=True):
+        """Milliseconds spent in the collectives since the last reset (timed = True): event time on the engine's stream for the
+        rccl transport, host wall time for the host-staged ones."""
+        ms = self.host_s * 1e3
+        if self.transport == "rccl" and self.engine is not None and self.world > 1:
+            ms += self.engine.span_total(reset)[0]
+        if reset:
+            self.host_s = 0.0
+        return ms
 
 
 def _counts(n, world):

@@ -271,6 +271,19 @@ class Engine:
         self._ck(self.L.pf_d2h_counts(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def span_begin(self):
+        """Open a HIP-event timed span on the engine's stream (closed by span_end; not nested, nothing synchronises)."""
+        self._ck(self.L.pf_span_begin(self.h))
+
+    def span_end(self):
+        self._ck(self.L.pf_span_end(self.h))
+
+    def span_total(self, reset=True):
+        """(milliseconds, spans) summed since the last reset; synchronises the stream."""
+        ms, cnt = C.c_double(0.0), C.c_int64(0)
+        self._ck(self.L.pf_span_total(self.h, C.byref(ms), C.byref(cnt), 1 if reset else 0))
+        return ms.value, cnt.value
+
     def read(self, ptr, count, dtype):
         """A small typed read from device memory (row reads on demand)."""
         out = np.empty(int(count), dtype)
