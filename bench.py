@@ -203,6 +203,9 @@ def measure(run, eng, comm, sync_all, world, torch, dist, local_rank, backend):
         run.pre()
     eng.klog = []
     sync_all()
+    if world > 1:                                       # the exchange block counts the timed region only (not warm-up / set-up waits)
+        comm.exchange_ms(reset=True)
+        run.x0 = (comm.bytes_moved, comm.calls)
     t0 = time.perf_counter()
     for _ in range(K):
         if os.environ.get("PF_BENCH_TRACE"):           # diagnostic: host wall time of every step, to stderr
@@ -442,17 +445,15 @@ def main():
         if comm.engine is None:
             comm.engine = eng      # (host-staged transports: the engine the exchange buffers live on)
         comm.timed = world > 1
-        b0, c0 = comm.bytes_moved, comm.calls
         value, dt, roof = measure(run, eng, comm, sync_all, world, torch, dist, local_rank, a.backend)
         if world > 1:
-            # the exchange of the timed region AND its warm-up (spans are folded once, after the region: nothing synchronises
-            # inside it); per step = over all steps that ran
-            steps_run = K_ + W_ + getattr(run, "setup_steps", 0)
-            run.cfg["exchange"] = {"transport": comm.transport, "bytes_per_rank_per_step": int((comm.bytes_moved - b0) / max(steps_run, 1)),
-                                   "calls_per_step": round((comm.calls - c0) / max(steps_run, 1), 2),
-                                   "exchange_ms_per_step": round(comm.exchange_ms(reset=True) / max(steps_run, 1), 4),
-                                   "timer": "HIP events on the engine's stream around every pf_comm_* call" if comm.transport == "rccl"
-                                            else "host clock around every host-staged torch.distributed call"}
+            # the exchange of the timed region (the spans are folded once, after the region: nothing synchronises inside it)
+            b0, c0 = run.x0
+            run.cfg["exchange"] = {"transport": comm.transport, "bytes_per_rank_per_step": int((comm.bytes_moved - b0) / max(K_, 1)),
+                                   "calls_per_step": round((comm.calls - c0) / max(K_, 1), 2),
+                                   "exchange_ms_per_step": round(comm.exchange_ms(reset=True) / max(K_, 1), 4),
+                                   "timer": "HIP events on the engine's stream around every pf_comm_* call (rank 0)" if comm.transport == "rccl"
+                                            else "host clock around every host-staged torch.distributed call, waits for the slower rank included (rank 0)"}
         return run, eng, grid, value, dt, roof
 
     run, eng, grid, value, dt, roof = run_one(a.workload, K, W)

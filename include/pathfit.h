@@ -174,6 +174,7 @@ int pf_maaco_update(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_
                     double best_len_overall);
 /* One whole iteration of MAACO.solve_path_planning (MAACO.py:340-359) for the ants of one GPU, enqueued back to back: walks,
  * best-of-iteration scan (:343-349), take-over test against the caller's overall best (:351-358), one-pass pheromone update.
+ * The overall best ant's path row stays in HBM (pf_maaco_best_path reads it on demand).
  * ONE 104-byte block comes back: out13 = {ib_len, ib_turns, ib_idx, took, best_len, best_turns, tmin, tmax, skipped, steps,
  * candidates, path_cells, overflow_agents}.  overflow_agents > 0: the pheromone was left untouched (skipped = 1); repeat
  * the call with longer path rows.  The call returns once the take-over test is known (the device mirrors out13 into pinned
@@ -182,6 +183,9 @@ int pf_maaco_update(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_
 int pf_maaco_iterate(pf_handle* h, int32_t iter, uint64_t seed, int32_t ant0, int32_t n, int32_t path_cap,
                      int32_t* d_cells, int32_t* d_len, double* d_plen, int32_t* d_turns, int32_t* d_status,
                      double best_len, double best_turns, double* out13);
+/* MAACO.best_path_overall (MAACO.py:351-358), kept in HBM by pf_maaco_iterate: whenever an iteration's best ant takes over, its
+ * path row is copied on the device.  This call materialises it: *len_out cells into cells_out[cap] (0: no ant has arrived yet). */
+int pf_maaco_best_path(pf_handle* h, int32_t* cells_out, int32_t cap, int32_t* len_out);
 /* pheromone_matrix attribute round trip (double[R*C]) */
 int pf_maaco_get_pheromone(pf_handle* h, double* tau);
 int pf_maaco_set_pheromone(pf_handle* h, const double* tau);

@@ -509,6 +509,7 @@ struct MaacoArgs {
   // chunk flags of the bit matrix: byte [cell >> 6][word] != 0 whenever some cell of that 64-cell stretch has a bit in that word
   // (plain stores of the same value; k_tau_update reads only flagged 512-byte chunks and clears the flags it used)
   uint8_t* flag; int fstride;
+  int groups;             // k_maaco_walk8: 8-lane groups of a wavefront that walk ants (8; fewer = fewer ants per wave, more waves)
 };
 
 __global__ void k_pack_tep(int RC, const double* tau, const double* eta, double* tep) {
@@ -734,7 +735,7 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
   double plen = 0.0;
   Rng g; g.key = 0; g.ctr = 0; g.kc = 0;
   int* out = p.cells;
-  bool need = true, alive = true;
+  bool need = true, alive = grp < p.groups;
 #ifdef PF_WALK_PROBE
   unsigned long long pr_wait = 0, pr_rounds = 0, pr_mark = 0, pr_sel0 = 0, pr_sel1 = 0, pr_head = 0, pr_emit = 0, pr_upd = 0, pr_loop = 0, pr_end = 0, pr_act = 0; const unsigned long long pr_t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1133,12 +1134,27 @@ PF_DEV void maaco_take(const double* scan3, double best_len, double best_turns, 
 // The scan and the take-over test of one iteration in ONE launch (a 1024-thread block): thread 0 runs the test once the block's
 // scan is in `scan3`, mirrors the 13 doubles into `host_state` (pinned, device-visible host memory: the caller reads them after an
 // event, no copy is enqueued) and hands the iteration's private work counter / counters back zeroed for the next walk.
+// When the iteration's best ant takes over the overall best (and no ant overflowed), its path row is copied into `best_row`
+// ([0] = length, then the cells): the walk buffer is overwritten by the next iteration, the overall best stays in HBM and
+// reaches the host only when somebody reads it (pf_maaco_best_path).
 __global__ __launch_bounds__(1024) void k_maaco_best_take(int n, const double* plen, const int* turns, double* scan3, double best_len,
                                                          double best_turns, double rho, int R, int C, int* work, DevCounters* cnt,
-                                                         double* state, double* host_state) {
+                                                         double* state, double* host_state, const int* cells, const int* len, int path_cap,
+                                                         int* best_row) {
+  __shared__ int s_take;
   maaco_best_block(n, plen, turns, scan3);
-  if (threadIdx.x != 0) return;                                    // (thread 0 wrote scan3 itself: program order)
-  maaco_take(scan3, best_len, best_turns, rho, R, C, cnt, state);
+  if (threadIdx.x == 0) {                                          // (thread 0 wrote scan3 itself: program order)
+    maaco_take(scan3, best_len, best_turns, rho, R, C, cnt, state);
+    s_take = (state[3] != 0.0 && state[8] == 0.0 && state[2] >= 0.0) ? (int)state[2] : -1;
+  }
+  __syncthreads();
+  const int a = s_take;
+  if (a >= 0 && best_row) {
+    const int L = len[a];
+    for (int i = threadIdx.x; i < L; i += 1024) best_row[1 + i] = cells[(size_t)a * path_cap + i];
+    if (threadIdx.x == 0) best_row[0] = L;
+  }
+  if (threadIdx.x != 0) return;
   for (int k = 0; k < 13; ++k) host_state[k] = state[k];
   *work = 0;
   DevCounters z; memset(&z, 0, sizeof(z)); *cnt = z;
@@ -2119,6 +2135,7 @@ struct pf_handle {
   int marks_n = 0; const int* marks_cells = nullptr;   // the last walk batch marked its own deposits (for these n ants / this path buffer)
   double* d_mstate = nullptr;         // pf_maaco_iterate's 13 doubles
   double* h_mstate = nullptr; double* h_mstate_dev = nullptr;   // ... mirrored by the device into pinned host memory (no copy is enqueued)
+  int* d_best_row = nullptr; int best_row_cap = 0;   // the overall best ant's path row, [0] = length (pf_maaco_iterate / pf_maaco_best_path)
   char* d_mctl = nullptr;             // pf_maaco_iterate's own {work counter @0, DevCounters @16}: zeroed by k_maaco_best_take for the next walk
   bool mctl_clean = false;
   unsigned* d_visit = nullptr; unsigned* d_visit_epoch = nullptr; int maaco_slots = 0;
@@ -2286,7 +2303,7 @@ void pf_destroy(pf_handle* h) {
   if (h->comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(h->stream); g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
   void* ptrs[] = {h->d_occ, h->d_mm_r1, h->d_mm_r0, h->d_mm_r1_nd, h->d_mm_r0_nd, h->d_d2near, h->d_rec, h->d_slot_state,
                   h->d_work, h->d_cnt, h->d_pen, h->d_tier2, h->d_tau, h->d_taua, h->d_eta, h->d_dep, h->d_tep, h->d_visit, h->d_visit_epoch,
-                  h->d_bits, h->d_flag, h->d_mstate, h->d_mctl, h->d_d2wide, h->d_penw, h->d_tmp, h->d_elite_stats, h->d_init_cells, h->d_init_stats, h->d_est, h->d_queue, h->d_jobs, h->d_jres, h->d_prop, h->d_doubt, h->d_scan, h->d_scan3, h->d_okey, h->d_opay, h->d_orank, h->d_elite_cells, h->d_elite_len, h->d_ga_pool, h->d_st_lab, h->d_st_touched, h->d_st_par, h->d_st_epoch,
+                  h->d_bits, h->d_flag, h->d_mstate, h->d_mctl, h->d_best_row, h->d_d2wide, h->d_penw, h->d_tmp, h->d_elite_stats, h->d_init_cells, h->d_init_stats, h->d_est, h->d_queue, h->d_jobs, h->d_jres, h->d_prop, h->d_doubt, h->d_scan, h->d_scan3, h->d_okey, h->d_opay, h->d_orank, h->d_elite_cells, h->d_elite_len, h->d_ga_pool, h->d_st_lab, h->d_st_touched, h->d_st_par, h->d_st_epoch,
                   h->d_comp[0], h->d_comp[1], h->d_comp[2], h->d_comp[3], h->d_ds, h->d_dt};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : h->span_ev) (void)hipEventDestroy(e);
@@ -2356,6 +2373,7 @@ static int g_settle = env_int("PF_SETTLE", -1);  // closed-set searches try the 
 static double g_doubt_log = 1.0 / 8589934592.0;   // 2^-33 relative margin on normalvariate's accept test (pf_set_option "mpa_doubt_log_e15" overrides, in 1e-15)
 static double g_doubt_round = 1e-7;                // absolute margin on the fraction fed to round()   ("mpa_doubt_round_e15")
 static int g_maaco_pack8_min = env_int("PF_MAACO_PACK8_MIN", 2048);   // ants per batch from which 8 ants share a wavefront
+static int g_maaco_groups = env_int("PF_MAACO_GROUPS", 8);   // ants per wavefront of k_maaco_walk8 (pf_set_option "maaco_ants_per_wave": 1..8)
 static int g_maaco_mark = env_int("PF_MAACO_MARK", 1);   // successful ants mark their deposits in the walk kernel (pf_set_option "maaco_mark_in_walk")
 static int g_tabu_epoch = -1;                      // test hook ("maaco_tabu_epoch"): >= 0 -> the next walk batch starts its tabu slots from this epoch (wrap coverage)
 static const int kLdsS = 16;
@@ -2720,6 +2738,7 @@ int pf_set_option(pf_handle* h, const char* name, int64_t value) {
   if (!name) return failmsg(h, "pf_set_option: bad arguments");
   if (!strcmp(name, "astar_step_cap")) { g_step_cap = value > 0 ? (long long)value : 0; return 0; }
   if (!strcmp(name, "maaco_pack8_min")) { g_maaco_pack8_min = (int)value; return 0; }
+  if (!strcmp(name, "maaco_ants_per_wave")) { g_maaco_groups = value < 1 ? 1 : (value > 8 ? 8 : (int)value); return 0; }
   if (!strcmp(name, "mpa_prune")) { g_mpa_prune = value != 0; return 0; }
 #ifdef PF_TWO_WAVE
   if (!strcmp(name, "two_wave")) { g_two_wave = value != 0; return 0; }
@@ -2821,6 +2840,7 @@ int pf_maaco_setup(pf_handle* h, const pf_maaco_params* p) {
   }
   CK(hipFuncSetAttribute((const void*)k_tau_update, hipFuncAttributeMaxDynamicSharedMemorySize, PF_DEP_CHUNK * (int)sizeof(double)));
   h->maaco_ready = true;
+  if (h->d_best_row) CK(hipMemsetAsync(h->d_best_row, 0, sizeof(int), h->stream));   // a new colony has no best path yet
   return maaco_refresh_taua(h);
 }
 
@@ -2886,8 +2906,9 @@ static int maaco_enqueue_walk(pf_handle* h, int32_t iter, uint64_t seed, int32_t
   }
   // eight ants per wavefront (k_maaco_walk8) once the batch can fill the chip that way; else one per wave
   const bool pack8 = n >= g_maaco_pack8_min;
+  a.groups = g_maaco_groups;
   int grid = pack8 ? h->maaco_slots / 8 : (h->maaco_slots < 8192 ? h->maaco_slots : 8192);
-  const int need = pack8 ? (n + 7) / 8 : n; if (grid > need) grid = need;
+  const int need = pack8 ? (n + a.groups - 1) / a.groups : n; if (grid > need) grid = need;
   if (own_ctl) {                                                    // pf_maaco_iterate: the previous iteration's last reader left the block zeroed
     if (!h->d_mctl) { CK(hipMalloc(&h->d_mctl, 16 + sizeof(DevCounters))); h->mctl_clean = false; }
     if (!h->mctl_clean) CK(hipMemsetAsync(h->d_mctl, 0, 16 + sizeof(DevCounters), h->stream));
@@ -2940,9 +2961,16 @@ int pf_maaco_iterate(pf_handle* h, int32_t iter, uint64_t seed, int32_t ant0, in
     CK(hipHostGetDevicePointer((void**)&h->h_mstate_dev, h->h_mstate, 0));
   }
   double* hs_dev = h->h_mstate_dev;
+  if (h->best_row_cap < path_cap + 1) {                             // (a longer row keeps the best so far: same stream, ordered)
+    int* nb = nullptr; CK(hipMalloc(&nb, sizeof(int) * ((size_t)path_cap + 1)));
+    if (h->d_best_row) { CK(hipMemcpyAsync(nb, h->d_best_row, sizeof(int) * (size_t)h->best_row_cap, hipMemcpyDeviceToDevice, h->stream)); CK(hipStreamSynchronize(h->stream)); CK(hipFree(h->d_best_row)); }
+    else CK(hipMemsetAsync(nb, 0, sizeof(int), h->stream));
+    h->d_best_row = nb; h->best_row_cap = path_cap + 1;
+  }
   if (maaco_enqueue_walk(h, iter, seed, ant0, n, path_cap, d_cells, d_len, d_plen, d_turns, d_status, true, true)) return -1;   // (this path always marks)
   hipLaunchKernelGGL(k_maaco_best_take, dim3(1), dim3(1024), 0, h->stream, n, (const double*)d_plen, (const int*)d_turns, (double*)h->d_scan3,
-                     best_len, best_turns, h->mp.rho, h->R, h->C, (int*)h->d_mctl, (DevCounters*)(h->d_mctl + 16), h->d_mstate, hs_dev);
+                     best_len, best_turns, h->mp.rho, h->R, h->C, (int*)h->d_mctl, (DevCounters*)(h->d_mctl + 16), h->d_mstate, hs_dev,
+                     (const int*)d_cells, (const int*)d_len, path_cap, h->d_best_row);
   CK(hipEventRecord(h->ev2, h->stream));
   const int words = (n + 63) / 64;
   hipLaunchKernelGGL(k_tau_update, dim3((h->RC + 1023) / 1024), dim3(1024), PF_DEP_CHUNK * sizeof(double), h->stream, h->d_tau, h->d_occ,
@@ -2961,6 +2989,22 @@ int pf_maaco_iterate(pf_handle* h, int32_t iter, uint64_t seed, int32_t ant0, in
   h->marks_n = 0;
   h->bits_clean = out13[8] == 0.0;                                  // the update pass read and zeroed every word (a skipped one did not)
   if (out13[8] == 0.0) return maaco_refresh_taua(h);                // (alpha == 1: nothing to do, nothing waits)
+  return 0;
+}
+
+// The overall best ant's path as pf_maaco_iterate keeps it in HBM: *len_out cells (0: none yet) into cells_out[cap].
+int pf_maaco_best_path(pf_handle* h, int32_t* cells_out, int32_t cap, int32_t* len_out) {
+  if (!h) return -2;
+  if (!len_out || cap < 0 || (cap > 0 && !cells_out)) return failmsg(h, "pf_maaco_best_path: bad arguments");
+  *len_out = 0;
+  if (!h->d_best_row) return 0;
+  CK(hipSetDevice(h->device));
+  int L = 0;
+  if (pf_d2h(h, &L, h->d_best_row, sizeof(int))) return -1;
+  if (L < 0 || L > h->best_row_cap - 1) return failmsg(h, "pf_maaco_best_path: corrupt row");
+  *len_out = L;
+  if (L > cap) return failmsg(h, "pf_maaco_best_path: the buffer is too small");
+  if (L > 0 && pf_d2h(h, cells_out, h->d_best_row + 1, (int64_t)sizeof(int) * L)) return -1;
   return 0;
 }
 

@@ -70,6 +70,7 @@ SYMBOLS = {
     "pf_maaco_clip": (C.c_int, [_vp, _dbl]),
     "pf_maaco_update": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _dbl]),
     "pf_maaco_iterate": (C.c_int, [_vp, _i32, _u64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _vp]),
+    "pf_maaco_best_path": (C.c_int, [_vp, _vp, _i32, C.POINTER(_i32)]),
     "pf_maaco_get_pheromone": (C.c_int, [_vp, _vp]),
     "pf_maaco_set_pheromone": (C.c_int, [_vp, _vp]),
     "pf_maaco_tau_dev": (_vp, [_vp]),

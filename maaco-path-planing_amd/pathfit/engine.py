@@ -320,6 +320,13 @@ class Engine:
         return {"ib_len": float(out[0]), "ib_turns": float(out[1]), "ib_idx": int(out[2]), "took": out[3] != 0.0, "best_len": float(out[4]),
                 "best_turns": float(out[5]), "skipped": out[8] != 0.0, "overflow_agents": int(out[12])}
 
+    def maaco_best_path(self, cap):
+        """The overall best ant's cells as pf_maaco_iterate keeps them in HBM (empty: none yet)."""
+        out = np.empty(int(cap), np.int32)
+        L = C.c_int32(0)
+        self._ck(self.L.pf_maaco_best_path(self.h, out.ctypes.data, int(cap), C.byref(L)))
+        return out[:L.value].copy()
+
     def maaco_evaporate(self):
         self._ck(self.L.pf_maaco_evaporate(self.h))
 

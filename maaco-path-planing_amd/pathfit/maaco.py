@@ -42,7 +42,7 @@ class MAACO:
         self.engine.maaco_setup(MaacoParams(float(alpha), float(beta), float(rho), float(Q), float(a_turn_coef),
                                             float(wh_max), float(wh_min), float(k_h_adaptive), float(q0_initial),
                                             float(C0_initial_pheromone), int(num_iterations), s, t))
-        self.best_path_overall = []
+        self._best_path, self._best_on_device = [], False   # best_path_overall: host list, or still in HBM (materialised on access)
         self.best_path_length_overall = INF
         self.best_path_turns_overall = INF
         self.convergence_curve_data = []
@@ -50,6 +50,18 @@ class MAACO:
         self._bufs = None
 
     # public state the reference exposes (MAACO.py:47-48, :373)
+    @property
+    def best_path_overall(self):
+        """MAACO.py:351-358: a list of (r, c).  The one-enqueue iteration keeps the row in HBM; it crosses PCIe here, once."""
+        if self._best_on_device:
+            self._best_path = CellPath(self.engine.maaco_best_path(self.path_cap), self.cols).tolist()
+            self._best_on_device = False
+        return self._best_path
+
+    @best_path_overall.setter
+    def best_path_overall(self, v):
+        self._best_path, self._best_on_device = v, False
+
     @property
     def pheromone_matrix(self):
         return self.engine.maaco_get_pheromone()
@@ -113,7 +125,7 @@ class MAACO:
     def iterate_dev(self, iter_num, ant0=0, n=None):
         """One iteration of solve_path_planning (MAACO.py:340-359) for ants [ant0, ant0 + n), everything enqueued back to back on
         the device -- walks, best-of-iteration scan, take-over test (:351-358), one-pass pheromone update -- with ONE 104-byte
-        copy back (the path row of a new overall best follows only when there is one).  -> ib_len."""
+        block back (the path row of a new overall best stays in HBM until `best_path_overall` is read).  -> ib_len."""
         n = self.num_ants if n is None else n
         while True:
             dc, dl, dp, dt, ds = self._alloc(n)
@@ -127,7 +139,7 @@ class MAACO:
             break
         if r["took"] and r["ib_idx"] >= 0:
             self.best_path_length_overall = r["best_len"]
-            self.best_path_overall = self.ant_path(r["ib_idx"]).tolist()
+            self._best_on_device = True                                    # (k_maaco_best_take copied the row on the device)
             self.best_path_turns_overall = int(r["best_turns"]) if r["best_turns"] != INF else INF
         self.convergence_curve_data.append(self.best_path_length_overall if self.best_path_length_overall != INF else None)
         return r["ib_len"]
