@@ -143,6 +143,20 @@ int pf_decode_batch(pf_handle* h, int32_t allow_diag, int32_t restrict_corner, i
 int pf_pso_update(pf_handle* h, int32_t n, int32_t W, double w, double c1, double c2, double max_vel,
                   double* d_pos, double* d_vel, const double* d_pbest, const double* d_gbest, uint64_t seed,
                   uint64_t iter, uint64_t agent0);
+/* The same update, asynchronous (stream ordered), leaving the pre-update position / velocity of every particle in
+ * d_pos_keep / d_vel_keep: the roll-back copy of the asynchronous sweep (pso.py:222-229: a particle evaluated on a gbest that
+ * an earlier particle of the sweep has moved must be evaluated again from its old state). */
+int pf_pso_update_keep(pf_handle* h, int32_t n, int32_t W, double w, double c1, double c2, double max_vel,
+                       double* d_pos, double* d_vel, const double* d_pbest, const double* d_gbest, uint64_t seed,
+                       uint64_t iter, uint64_t agent0, double* d_pos_keep, double* d_vel_keep);
+/* One round of the asynchronous sweep committed in one launch, for the evaluated batch [0, m): particles [0, n_final) are
+ * final -- pso.py:216-220 (pbest position, fitness AND path row) --, `improver` (< n_final, or -1) is the round's first gbest
+ * improver -- pso.py:222-229: its position -> d_gbest[W*2], its five stats -> d_gbest_stats[5], its path -> d_gbest_path
+ * ([0] = length, then the cells) --, particles [n_final, m) roll back to d_pos_keep / d_vel_keep.  Asynchronous. */
+int pf_pso_commit(pf_handle* h, int32_t m, int32_t W, int32_t path_cap, int32_t n_final, int32_t improver, double* d_pos,
+                  double* d_vel, const double* d_pos_keep, const double* d_vel_keep, const double* d_stats, const int32_t* d_len,
+                  const int32_t* d_cells, double* d_pbest, double* d_pbest_fit, int32_t* d_pb_cells, int32_t* d_pb_len,
+                  double* d_gbest, double* d_gbest_stats, int32_t* d_gbest_path);
 /* pbest bookkeeping pso.py:216-220: where stats fitness < pbest_fit (strict),
  * copy pos -> pbest and fitness -> pbest_fit.  d_improved int32[n] out. */
 int pf_pso_pbest(pf_handle* h, int32_t n, int32_t W, const double* d_pos, const double* d_stats,

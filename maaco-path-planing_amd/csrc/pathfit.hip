@@ -390,6 +390,7 @@ struct PsoArgs {
   int n, W, R, C; double w, c1, c2, max_vel;
   double* pos; double* vel; const double* pbest; const double* gbest;
   unsigned long long seed, iter, agent0;
+  double* pos_keep; double* vel_keep;   // non-null: the pre-update values are left here (the asynchronous sweep's roll-back copy)
 };
 // one thread per (particle, waypoint): the counter RNG is random access, so
 // waypoint d starts at draw 4*d of the particle's stream (pso.py:186-190 order).
@@ -403,8 +404,9 @@ __global__ void k_pso_update(PsoArgs p) {
     const size_t i = ((size_t)part * p.W + d) * 2 + ax;
     const double hi = ax == 0 ? (double)(p.R - 1) : (double)(p.C - 1);
     const double r1 = g.random(), r2 = g.random();
-    const double x = p.pos[i];
-    double v = p.w * p.vel[i] + p.c1 * r1 * (p.pbest[i] - x) + p.c2 * r2 * (p.gbest[d * 2 + ax] - x);
+    const double x = p.pos[i], v0 = p.vel[i];
+    if (p.pos_keep) { p.pos_keep[i] = x; p.vel_keep[i] = v0; }
+    double v = p.w * v0 + p.c1 * r1 * (p.pbest[i] - x) + p.c2 * r2 * (p.gbest[d * 2 + ax] - x);
     v = fmin(fmax(v, -p.max_vel), p.max_vel);                     // np.clip pso.py:192-193
     double nx = x + v;
     nx = fmin(fmax(nx, 0.0), hi);                                 // np.clip pso.py:201-202
@@ -430,6 +432,38 @@ __global__ __launch_bounds__(64) void k_pso_pbest_paths(int n, int path_cap, con
   const int L = len[a];
   for (int i = threadIdx.x; i < L; i += 64) pb_cells[(size_t)a * path_cap + i] = cells[(size_t)a * path_cap + i];
   if (threadIdx.x == 0) pb_len[a] = L;
+}
+// One round of the asynchronous sweep committed in ONE launch (it was pbest + pbest paths + two / four device-to-device copies
+// + two small reads, each behind a stream synchronisation).  Block a = particle a of the evaluated batch [0, m):
+//   a <  k   final: pso.py:216-220 -- fitness below its pbest (strict) -> position, fitness and path row become the pbest;
+//   a == j   (j < k, or -1) the round's gbest improver: pso.py:222-229 -- its position, five stats and path row (length first)
+//            go to the gbest buffers;
+//   a >= k   evaluated on a gbest that has moved since: position and velocity roll back to the values k_pso_update kept.
+__global__ __launch_bounds__(64) void k_pso_commit(int m, int W, int path_cap, int k, int j, double* pos, double* vel,
+                                                   const double* pos_keep, const double* vel_keep, const double* stats, const int* len,
+                                                   const int* cells, double* pbest, double* pbest_fit, int* pb_cells, int* pb_len,
+                                                   double* gb, double* gstats, int* gpath) {
+  const int a = blockIdx.x, t = threadIdx.x;
+  if (a >= m) return;
+  const size_t w0 = (size_t)a * W * 2;
+  if (a >= k) {                                                   // roll back
+    for (int i = t; i < W * 2; i += 64) { pos[w0 + i] = pos_keep[w0 + i]; vel[w0 + i] = vel_keep[w0 + i]; }
+    return;
+  }
+  const int L = len[a];
+  const double fit = stats[(size_t)a * 5 + 4];
+  if (a == j) {                                                   // the gbest moves here (decided by k_pso_scan against the OLD pbest: read before it changes)
+    for (int i = t; i < W * 2; i += 64) gb[i] = pos[w0 + i];
+    if (t < 5) gstats[t] = stats[(size_t)a * 5 + t];
+    for (int i = t; i < L; i += 64) gpath[1 + i] = cells[(size_t)a * path_cap + i];
+    if (t == 0) gpath[0] = L;
+  }
+  const bool better = L > 0 && fit < pbest_fit[a];               // pso.py:210,216
+  if (!better) return;
+  for (int i = t; i < W * 2; i += 64) pbest[w0 + i] = pos[w0 + i];
+  for (int i = t; i < L; i += 64) pb_cells[(size_t)a * path_cap + i] = cells[(size_t)a * path_cap + i];
+  __syncthreads();                                                // (every thread has read pbest_fit[a] before it changes)
+  if (t == 0) { pbest_fit[a] = fit; pb_len[a] = L; }
 }
 // pbest -> gbest scan over particles [0, n) of one evaluated batch (pso.py:216-229), one block.  A particle improves
 // the gbest when its path is feasible and its fitness is below both its own pbest (:216) and the gbest (:222).
@@ -2661,7 +2695,7 @@ int pf_pso_update(pf_handle* h, int32_t n, int32_t W, double w, double c1, doubl
   if (n < 0 || W < 1 || !d_pos || !d_vel || !d_pbest || !d_gbest) return failmsg(h, "pf_pso_update: bad arguments");
   if (n == 0) return 0;
   CK(hipSetDevice(h->device));
-  PsoArgs a{n, W, h->R, h->C, w, c1, c2, max_vel, d_pos, d_vel, d_pbest, d_gbest, seed, iter, agent0};
+  PsoArgs a{n, W, h->R, h->C, w, c1, c2, max_vel, d_pos, d_vel, d_pbest, d_gbest, seed, iter, agent0, nullptr, nullptr};
   const int threads = 256, blocks = (n * W + threads - 1) / threads;
   CK(hipEventRecord(h->ev0, h->stream));
   hipLaunchKernelGGL(k_pso_update, dim3(blocks), dim3(threads), 0, h->stream, a);
@@ -2669,6 +2703,37 @@ int pf_pso_update(pf_handle* h, int32_t n, int32_t W, double w, double c1, doubl
   CK(hipEventRecord(h->ev1, h->stream));
   CK(hipStreamSynchronize(h->stream));
   CK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+  return 0;
+}
+
+// pf_pso_update that also leaves the pre-update position / velocity in d_pos_keep / d_vel_keep; asynchronous (stream ordered)
+int pf_pso_update_keep(pf_handle* h, int32_t n, int32_t W, double w, double c1, double c2, double max_vel, double* d_pos,
+                       double* d_vel, const double* d_pbest, const double* d_gbest, uint64_t seed, uint64_t iter,
+                       uint64_t agent0, double* d_pos_keep, double* d_vel_keep) {
+  if (!h) return -2;
+  if (n < 0 || W < 1 || !d_pos || !d_vel || !d_pbest || !d_gbest || !d_pos_keep || !d_vel_keep) return failmsg(h, "pf_pso_update_keep: bad arguments");
+  if (n == 0) return 0;
+  CK(hipSetDevice(h->device));
+  PsoArgs a{n, W, h->R, h->C, w, c1, c2, max_vel, d_pos, d_vel, d_pbest, d_gbest, seed, iter, agent0, d_pos_keep, d_vel_keep};
+  const int threads = 256, blocks = (n * W + threads - 1) / threads;
+  hipLaunchKernelGGL(k_pso_update, dim3(blocks), dim3(threads), 0, h->stream, a);
+  CK(hipGetLastError());
+  return 0;
+}
+// one round of the asynchronous sweep committed in one launch (k_pso_commit); asynchronous (stream ordered)
+int pf_pso_commit(pf_handle* h, int32_t m, int32_t W, int32_t path_cap, int32_t n_final, int32_t improver, double* d_pos,
+                  double* d_vel, const double* d_pos_keep, const double* d_vel_keep, const double* d_stats, const int32_t* d_len,
+                  const int32_t* d_cells, double* d_pbest, double* d_pbest_fit, int32_t* d_pb_cells, int32_t* d_pb_len,
+                  double* d_gbest, double* d_gbest_stats, int32_t* d_gbest_path) {
+  if (!h) return -2;
+  if (m < 0 || W < 1 || path_cap < 1 || n_final < 0 || n_final > m || improver >= n_final || !d_pos || !d_vel || !d_stats || !d_len || !d_cells ||
+      !d_pbest || !d_pbest_fit || !d_pb_cells || !d_pb_len || (n_final < m && (!d_pos_keep || !d_vel_keep)) ||
+      (improver >= 0 && (!d_gbest || !d_gbest_stats || !d_gbest_path))) return failmsg(h, "pf_pso_commit: bad arguments");
+  if (m == 0) return 0;
+  CK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(k_pso_commit, dim3(m), dim3(64), 0, h->stream, m, W, path_cap, n_final, improver, d_pos, d_vel, d_pos_keep, d_vel_keep,
+                     d_stats, d_len, d_cells, d_pbest, d_pbest_fit, d_pb_cells, d_pb_len, d_gbest, d_gbest_stats, d_gbest_path);
+  CK(hipGetLastError());
   return 0;
 }
 

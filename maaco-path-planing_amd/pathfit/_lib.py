@@ -63,6 +63,8 @@ SYMBOLS = {
                                   C.POINTER(ScoreParams), _vp]),
     "pf_pso_update": (C.c_int, [_vp, _i32, _i32, _dbl, _dbl, _dbl, _dbl, _vp, _vp, _vp, _vp, _u64, _u64, _u64]),
     "pf_pso_pbest": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pf_pso_update_keep": (C.c_int, [_vp, _i32, _i32, _dbl, _dbl, _dbl, _dbl, _vp, _vp, _vp, _vp, _u64, _u64, _u64, _vp, _vp]),
+    "pf_pso_commit": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pf_maaco_setup": (C.c_int, [_vp, C.POINTER(MaacoParams)]),
     "pf_maaco_walk_batch": (C.c_int, [_vp, _i32, _u64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "pf_maaco_evaporate": (C.c_int, [_vp]),

@@ -245,6 +245,18 @@ class Engine:
         self._ck(self.L.pf_pso_update(self.h, n, W, w, c1, c2, max_vel, pos_ptr, vel_ptr, pbest_ptr, gbest_ptr,
                                       int(seed), int(it), int(agent0)))
 
+    def pso_update_keep_raw(self, n, W, w, c1, c2, max_vel, pos_ptr, vel_ptr, pbest_ptr, gbest_ptr, seed, it, agent0, pos_keep_ptr, vel_keep_ptr):
+        """pso_update_raw + the pre-update position / velocity kept for the roll-back; nothing synchronises."""
+        self._ck(self.L.pf_pso_update_keep(self.h, n, W, w, c1, c2, max_vel, pos_ptr, vel_ptr, pbest_ptr, gbest_ptr,
+                                           int(seed), int(it), int(agent0), pos_keep_ptr, vel_keep_ptr))
+
+    def pso_commit_raw(self, m, W, path_cap, n_final, improver, pos_ptr, vel_ptr, pos_keep_ptr, vel_keep_ptr, stats_ptr, len_ptr, cells_ptr,
+                       pbest_ptr, pbf_ptr, pb_cells_ptr, pb_len_ptr, gb_ptr, gstats_ptr, gpath_ptr):
+        """One round of the asynchronous sweep committed in one launch (pbest + paths, gbest move, roll-back); nothing synchronises."""
+        self._ck(self.L.pf_pso_commit(self.h, int(m), int(W), int(path_cap), int(n_final), int(improver), pos_ptr, vel_ptr, pos_keep_ptr,
+                                      vel_keep_ptr, stats_ptr, len_ptr, cells_ptr, pbest_ptr, pbf_ptr, pb_cells_ptr, pb_len_ptr, gb_ptr,
+                                      gstats_ptr, gpath_ptr))
+
     def decode_raw(self, n, W, start, target, path_cap, cells_ptr, len_ptr, status_ptr, wp_pos_ptr, sp, stats_ptr,
                    allow_diag=True, restrict_corner=True):
         self._ck(self.L.pf_decode_batch(self.h, int(allow_diag), int(restrict_corner), n, W, None, wp_pos_ptr,

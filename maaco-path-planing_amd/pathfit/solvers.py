@@ -614,15 +614,11 @@ class PSOSolver(_WaypointSolver):
         # cleared by collective steps only -- so either every rank enters the broadcasts below, with the same root, or none does)
         if d is None or c is None or c.world == 1 or self._gowner < 0 or self._gbest_everywhere:
             return
-        e = self.engine
-        hdr = self._d.setdefault("ghdr", e.buf(8, np.float64))
-        if c.rank == self._gowner:
-            hdr.write(0, d["stats"])
-        c.broadcast(hdr, 0, 5, self._gowner)
+        c.broadcast(self._d["gstats"], 0, 5, self._gowner)              # device row to device row (the owner's k_pso_commit wrote it)
         c.broadcast(self._d["gpath"], 0, 1, self._gowner)               # the length, then exactly that many cells
         L = int(self._d["gpath"].read(0, 1)[0])
         c.broadcast(self._d["gpath"], 1, L, self._gowner)
-        self._gbest_dev = dict(d, stats=hdr.read(0, 5), len=L)
+        self._gbest_dev = dict(d, host=False)
         self._gbest_everywhere = True                                    # every rank holds the row now (until a sweep moves the gbest)
 
     @property
@@ -635,8 +631,9 @@ class PSOSolver(_WaypointSolver):
                 # purely local view: the path row and the stats live on the owner until fetch_gbest() (a collective) is called
                 return {"fitness": float(d["fitness"]), "position": pos.tolist(), "path": None, "index": d["idx"], "owner_rank": self._gowner}
             if not d.get("host"):
-                cells = self._d["gpath"].read(1, d["len"])
-                self._set_gbest(d["idx"], pos, CellPath(cells, self.cols), d["stats"])
+                L = int(self._d["gpath"].read(0, 1)[0])                  # the row k_pso_commit left in HBM: length, cells, five stats
+                cells = self._d["gpath"].read(1, L)
+                self._set_gbest(d["idx"], pos, CellPath(cells, self.cols), self._d["gstats"].read(0, 5))
                 # the device-side record stays: whether fetch_gbest() has anything to do must not depend on which ranks happened to
                 # READ the property (a monitoring rank would otherwise leave the collective the others still enter)
                 self._gbest_dev = dict(d, host=True)
@@ -705,6 +702,7 @@ class PSOSolver(_WaypointSolver):
         d["stats"], d["imp"] = e.buf((m, 5), np.float64), e.buf(m, np.int32)
         d["pos0"], d["vel0"] = e.buf((m, W, 2), np.float64), e.buf((m, W, 2), np.float64)
         d["gpath"] = e.buf(cap + 1, np.int32)
+        d["gstats"] = e.buf(5, np.float64)
         d["pb_cells"], d["pb_len"] = e.buf((m, cap), np.int32), e.buf(m, np.int32)
         if n:
             d["pos"].upload(self._pos); d["vel"].upload(self._vel); d["pb"].upload(self._pbest); d["pbf"].upload(self._pbest_fit)
@@ -731,8 +729,8 @@ class PSOSolver(_WaypointSolver):
         particles after it are rolled back and re-evaluated (their draws are keyed per particle, so the re-evaluation
         consumes the same random numbers).  Synchronous mode commits the whole batch.  Sharded, the first improver is
         the smallest GLOBAL index over the ranks (16 B per rank per round), its owner broadcasts the new gbest position.
-        Device-to-host traffic: 16 bytes per launch (the improver scan) + 44 bytes per gbest change; no path, position
-        or stats column leaves HBM."""
+        Device-to-host traffic: 16 bytes per round (the improver scan) + the decode batch's counter block; no path, position or
+        stats column leaves HBM, and a round is four launches (update, decode, scan, commit) with no copy in between."""
         e, N, W, d, cap, it, c = self.engine, self.num_particles, self.num_waypoints, self._d, self._cap, self._it, self.comm
         world = c.world if c is not None else 1
         rank = c.rank if c is not None else 0
@@ -748,11 +746,9 @@ class PSOSolver(_WaypointSolver):
             idx, fit = -1, INF
             if m:
                 l0 = a0 - lo
-                if self.asynchronous:
-                    e.d2d(d["pos0"].at(l0 * W * 2), d["pos"].at(l0 * W * 2), m * st_sz)
-                    e.d2d(d["vel0"].at(l0 * W * 2), d["vel"].at(l0 * W * 2), m * st_sz)
-                e.pso_update_raw(m, W, self.w, self.c1, self.c2, self.max_vel, d["pos"].at(l0 * W * 2), d["vel"].at(l0 * W * 2),
-                                 d["pb"].at(l0 * W * 2), d["gb"].ptr, self.seed, it, a0)
+                # update (the pre-update position / velocity stay in pos0 / vel0 for the roll-back) -> decode + score -> scan
+                e.pso_update_keep_raw(m, W, self.w, self.c1, self.c2, self.max_vel, d["pos"].at(l0 * W * 2), d["vel"].at(l0 * W * 2),
+                                      d["pb"].at(l0 * W * 2), d["gb"].ptr, self.seed, it, a0, d["pos0"].at(l0 * W * 2), d["vel0"].at(l0 * W * 2))
                 e.decode_raw(m, W, s_cell, t_cell, cap, d["cells"].at(l0 * cap), d["len"].at(l0), d["st"].at(l0), d["pos"].at(l0 * W * 2),
                              self._sp, d["stats"].at(l0 * 5), self.allow_diagonal_moves, self.restrict_diagonal_near_obstacle_policy)
                 idx, fit, ovf = e.pso_scan(m, d["stats"].at(l0 * 5), d["len"].at(l0), d["st"].at(l0), d["pbf"].at(l0), gfit,
@@ -772,33 +768,24 @@ class PSOSolver(_WaypointSolver):
                 r_star, p_star, f_star = rank, mine, fit
             last_eval = N - 1 if not (self.asynchronous and self.max_speculation) else min(N, cur + int(self.max_speculation)) - 1
             upto = (p_star if p_star >= 0 else last_eval) if self.asynchronous else N - 1   # last particle whose evaluation is final
-            k = min(upto, hi - 1) - a0 + 1                                 # my evaluated particles that are final now
-            if m and k > 0:
+            if m:
+                # ONE launch commits the round (k_pso_commit): pso.py:216-220 for my final particles (pbest position, fitness, path
+                # row), pso.py:222-229 for the improver if it is mine (position, stats and path row stay in HBM), roll-back of the
+                # particles that were evaluated on a gbest that has moved.  No copy, nothing synchronises.
                 l0 = a0 - lo
-                e.pso_pbest_raw(k, W, d["pos"].at(l0 * W * 2), d["stats"].at(l0 * 5), d["len"].at(l0), d["pb"].at(l0 * W * 2),
-                                d["pbf"].at(l0), d["imp"].at(l0))                  # pso.py:216-220
-                e.pso_pbest_paths_raw(k, cap, d["cells"].at(l0 * cap), d["len"].at(l0), d["imp"].at(l0), d["pb_cells"].at(l0 * cap),
-                                      d["pb_len"].at(l0))
+                k = min(max(min(upto, hi - 1) - a0 + 1, 0), m)             # my evaluated particles that are final now
+                j = p_star - a0 if (p_star >= 0 and r_star == rank) else -1
+                e.pso_commit_raw(m, W, cap, k, j, d["pos"].at(l0 * W * 2), d["vel"].at(l0 * W * 2), d["pos0"].at(l0 * W * 2),
+                                 d["vel0"].at(l0 * W * 2), d["stats"].at(l0 * 5), d["len"].at(l0), d["cells"].at(l0 * cap),
+                                 d["pb"].at(l0 * W * 2), d["pbf"].at(l0), d["pb_cells"].at(l0 * cap), d["pb_len"].at(l0),
+                                 d["gb"].ptr, d["gstats"].ptr, d["gpath"].ptr)
             if p_star >= 0:                                                # pso.py:222-229: gbest moves to particle p*
-                if r_star == rank:
-                    j = p_star - lo
-                    e.d2d(d["gb"].ptr, d["pos"].at(j * W * 2), st_sz)
-                    stats_j = e.read(d["stats"].at(j * 5), 5, np.float64)
-                    len_j = int(e.read(d["len"].at(j), 1, np.int32)[0])
-                    e.d2d(d["gpath"].at(1), d["cells"].at(j * cap), len_j * 4)
-                    d["gpath"].write(0, [len_j])
-                    self._gbest_dev = {"idx": p_star, "fitness": f_star, "stats": stats_j, "len": len_j}
-                else:
-                    self._gbest_dev = {"idx": p_star, "fitness": f_star, "stats": None, "len": 0}
+                self._gbest_dev = {"idx": p_star, "fitness": f_star, "host": False}
                 if world > 1:
                     c.broadcast(d["gb"], 0, W * 2, r_star)                 # the new gbest position: W x 16 B
                 self._gowner = r_star
                 self._gbest_everywhere = False
                 gfit = f_star
-            if m and upto < top - 1:                                       # roll back my evaluated but not yet final particles
-                r0 = max(upto + 1, a0) - lo
-                e.d2d(d["pos"].at(r0 * W * 2), d["pos0"].at(r0 * W * 2), (top - lo - r0) * st_sz)
-                e.d2d(d["vel"].at(r0 * W * 2), d["vel0"].at(r0 * W * 2), (top - lo - r0) * st_sz)
             cur = upto + 1
         self._particles_stale = True
         self._it += 1
