@@ -817,7 +817,11 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
       // Every step that finds a candidate draws q (:232) and then at least one more 64-bit word (random.choice's first
       // getrandbits at :250 / :254, or numpy's random_sample at :259): both words are mixed here, before the loads below
       // are waited for, and the counter advances only when the step gets that far.
-      const uint64_t w1 = g.peek64(1), w2 = g.peek64(2);
+      // ONE mix serves the whole step: lane j of the ant's group mixes word j + 1 of the stream (the same instructions in every
+      // lane), i.e. the eight next words at once -- q, the first word of the choice, and six more for random.choice's rejection
+      // loop (_randbelow redraws while the k-bit value is >= n: every second draw for n = 1, every fourth for n = 3), which used to
+      // cost the wave a full mix64 (~25 instructions, eight quarter-rate multiplies) per extra draw of its unluckiest ant.
+      const uint64_t Wk = g.peek64(1 + (uint64_t)k);
 #ifdef PF_WALK_PROBE
       __builtin_amdgcn_sched_barrier(0); const unsigned long long pr_ta = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
       pr_head += pr_ta - pr_r0; pr_stepped = true; pr_act += 1;   // (per-lane copies: lane 0 reports, so the in-step stamps cover the rounds in which group 0 stepped)
@@ -849,32 +853,36 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
         const int ncand = __builtin_popcount(cand);
         cand_tot += ncand;
         const bool cmine = (cand >> k) & 1u;
-        g.advance(2);
-        const double q = Rng::to_unit(w1);                          // :232
+        // :232 q = word 1 of the step (lane 0 of the group holds it): one ballot tells the group which rule applies
+        const bool greedy = (gballot8(Rng::to_unit(Wk) <= p.q0) & 1u) != 0;
         const double attr = cmine ? tv * ev : 0.0;                  // :238; the other lanes add an exact zero to the ordered sums below
         int pick = 0;
 #ifdef PF_WALK_PROBE
         __builtin_amdgcn_sched_barrier(0); const unsigned long long pr_s0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
         pr_sel0 += pr_s0 - pr_ta;
 #endif
-        if (q <= p.q0) {
-          // :241-250, the running maximum with its absolute tolerance, in closed form: the tie set restarts at the FIRST
-          // occurrence of the maximum M (`attr > max` drops every earlier member there) and from then on collects the
-          // candidates within 1e-9 of M (none can exceed it).  NaN neither restarts nor joins, as in the loop.
-          const double M = gmax8(cmine ? attr : -1.0);
-          const unsigned eq = gballot8(cmine && attr == M);
-          if (!eq) { rc = 1; done = true; }
-          else {
-            const unsigned bm = gballot8(cmine && k >= __builtin_ctz(eq) && fabs(attr - M) < 1e-9);
-            pick = gnth8(bm, (int)g.randbelow_from(w2, (unsigned long long)__builtin_popcount(bm)), k);   // random.choice
-          }
-        } else {
+        // Both rules end in random.choice over a set of candidates: the greedy rule (:241-250) over its tie set, the other one
+        // (:252-254) over all candidates whenever the attractiveness sum is below 1e-9 -- on the 512^2 and 1024^2 maps with beta = 7
+        // that is EVERY non-greedy step (eta'^7 ~ 1e-19: SURVEY H8 measured 0 % roulette picks).  So the two rules only differ in
+        // the set, and ONE choice serves every ant of the wave; the roulette proper runs behind a wave-uniform test.
+        // The largest attractiveness among the candidates is the greedy rule's maximum AND a bound on the other rule's sum: the
+        // ordered sum of at most 8 non-negative terms, none above Mx, is at most 8 Mx (1 + 2^-53)^7 -- with 8 Mx < 5e-10 it is
+        // below 1e-9 whatever its rounding, and the 7-step ordered scan need not run.
+        const double Mx = gmax8(cmine ? attr : -1.0);
+        // :241-250, the running maximum with its absolute tolerance, in closed form: the tie set restarts at the FIRST occurrence of
+        // the maximum (`attr > max` drops every earlier member there) and from then on collects the candidates within 1e-9 of it
+        // (none can exceed it).  NaN neither restarts nor joins, as in the loop.
+        const unsigned eq = gballot8(cmine && attr == Mx);
+        const unsigned bm = gballot8(cmine && k >= __builtin_ctz(eq | 0x100u) && fabs(attr - Mx) < 1e-9);
+        const bool tiny = Mx * 8.0 < 5e-10;                         // (a NaN maximum compares false: the sum decides)
+        if (greedy && !eq) { rc = 1; done = true; }
+        bool chosen = false;                                        // the roulette proper picked (two words of the stream: q and u)
+        if (__ballot(!greedy && !tiny)) {
           // The sums of :252-259 run over the candidates in candidate order.  Candidate j lives in lane j, so each is one
           // ordered 8-lane scan (7 dependent DPP steps, no LDS round trip per candidate); every quotient belongs to one
-          // candidate and is computed in its lane.
+          // candidate and is computed in its lane.  (The scans run for the whole wave; only the ants that need them use the result.)
           const double sum = glast8(gscan8(attr, k));               // :252
-          if (sum < 1e-9) pick = gnth8(cand, (int)g.randbelow_from(w2, (unsigned long long)ncand), k);   // :253-254
-          else {
+          if (!greedy && !tiny && !(sum < 1e-9)) {                  // else :253-254: random.choice over all candidates, below
             const double p0 = attr / sum;                           // :255 probabilities[j]
             // :256-258 renormalise when |sum(probabilities) - 1| > 1e-6.  For a finite sum of at most 8 non-negative terms
             // that never happens: sum = S(1 + e), |e| <= 7u (u = 2^-53), every quotient is a_j / sum (1 + d_j), |d_j| <= u
@@ -885,14 +893,32 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
               const double ps = glast8(gscan8(p0, k));              // :256 sum(probabilities)
               if (fabs(ps - 1.0) > 1e-6) pj = p0 / ps;              // :257-258
             }
-            const double u = Rng::to_unit(w2);                      // :259 numpy.random.choice: cdf = cumsum(p); cdf /= cdf[-1]
+            const double u = gbcast8_d(Rng::to_unit(Wk), 1);        // :259 numpy.random.choice: cdf = cumsum(p); cdf /= cdf[-1]; word 2 of the step
             const double mine = gscan8(pj, k);                      // cdf[position of my move]
             const double last = glast8(mine);
             const unsigned tm = gballot8(cmine && mine / last <= u);   // searchsorted(cdf, u, side="right")
             int idx = tm ? __builtin_popcount(cand & ((2u << (31 - __builtin_clz(tm))) - 1u)) : 0;
             if (idx > ncand - 1) idx = ncand - 1;
             pick = gnth8(cand, idx, k);
+            chosen = true;
+            g.advance(2);
           }
+        }
+        {
+          // random.choice(set) = set[_randbelow(n)]: kb = n.bit_length() bits of a word, redrawn while >= n (:250 / :254).  Word j + 1
+          // of the step sits in lane j: every lane tests ITS word, the first acceptable one (a ballot) is the draw.
+          const unsigned msel = greedy ? bm : cand;
+          const unsigned nsel = (unsigned)__builtin_popcount(msel) | (msel ? 0u : 1u);   // (>= 1: a failed ant's value is never used)
+          const int kb = 32 - __builtin_clz(nsel);
+          unsigned rk = (unsigned)(Wk >> (64 - kb));
+          const unsigned acc = gballot8(k >= 1 && rk < nsel);
+          const bool more = !chosen && !done && acc == 0u;           // all seven rejected (n = 1: once in 128 steps): draw on, one word at a time
+          unsigned r = (unsigned)gbcast8_i((int)rk, __builtin_ctz(acc | 0x80u));
+          if (!chosen) g.advance(acc ? 1u + (unsigned)__builtin_ctz(acc) : 8u);
+          if (__ballot(more)) {
+            if (more) { do { r = (unsigned)(g.next64() >> (64 - kb)); } while (r >= nsel); }
+          }
+          if (!chosen) pick = gnth8(msel, (int)r, k);
         }
 #ifdef PF_WALK_PROBE
         int t_ = pick; asm volatile("" : "+v"(t_)); __builtin_amdgcn_sched_barrier(0); const unsigned long long pr_s1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
