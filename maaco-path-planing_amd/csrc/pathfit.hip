@@ -761,45 +761,47 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
   const int vrS = tr - sr, vcS = tc - sc;
   const bool o1 = !((vcS > 0 && mdc < 0) || (vcS < 0 && mdc > 0) || (vrS > 0 && mdr < 0) || (vrS < 0 && mdr > 0));
   const unsigned O1 = gballot8(o1);
-  const long long max_steps = (long long)RC * 2;                   // MAACO.py:283
+  const int max_steps = RC * 2;                                    // MAACO.py:283
   unsigned long long steps_tot = 0, cand_tot = 0, cells_tot = 0, ovf_tot = 0;
   // per-ant state (replicated in the 8 lanes of the group)
   int a = -1, cr = 0, cc = 0, n = 0, prev_k = -1, nturn = 0, rc = 0;
-  long long steps = 0;
+  int steps = 0;                                                   // (<= 2 R C <= 2^25)
   double plen = 0.0;
   Rng g; g.key = 0; g.ctr = 0; g.kc = 0;
   int* out = p.cells;
-  bool need = true, alive = grp < p.groups;
+  bool alive = grp < p.groups;
 #ifdef PF_WALK_PROBE
   unsigned long long pr_wait = 0, pr_rounds = 0, pr_mark = 0, pr_sel0 = 0, pr_sel1 = 0, pr_head = 0, pr_emit = 0, pr_upd = 0, pr_loop = 0, pr_end = 0, pr_act = 0; const unsigned long long pr_t0 = __builtin_amdgcn_s_memtime();
 #endif
-  while (__ballot(alive)) {
-    if (alive && need) {                                           // fetch + initialise the next ant of this group
-      int w = 0;
-      if (k == 0) w = atomicAdd(p.work, 1);
-      w = gbcast8_i(w, 0);
-      if (w >= p.n) alive = false;
-      else {
-        a = w;
-        epoch += 1;
-        if (epoch >= PF_TABU_WRAP) {
-          for (int i = k; i < p.vstride; i += 8) visit[i] = 0;
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          epoch = 1;
-        }
-        g.init(p.seed, DOM_MAACO, (unsigned long long)p.iter, (unsigned long long)(p.ant0 + a));
-        out = p.cells + (size_t)a * p.path_cap;
-        cr = sr; cc = sc; n = 1; prev_k = -1; nturn = 0; rc = 0; plen = 0.0; steps = 0;
-        tl.reset();
-        {
-          const int wi = sr * WPR + (sc >> 4); const unsigned wv = tabu_set(0u, epoch, sc);
-          if (k == 0) { out[0] = p.start; visit[wi] = wv; }
-          tl.stored(wi, wv);
-        }
-        need = false;
+  // fetch + initialise the next ant of this group (alive = false when the queue is empty)
+  auto fetch = [&]() {
+    int w = 0;
+    if (k == 0) w = atomicAdd(p.work, 1);
+    w = gbcast8_i(w, 0);
+    if (w >= p.n) alive = false;
+    else {
+      a = w;
+      epoch += 1;
+      if (epoch >= PF_TABU_WRAP) {
+        for (int i = k; i < p.vstride; i += 8) visit[i] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        epoch = 1;
       }
+      g.init(p.seed, DOM_MAACO, (unsigned long long)p.iter, (unsigned long long)(p.ant0 + a));
+      out = p.cells + (size_t)a * p.path_cap;
+      cr = sr; cc = sc; n = 1; prev_k = -1; nturn = 0; rc = 0; plen = 0.0; steps = 0;
+      tl.reset();
+      const int wi = sr * WPR + (sc >> 4); const unsigned wv = tabu_set(0u, epoch, sc);
+      if (k == 0) { out[0] = p.start; visit[wi] = wv; }
+      tl.stored(wi, wv);
     }
-    bool done = alive && ((cr == tr && cc == tc) || steps >= max_steps);
+  };
+  if (alive) fetch();
+  // One wave-uniform test per round: "did an ant finish?" (one round in a hundred).  Emitting, deposit marking, fetching the group's
+  // next ant and the end-of-queue test all sit behind it; a round that only steps pays for nothing else.  (A wave none of whose
+  // groups got an ant -- the queue was drained by the others' first fetches -- never enters the loop: every exit is behind any_fin.)
+  if (__ballot(alive)) for (;;) {
+    bool done = alive & (((cr == tr) & (cc == tc)) | (steps >= max_steps));
 #ifdef PF_WALK_PROBE
     __builtin_amdgcn_sched_barrier(0); const unsigned long long pr_r0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
     bool pr_stepped = false; unsigned long long pr_u0 = 0;
@@ -808,9 +810,9 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
     if (alive && !done) {
       const int cur = cr * C + cc;
       const int nr = cr + mdr, nc = cc + mdc;
-      const bool inb = nr >= 0 && nr < R && nc >= 0 && nc < C;
+      const bool inb = ((unsigned)nr < (unsigned)R) & ((unsigned)nc < (unsigned)C);
       const int nidx = nr * C + nc;
-      const int turn = (prev_k >= 0 && k != prev_k) ? 1 : 0;       // MAACO.py:184-195
+      const int turn = ((prev_k >= 0) & (k != prev_k)) ? 1 : 0;    // MAACO.py:184-195
       unsigned vw = 0; double tv = 0.0, ev = 0.0;
       const unsigned M = G.mm[cur];
       const int widx = nr * WPR + (nc >> 4);
@@ -840,10 +842,11 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
         pr_wait += __builtin_amdgcn_s_memtime() - pr_ta; }
 #endif
-      const bool ok = inb && (M & hbit) && !tabu_test(vw, epoch, nc);
+      // (bitwise on purpose: the short-circuit forms compiled to branches, each a scalar round trip on a freshly written lane mask)
+      const bool ok = inb & ((M & hbit) != 0u) & !(((vw >> 16) == epoch) & (((vw >> (nc & 15)) & 1u) != 0u));
       const unsigned mall = gballot8(ok);
       const int vr = tr - cr, vc = tc - cc;
-      const bool o2 = !((vc > 0 && mdc < 0) || (vc < 0 && mdc > 0) || (vr > 0 && mdr < 0) || (vr < 0 && mdr > 0));
+      const bool o2 = !(((vc > 0) & (mdc < 0)) | ((vc < 0) & (mdc > 0)) | ((vr > 0) & (mdr < 0)) | ((vr < 0) & (mdr > 0)));
       const unsigned O2 = gballot8(o2);
       unsigned cand = mall & O1;                                    // :165
       if (!cand) cand = mall & O2;                                  // :168-169
@@ -959,7 +962,6 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
         p.status[a] = rc;
       }
       cells_tot += rc == 0 ? n : 0; ovf_tot += rc == 3;
-      need = true;
     }
 #ifdef PF_WALK_PROBE
     pr_rounds += 1; const unsigned long long pr_m0 = __builtin_amdgcn_s_memtime(); pr_emit += pr_m0 - pr_e0;
@@ -991,6 +993,10 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
           }
         }
       }
+    }
+    if (any_fin) {
+      if (alive && done) fetch();                                   // the group's next ant starts in the next round
+      if (!__ballot(alive)) break;
     }
 #ifdef PF_WALK_PROBE
     pr_end = __builtin_amdgcn_s_memtime(); pr_mark += pr_end - pr_m0;
