@@ -732,7 +732,7 @@ __global__ __launch_bounds__(64) void k_maaco_walk(MaacoArgs p) {
 // its ant emits the result and immediately fetches the next ant from the queue inside the same loop, so no
 // lanes idle until the queue is empty.  Same draws, same arithmetic, same order as k_maaco_walk.
 // ---------------------------------------------------------------------------
-PF_DEV unsigned gballot8(bool p) { return (unsigned)(__ballot(p) >> (lane_id() & 56)) & 0xFFu; }
+PF_DEV unsigned gballot8(bool p) { return (unsigned)(__builtin_amdgcn_ballot_w64(p) >> (lane_id() & 56)) & 0xFFu; }
 PF_DEV int gbcast8_i(int v, int k) { return __builtin_amdgcn_ds_bpermute(((lane_id() & 56) + k) << 2, v); }
 // index of the idx-th set bit of an 8-bit mask (lane k tests bit k)
 PF_DEV int gnth8(unsigned m, int idx, int k) {
@@ -762,6 +762,8 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
   const bool o1 = !((vcS > 0 && mdc < 0) || (vcS < 0 && mdc > 0) || (vrS > 0 && mdr < 0) || (vrS < 0 && mdr > 0));
   const unsigned O1 = gballot8(o1);
   const int max_steps = RC * 2;                                    // MAACO.py:283
+  // q0 is in [0.01, 0.99] (MAACO.py:226): q0 2^53 is exact, its floor the largest 53-bit draw that still takes the greedy rule
+  const uint64_t q0_bits = p.q0 >= 1.0 ? ~0ull : (p.q0 < 0.0 ? 0ull : (uint64_t)(p.q0 * 9007199254740992.0));
   unsigned long long steps_tot = 0, cand_tot = 0, cells_tot = 0, ovf_tot = 0;
   // per-ant state (replicated in the 8 lanes of the group)
   int a = -1, cr = 0, cc = 0, n = 0, prev_k = -1, nturn = 0, rc = 0;
@@ -808,14 +810,16 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
     if (pr_end) pr_loop += pr_r0 - pr_end;
 #endif
     if (alive && !done) {
-      const int cur = cr * C + cc;
+      // (rows, columns and cells fit 24 bits -- R, C <= 4096 --: v_mad_u32_u24 at full rate and 32-bit byte offsets on a scalar
+      // base, where `int` indices cost a quarter-rate 64-bit multiply-add, a sign extension and a 64-bit add per load)
+      const unsigned cur = __umul24((unsigned)cr, (unsigned)C) + (unsigned)cc;
       const int nr = cr + mdr, nc = cc + mdc;
       const bool inb = ((unsigned)nr < (unsigned)R) & ((unsigned)nc < (unsigned)C);
-      const int nidx = nr * C + nc;
+      const unsigned nidx = __umul24((unsigned)nr, (unsigned)C) + (unsigned)nc;
       const int turn = ((prev_k >= 0) & (k != prev_k)) ? 1 : 0;    // MAACO.py:184-195
       unsigned vw = 0; double tv = 0.0, ev = 0.0;
-      const unsigned M = G.mm[cur];
-      const int widx = nr * WPR + (nc >> 4);
+      const unsigned M = *((const uint8_t*)G.mm + (size_t)cur);
+      const unsigned widx = __umul24((unsigned)nr, (unsigned)WPR) + ((unsigned)nc >> 4);
       // Every step that finds a candidate draws q (:232) and then at least one more 64-bit word (random.choice's first
       // getrandbits at :250 / :254, or numpy's random_sample at :259): both words are mixed here, before the loads below
       // are waited for, and the counter advances only when the step gets that far.
@@ -831,10 +835,11 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
       {
         // unconditional loads (a move that leaves the map reads cell 0 and is rejected by `inb` below): a branch around them costs
         // a scalar round trip on the mask, and loads under a branch keep the compiler from counting them
-        const int widx_c = inb ? widx : 0, nidx_c = inb ? nidx : 0;
-        vw = tl.patch(widx_c, visit[widx_c]);
+        const unsigned widx_c = inb ? widx : 0u, nidx_c = inb ? nidx : 0u;
+        vw = tl.patch((int)widx_c, visit[widx_c]);
         // one divergent vector load less per step: tau and eta'[turn] in one
-        const pf_d2u te = *(const pf_d2u*)(p.tep + (size_t)nidx_c * 3 + turn);
+        const unsigned toff = __umul24(nidx_c, 24u) + ((unsigned)turn << 3);
+        const pf_d2u te = *(const pf_d2u*)((const char*)p.tep + (size_t)toff);
         tv = turn ? te.x : te.y; ev = turn ? te.y : te.x;
       }
 #ifdef PF_WALK_PROBE
@@ -857,7 +862,8 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
         cand_tot += ncand;
         const bool cmine = (cand >> k) & 1u;
         // :232 q = word 1 of the step (lane 0 of the group holds it): one ballot tells the group which rule applies
-        const bool greedy = (gballot8(Rng::to_unit(Wk) <= p.q0) & 1u) != 0;
+        // (q = (w >> 11) 2^-53 exactly, so q <= q0 iff w >> 11 <= floor(q0 2^53): two integer instructions instead of the conversion)
+        const bool greedy = (gballot8((Wk >> 11) <= q0_bits) & 1u) != 0;
         const double attr = cmine ? tv * ev : 0.0;                  // :238; the other lanes add an exact zero to the ordered sums below
         int pick = 0;
 #ifdef PF_WALK_PROBE
@@ -875,8 +881,8 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
         // :241-250, the running maximum with its absolute tolerance, in closed form: the tie set restarts at the FIRST occurrence of
         // the maximum (`attr > max` drops every earlier member there) and from then on collects the candidates within 1e-9 of it
         // (none can exceed it).  NaN neither restarts nor joins, as in the loop.
-        const unsigned eq = gballot8(cmine && attr == Mx);
-        const unsigned bm = gballot8(cmine && k >= __builtin_ctz(eq | 0x100u) && fabs(attr - Mx) < 1e-9);
+        const unsigned eq = gballot8(cmine & (attr == Mx));
+        const unsigned bm = gballot8(cmine & (k >= __builtin_ctz(eq | 0x100u)) & (fabs(attr - Mx) < 1e-9));
         const bool tiny = Mx * 8.0 < 5e-10;                         // (a NaN maximum compares false: the sum decides)
         if (greedy && !eq) { rc = 1; done = true; }
         bool chosen = false;                                        // the roulette proper picked (two words of the stream: q and u)
