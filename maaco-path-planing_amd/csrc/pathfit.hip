@@ -611,6 +611,7 @@ __global__ __launch_bounds__(64) void k_maaco_walk(MaacoArgs p) {
   const bool o1 = !((vcS > 0 && mdc < 0) || (vcS < 0 && mdc > 0) || (vrS > 0 && mdr < 0) || (vrS < 0 && mdr > 0));
   const unsigned O1 = (unsigned)(__ballot(o1 && lane < 8) & 0xFF);
   const double mcost = (mdr != 0 && mdc != 0) ? PF_SQRT2 : 1.0;
+  const uint64_t q0_bits = p.q0 >= 1.0 ? ~0ull : (p.q0 < 0.0 ? 0ull : (uint64_t)(p.q0 * 9007199254740992.0));   // q <= q0 as an integer test (k_maaco_walk8)
   unsigned long long steps_tot = 0, cand_tot = 0, cells_tot = 0, ovf_tot = 0;
   for (;;) {
     const int a = next_work(p.work, lane);
@@ -631,8 +632,8 @@ __global__ __launch_bounds__(64) void k_maaco_walk(MaacoArgs p) {
       if (lane == 0) { out[0] = p.start; visit[wi] = wv; }
       tl.stored(wi, wv);
     }
-    const long long max_steps = (long long)RC * 2;                 // MAACO.py:283
-    long long steps = 0;
+    const int max_steps = RC * 2;                                  // MAACO.py:283 (<= 2^25)
+    int steps = 0;
     while (!(cr == tr && cc == tc) && steps < max_steps) {
       const int cur = cr * C + cc;
       const int nr = cr + mdr, nc = cc + mdc;
@@ -657,33 +658,49 @@ __global__ __launch_bounds__(64) void k_maaco_walk(MaacoArgs p) {
       const int ncand = __builtin_popcount(cand);
       cand_tot += ncand;
       const bool cmine = lane < 8 && ((cand >> k) & 1u);
-      const double q = g.random();                                // :232 (drawn even for one candidate)
+      // ONE mix serves the step (see k_maaco_walk8): lane j mixes word j + 1 of the ant's stream -- q, the first word of the choice
+      // and six more for random.choice's rejection loop, which used to cost a full mix64 per extra draw.
+      const uint64_t Wk = g.peek64(1 + (uint64_t)k);
+      const bool greedy = (__builtin_amdgcn_ballot_w64((Wk >> 11) <= q0_bits) & 1ull) != 0;   // :232 q = word 1 (lane 0); q <= q0 as integers
       const double attr = cmine ? tv * ev : 0.0;                  // :238 tau^alpha * eta'^beta; the other lanes add exact zeros
-      int pick;
-      if (q <= p.q0) {                                            // :241-250 running max with absolute tolerance, closed form (k_maaco_walk8)
-        const double M = gmax8(cmine ? attr : -1.0);
-        const unsigned eq = (unsigned)__ballot(cmine && attr == M) & 0xFFu;
+      const double Mx = gmax8(cmine ? attr : -1.0);               // (lanes 0..7 are one 8-lane group)
+      int pick = 0;
+      unsigned msel = cand;                                       // the set random.choice draws from
+      bool chosen = false;
+      if (greedy) {                                               // :241-250 running max with absolute tolerance, closed form (k_maaco_walk8)
+        const unsigned eq = (unsigned)__ballot(cmine && attr == Mx) & 0xFFu;
         if (!eq) { rc = 1; break; }
-        const unsigned bm = (unsigned)__ballot(cmine && k >= __builtin_ctz(eq) && fabs(attr - M) < 1e-9) & 0xFFu;
-        pick = nth_set_bit(bm, (int)g.randbelow((unsigned long long)__builtin_popcount(bm)));   // random.choice
-      } else {
+        msel = (unsigned)__ballot(cmine && k >= __builtin_ctz(eq) && fabs(attr - Mx) < 1e-9) & 0xFFu;
+      } else if (!(bcast_d(Mx, 0) * 8.0 < 5e-10)) {               // (else the ordered sum is below 1e-9 whatever its rounding: k_maaco_walk8)
         const double sum = bcast_d(gscan8(attr, k), 7);           // :252 sum() in candidate order (ordered 8-lane scan)
-        if (sum < 1e-9) pick = nth_set_bit(cand, (int)g.randbelow((unsigned long long)ncand));   // :253-254
-        else {
+        if (!(sum < 1e-9)) {                                      // else :253-254: random.choice over all candidates
           const double p0 = attr / sum;                           // :255
           double pj = p0;
           if (!(sum < 1.0e300)) {                                 // :256-258 cannot renormalise for a finite sum (see k_maaco_walk8)
             const double ps = bcast_d(gscan8(p0, k), 7);
             if (fabs(ps - 1.0) > 1e-6) pj = p0 / ps;
           }
-          const double u = g.random();                            // :259 np.random.choice -> one random_sample
+          const double u = Rng::to_unit(((uint64_t)(unsigned)bcast_i((int)(Wk >> 32), 1) << 32) | (unsigned)bcast_i((int)Wk, 1));   // :259 np.random.choice -> one random_sample: word 2
           const double mine = gscan8(pj, k);                      // cdf = cumsum(p); cdf /= cdf[-1]
           const double last = bcast_d(mine, 7);
           const unsigned tm = (unsigned)__ballot(cmine && mine / last <= u) & 0xFFu;   // searchsorted(cdf, u, side='right')
           int idx = tm ? __builtin_popcount(cand & ((2u << (31 - __builtin_clz(tm))) - 1u)) : 0;
           if (idx > ncand - 1) idx = ncand - 1;
           pick = nth_set_bit(cand, idx);
+          chosen = true;
+          g.advance(2);
         }
+      }
+      if (!chosen) {
+        // random.choice(set) = set[_randbelow(n)]: the first of words 2..8 whose top bit_length(n) bits are below n (a ballot)
+        const unsigned nsel = (unsigned)__builtin_popcount(msel);
+        const int kb = 32 - __builtin_clz(nsel);
+        const unsigned rk = (unsigned)(Wk >> (64 - kb));
+        const unsigned acc = (unsigned)__ballot(lane >= 1 && lane < 8 && rk < nsel) & 0xFFu;
+        unsigned r;
+        if (acc) { const int first = __builtin_ctz(acc); r = (unsigned)bcast_i((int)rk, first); g.advance(1u + (unsigned)first); }
+        else { g.advance(8); do { r = (unsigned)(g.next64() >> (64 - kb)); } while (r >= nsel); }
+        pick = nth_set_bit(msel, (int)r);
       }
       plen += bcast_d(mcost, pick);                               // :293
       if (prev_k >= 0 && pick != prev_k) nturn += 1;              // :264-276 counted on the fly
