@@ -236,10 +236,10 @@ def measure(run, eng, comm, sync_all, world, torch, dist, local_rank, backend):
 
 
 def traffic_note(roof, workload):
-    """HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/r03_traffic.json: FETCH_SIZE and
+    """HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/r04_traffic.json, written by scripts/profile_round.sh: FETCH_SIZE and
     WRITE_SIZE in separate --pmc runs, KB -> B, FETCH x2 per MI355X_MICROARCH.md).  The file records the kernel time it
     was captured at; a figure whose kernel has since changed speed by more than 15 % is reported as stale, not used."""
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_traffic.json")))
         except Exception:

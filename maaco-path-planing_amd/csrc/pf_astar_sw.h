@@ -723,15 +723,10 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     // v_readlane each, >100 instructions per trip.
     int grp = grp0, sub = sub0, lane_t = lane;
     asm volatile("" : "+v"(grp), "+v"(sub), "+v"(lane_t));
-    // the head cells feed the load addresses: v_readlane + select has none of the LDS crossbar's latency
-    int hcell[NH];                                              // (r << 16 | c) of head h, wave-uniform
-    hcell[0] = bcast_i(W.wc, W.wp);
-    int prc = hcell[0];
-#pragma unroll
-    for (int h = 1; h < NH; ++h) {
-      hcell[h] = bcast_i(W.wc, W.wp + h < 64 ? W.wp + h : 63);
-      prc = grp == h ? hcell[h] : prc;
-    }
+    // my group's head cell: ONE crossbar permute from the window lane that holds it (seven v_readlane + six selects -- ~40 wave
+    // instructions with their scalar index arithmetic -- bought the load addresses ~70 clocks of LDS latency at 4x the issue slots)
+    const int hsrc = W.wp + grp < 64 ? W.wp + grp : 63;            // my group's head lives in this window lane
+    const int prc = bperm_i(hsrc, W.wc);                        // (r << 16 | c)
     const bool have = grp < nh;                                 // (lane 63 is group 7: never)
     const int pr = prc >> 16, pc = prc & 0xFFFF;
     const int cur = pr * C + pc;
@@ -750,7 +745,6 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     { SW_T(ti_) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SW_T(tj_) sw_cnt[0] += tj_ - ti_; }   // diagnostic: the bare load latency
 #endif
     // -- everything below is in the shadow of the loads --
-    const int hsrc = W.wp + grp < 64 ? W.wp + grp : 63;            // my group's head lives in this window lane
     const double pg = bperm_d(hsrc, W.wg);
     unsigned long long hfb[NH];                                 // f of heads 1.. (uniform) for the push test below
     hfb[0] = 0;

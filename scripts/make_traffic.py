@@ -10,7 +10,7 @@ tallied at 64 B) -- calibrated there for wide streaming reads only, so for 8/16-
 import sys, os, glob, csv, json
 d = sys.argv[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = os.environ.get("PF_ROUND", "r03")
+RND = os.environ.get("PF_ROUND", "r04")
 KERN = {"mpa512": "k_mpa_search", "maaco512": "k_maaco_walk8", "maaco1024": "k_maaco_walk8", "maaco128": "k_maaco_walk(",
         "ga512": "k_decode_batch", "pso512": "k_decode_batch", "astar1024": "k_astar_batch"}
 try:

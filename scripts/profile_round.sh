@@ -1,9 +1,10 @@
 #!/bin/bash
 # One round of profiling runs on the GPU box (run through gpurun from the repo root):
-#   bash scripts/profile_round.sh gpurun_out/prof_r03 [workloads...]
+#   bash scripts/profile_round.sh gpurun_out/prof_r04 [workloads...]
 # per workload: rocprofv3 --kernel-trace --stats, --pmc FETCH_SIZE, --pmc WRITE_SIZE (separate passes, as
 # MI355X_MICROARCH.md prescribes: the two do not fit one pass) and the unprofiled bench line; scripts/make_traffic.py turns
-# them into profiles/r03_traffic.json + profiles/r03_<workload>_kernel_stats.csv.  The program goes straight after `--`
+# them into profiles/<round>_traffic.json + profiles/<round>_<workload>_kernel_stats.csv (PF_ROUND, default r04) as the LAST STEP OF THIS SCRIPT, so the
+# traffic figure bench.py quotes is always captured with the kernels it describes.  The program goes straight after `--`
 # (python3 itself: no env / bash -c hop, the profiler's preload has already initialised the GPU).
 set -o pipefail
 OUT=$(realpath "$1"); shift; mkdir -p "$OUT"
@@ -13,7 +14,7 @@ export TMPDIR=/tmp
 cd /tmp
 for W in $WL; do
   # mpa512 runs the driver's protocol: the traffic figure is keyed to this kernel time
-  case $W in mpa512) ST="--steps 20 --warmup 5";; ga512|astar1024|pso512) ST="--steps 2 --warmup 1";; *) ST="--steps 6 --warmup 2";; esac
+  case $W in mpa512) ST="--steps 20 --warmup 5";; ga512|astar1024|pso512) ST="--steps 2 --warmup 1";; maaco128) ST="--steps 100 --warmup 5";; *) ST="--steps 10 --warmup 2";; esac
   timeout -k 10 200 python3 "$ROOT/bench.py" --workload $W --no-cpu --no-extra $ST > "$OUT/${W}_bench.json" 2> "$OUT/${W}_bench.err" || { echo "$W bench failed"; exit 1; }
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${W}_stats" -- python3 "$ROOT/bench.py" --workload $W --no-cpu --no-extra $ST > "$OUT/${W}_stats.log" 2>&1 || { echo "$W stats failed"; exit 1; }
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/${W}_fetch" -- python3 "$ROOT/bench.py" --workload $W --no-cpu --no-extra $ST > "$OUT/${W}_fetch.log" 2>&1 || { echo "$W fetch failed"; exit 1; }
@@ -38,5 +39,5 @@ done
 find "$OUT" -type f \( -name '*.db' -o -name '*kernel_trace.csv' -o -name '*agent_info.csv' \) -delete
 cd "$ROOT"
 python3 scripts/make_traffic.py "$OUT" > "$OUT/traffic_summary.log" 2>&1 || true
-cp profiles/${PF_ROUND:-r03}_traffic.json profiles/${PF_ROUND:-r03}_*_kernel_stats.csv "$OUT/" 2>/dev/null || true
+cp profiles/${PF_ROUND:-r04}_traffic.json profiles/${PF_ROUND:-r04}_*_kernel_stats.csv "$OUT/" 2>/dev/null || true
 tail -60 "$OUT/traffic_summary.log"
