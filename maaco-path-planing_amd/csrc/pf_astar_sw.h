@@ -746,10 +746,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
 #endif
     // -- everything below is in the shadow of the loads --
     const double pg = bperm_d(hsrc, W.wg);
-    unsigned long long hfb[NH];                                 // f of heads 1.. (uniform) for the push test below
-    hfb[0] = 0;
-#pragma unroll
-    for (int h = 1; h < NH; ++h) hfb[h] = dbits(bcast_d(W.wf, W.wp + (h < nh ? h : nh - 1)));   // (past the last head: its f again, so the list stays sorted)
+    const unsigned long long f_last = dbits(bcast_d(W.wf, W.wp + nh - 1));   // f of the trip's last head (uniform) for the push test below
     // lanes 0..48 look at the head pair (e, h) = (lane / 7, lane % 7): too close to be independent?
     const int pe = (lane_t * 37) >> 8, ph = lane_t - 7 * pe;
     const int rce = bperm_i(W.wp + pe < 64 ? W.wp + pe : 63, W.wc), rch = bperm_i(W.wp + ph < 64 ? W.wp + ph : 63, W.wc);
@@ -847,15 +844,20 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     // bit h: an earlier group pushes a key at or below head h's f.  The heads' f are sorted, so a push violates the heads
     // from some h on: the first one is 1 + max(#heads with f below the key, own group), and the mask starts at the
     // smallest of those over the pushing lanes.
-    unsigned viol;
+    unsigned viol = 0;
     {
       const unsigned long long fb = dbits(fnew);                // non-negative doubles order like their bit patterns
-      int c_ = 0;
+      // A push can only violate a head that exists, lies behind its own group and has f >= the key -- so at the very least the
+      // LAST head: no push at or below f_last from a group before the last one means no violation at all, and the six compares
+      // (with the twelve v_readlane that fetch the heads' f) run only in the trips that may lose a head (one in ten).
+      if (__ballot(push0 && grp < nh - 1 && fb <= f_last)) {
+        int c_ = 0;
 #pragma unroll
-      for (int h = 1; h < NH; ++h) c_ += hfb[h] < fb ? 1 : 0;
-      const int hv = (c_ > grp ? c_ : grp) + 1;
-      const unsigned hmin = wave_min_u32(push0 ? (unsigned)hv : (unsigned)NH);
-      viol = (0x7Fu << hmin) & 0x7Fu;
+        for (int h = 1; h < NH; ++h) c_ += dbits(bcast_d(W.wf, W.wp + (h < nh ? h : nh - 1))) < fb ? 1 : 0;   // (past the last head: its f again, so the list stays sorted)
+        const int hv = (c_ > grp ? c_ : grp) + 1;
+        const unsigned hmin = wave_min_u32(push0 ? (unsigned)hv : (unsigned)NH);
+        viol = (0x7Fu << hmin) & 0x7Fu;
+      }
     }
     // Branch-free form of the sequential rule.  A superseded head (closed-set variants) is transparent: consumed, no
     // effect, not a pop.  A real head fails if an earlier group pushed at or below its f or it is near an earlier
