@@ -528,8 +528,8 @@ def main():
         extra = {}
         run = None
         eng.close()
-        for name, k_, w_ in (("maaco128", 20, 3), ("maaco512", 10, 2), ("maaco1024", 6, 1), ("ga512", 3, 1), ("pso512", 2, 1),
-                             ("astar1024", 2, 1)):
+        for name, k_, w_ in (("maaco128", 40, 3), ("maaco512", 20, 2), ("maaco1024", 20, 2), ("ga512", 3, 1), ("pso512", 2, 1),
+                             ("astar1024", 2, 1)):       # (the MAACO legs are milliseconds per step: enough steps that one slow step does not show)
             try:
                 r2, e2, _, v2, dt2, roof2 = run_one(name, k_, w_)
                 extra[name] = {"value": round(v2, 2), "unit": "evals/s", "steps": k_, "warmup": w_, "ms_per_step": round(dt2 / k_ * 1e3, 3),
