@@ -369,6 +369,8 @@ def main():
     ap.add_argument("--pso-sync", action="store_true", help="pso512: one batch per sweep (sweep-start gbest) instead of the exact asynchronous mode")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + PF_BENCH_SHARE_GPU=1 rehearses N ranks on one GPU (exchange logic only)")
+    ap.add_argument("--no-copy-probe", action="store_true", help="skip the 1 GiB device-to-device copies behind roofline.copy_GBs_measured "
+                    "(profile runs: they show up as eleven copyBuffer kernels of ~0.4 ms that are not the workload's)")
     ap.add_argument("--cpu-worker", default="", help=argparse.SUPPRESS)   # internal: "workload:lo:hi" slice for the all-cores CPU leg
     a = ap.parse_args()
     if a.cpu_worker:                                                       # a child of cpu_baseline(): no GPU, no torch
@@ -459,7 +461,7 @@ def main():
     run, eng, grid, value, dt, roof = run_one(a.workload, K, W)
     head_cfg = run.cfg
 
-    if roof is not None and rank == 0:
+    if roof is not None and rank == 0 and not a.no_copy_probe:
         # the nominal 8 TB/s next to what a plain device-to-device copy reaches on this GPU, same run
         try:
             nb = 1 << 30

@@ -15,10 +15,10 @@ cd /tmp
 for W in $WL; do
   # mpa512 runs the driver's protocol: the traffic figure is keyed to this kernel time
   case $W in mpa512) ST="--steps 20 --warmup 5";; ga512|astar1024|pso512) ST="--steps 2 --warmup 1";; maaco128) ST="--steps 100 --warmup 5";; *) ST="--steps 10 --warmup 2";; esac
-  timeout -k 10 200 python3 "$ROOT/bench.py" --workload $W --no-cpu --no-extra $ST > "$OUT/${W}_bench.json" 2> "$OUT/${W}_bench.err" || { echo "$W bench failed"; exit 1; }
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${W}_stats" -- python3 "$ROOT/bench.py" --workload $W --no-cpu --no-extra $ST > "$OUT/${W}_stats.log" 2>&1 || { echo "$W stats failed"; exit 1; }
-  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/${W}_fetch" -- python3 "$ROOT/bench.py" --workload $W --no-cpu --no-extra $ST > "$OUT/${W}_fetch.log" 2>&1 || { echo "$W fetch failed"; exit 1; }
-  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/${W}_write" -- python3 "$ROOT/bench.py" --workload $W --no-cpu --no-extra $ST > "$OUT/${W}_write.log" 2>&1 || { echo "$W write failed"; exit 1; }
+  timeout -k 10 200 python3 "$ROOT/bench.py" --workload $W --no-cpu --no-extra --no-copy-probe $ST > "$OUT/${W}_bench.json" 2> "$OUT/${W}_bench.err" || { echo "$W bench failed"; exit 1; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${W}_stats" -- python3 "$ROOT/bench.py" --workload $W --no-cpu --no-extra --no-copy-probe $ST > "$OUT/${W}_stats.log" 2>&1 || { echo "$W stats failed"; exit 1; }
+  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/${W}_fetch" -- python3 "$ROOT/bench.py" --workload $W --no-cpu --no-extra --no-copy-probe $ST > "$OUT/${W}_fetch.log" 2>&1 || { echo "$W fetch failed"; exit 1; }
+  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/${W}_write" -- python3 "$ROOT/bench.py" --workload $W --no-cpu --no-extra --no-copy-probe $ST > "$OUT/${W}_write.log" 2>&1 || { echo "$W write failed"; exit 1; }
   echo "$W done"
 done
 # keep the merge-back small: the per-dispatch trace is reduced to the workload's dominant kernel (make_traffic.py averages the

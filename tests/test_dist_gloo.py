@@ -23,10 +23,13 @@ def _worker(rank, world, port, out_dir, strict, ants=21, chunks=8, cap_factor=No
     from pathfit.dist import Comm, ShardedMAACO
     g, s, t = gio.grid("fig7")
     comm = Comm(dist, None)           # transport: gloo (host staged) -- the exchange logic is transport independent
+    comm.timed = True                 # bench.py's exchange accounting: every collective is timed (host clock for this transport)
     sm = ShardedMAACO(comm, lambda: FakeMAACO(g, s, t, ants, 5, 7, **KW), ants, strict=strict, chunks=chunks)
     if cap_factor:                    # this rank's walk "overflowed and grew its path rows" (MAACO.walk_iteration_dev): path_cap differs per rank
         sm.local.path_cap *= cap_factor[rank]
     path, length, turns = sm.solve_path_planning()
+    ms = comm.exchange_ms(reset=True)
+    assert ms > 0.0 and comm.calls > 0 and comm.bytes_moved > 0 and comm.exchange_ms() == 0.0, (ms, comm.calls)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), path=np.array(path), length=length, turns=turns,
              tau=sm.local.engine.maaco_get_pheromone(), curve=np.array(sm.local.convergence_curve_data, float))
     dist.barrier()
