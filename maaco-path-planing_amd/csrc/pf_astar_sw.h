@@ -734,13 +734,11 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     int nidx = cur + doff;
     nidx = nidx < 0 ? 0 : (nidx >= RC ? RC - 1 : nidx);        // the move mask rejects what the clamp invents
     Rec rn; rn.g = 0.0; rn.tagmm = 0; rn.meta = 0;
-    unsigned M = 0;
     double cur_g = 0.0;
-#ifdef PF_CURG_LOAD
-    if (have) { rn = rec[nidx]; M = G.mm[cur]; if (SEM == 1) cur_g = rec[cur].g; }
-#else
-    if (have) { rn = rec[nidx]; M = G.mm[cur]; }               // (MPA variant: g_score[current] comes from the self lane's record)
-#endif
+    // ONE vector-memory instruction per trip: the head's move mask is the low byte of its own record (every record carries its
+    // cell's static mask: k_slot_init, and every store keeps it), which the self lane loads anyway -- the separate byte load from
+    // the mask table was a second fully divergent access (address processing for 63 lanes, seven more sectors) for nothing.
+    if (have) rn = rec[nidx];                                   // (MPA variant: g_score[current] comes from the self lane's record too)
 #if defined(PF_STAMPS) && defined(PF_WAIT_EARLY)
     { SW_T(ti_) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SW_T(tj_) sw_cnt[0] += tj_ - ti_; }   // diagnostic: the bare load latency
 #endif
@@ -787,9 +785,8 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     const bool self_stale = SEM == 0 && sub == 8 && ((cur_meta & PF_M_CLOSED) || rn.g != pg);
     const unsigned long long stm = __ballot(have && self_stale);
     const bool my_stale = (stm >> grp) & 1ull;
-#ifndef PF_CURG_LOAD
-    if (SEM == 1) cur_g = bperm_d(grp, rn.g);               // my head's self lane is lane `grp`
-#endif
+    const unsigned M = (unsigned)bperm_i(grp, (int)rn.tagmm) & 0xFFu;   // my head's self lane is lane `grp`: its record's mask byte
+    if (SEM == 1) cur_g = bperm_d(grp, rn.g);
     const double base_g = SEM == 0 ? pg : cur_g;           // astar.py:85 popped g / MPA.py:135 g_score[current]
     const bool rvalid = (rn.tagmm >> PF_TAG_SHIFT) == tag;
     const bool avoided = (rn.meta >> PF_AVOID_SHIFT) == avm;
