@@ -245,7 +245,7 @@ PF_DEV void ent_get(const SwPool& P, const PoolEnt* e, double& f, double& g, int
   const PoolEnt v = *e;
   g = v.g; c = v.c;
   const int dr = (v.c >> 16) - P.tr, dc = (v.c & 0xFFFF) - P.tc;
-  f = P.hzero ? v.g : v.g + __builtin_sqrt((double)(dr * dr + dc * dc));
+  f = P.hzero ? v.g : v.g + __builtin_sqrt((double)(__mul24(dr, dr) + __mul24(dc, dc)));   // (|dr|, |dc| < 4096)
 }
 // append one entry (uniform values): to the front bucket when it sorts before every regular bucket (f below the
 // boundary of bucket bcur), else to its f bucket, else (bucket full / out of range) to the spill list;
@@ -750,7 +750,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     const int rce = bperm_i(W.wp + pe < 64 ? W.wp + pe : 63, W.wc), rch = bperm_i(W.wp + ph < 64 ? W.wp + ph : 63, W.wc);
     const int nr = pr + ddr, nc = pc + ddc;
     const int hdr = nr - tr, hdc = nc - tc;                    // |.| < 2^15: the squares fit 32 bits
-    double hn = VARIANT == 2 ? 0.0 : __builtin_sqrt((double)(hdr * hdr + hdc * hdc));   // astar.py:90 / MPA.py:140 / dijkstra.py:89
+    double hn = VARIANT == 2 ? 0.0 : __builtin_sqrt((double)(__mul24(hdr, hdr) + __mul24(hdc, hdc)));   // astar.py:90 / MPA.py:140 / dijkstra.py:89 (24-bit multiplies run at full rate)
     asm volatile("" : "+v"(hn));                               // computed in the shadow of the loads
     // Heads within 2 cells of each other touch common records.  Instead of stopping the trip there, every lane
     // replays, in head order, what the earlier heads of this trip do to ITS cell: for an earlier head e the lane that
