@@ -506,11 +506,17 @@ def main():
 
         def watchdog():
             if not done.wait(budget):
-                if out is not None:
-                    extra.setdefault("_error", f"the multi-GPU extras did not finish within {budget:.0f} s: line printed by the watchdog")
-                    print(json.dumps(out), flush=True)
-                sys.stderr.flush()
-                os._exit(0)
+                try:
+                    if out is not None:
+                        note = f"the multi-GPU extras did not finish within {budget:.0f} s: line printed by the watchdog"
+                        try:                       # (the main thread may be filling `extra` this very moment)
+                            line = json.dumps(dict(out, extra=dict(dict(extra), _error=note)))
+                        except Exception:
+                            line = json.dumps(dict({k: v for k, v in out.items() if k != "extra"}, extra={"_error": note}))
+                        print(line, flush=True)
+                    sys.stderr.flush()
+                finally:
+                    os._exit(0)
         threading.Thread(target=watchdog, daemon=True).start()
         run = None
         eng.close()
