@@ -765,11 +765,15 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     const unsigned char* geo = (const unsigned char*)O.lf + PF_GEO_OFF;
     int fsrc[NH - 1];
     {
-      int pc_[NH - 1];                                          // the six permutes go out together, then the six table reads:
-#pragma unroll                                                  // two LDS round trips in all instead of two per row
-      for (int e = 0; e < NH - 1; ++e) pc_[e] = bperm_i(7 * e + grp, pcode);   // (groups <= e read a pair lane with pe >= ph: "far")
 #pragma unroll
-      for (int e = 0; e < NH - 1; ++e) fsrc[e] = geo[e * (26 * 16) + pc_[e] * 16 + sub];   // (skipping rows without a near pair measured slower)
+      for (int e = 0; e < NH - 1; ++e) fsrc[e] = 63 * 4;        // no counterpart anywhere ...
+      if (nearg) {                                              // ... unless SOME pair of heads is near (one wave-uniform test for the whole block)
+        int pc_[NH - 1];                                        // the six permutes go out together, then the six table reads:
+#pragma unroll                                                  // two LDS round trips in all instead of two per row
+        for (int e = 0; e < NH - 1; ++e) pc_[e] = bperm_i(7 * e + grp, pcode);   // (groups <= e read a pair lane with pe >= ph: "far")
+#pragma unroll
+        for (int e = 0; e < NH - 1; ++e) fsrc[e] = geo[e * (26 * 16) + pc_[e] * 16 + sub];   // (skipping single rows without a near pair measured slower)
+      }
 #pragma unroll
       for (int e = 0; e < NH - 1; ++e) asm volatile("" : "+v"(fsrc[e]));
     }
