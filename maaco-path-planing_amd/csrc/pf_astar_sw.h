@@ -812,6 +812,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
       const double tent_ok = ok ? tent : PF_INF;               // what my relaxation offers my cell (decided statically)
       const unsigned long long b_ = dbits(tent_ok);
       double tf[NH - 1];
+      if (nearg) {                                              // (wave-uniform) no near pair at all: no lane has a counterpart, nothing to replay
 #pragma unroll
       for (int e = 0; e < NH - 1; ++e) {
         tf[e] = PF_INF;
@@ -832,6 +833,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
         gmin = rel ? tf[e] : gmin;
         if (SEM == 0) clsd = clsd || popev;
         pred = (rel || popev) ? fsrc[e] : pred;
+      }
       }
     }
     const bool imp = gmin < g0;                                 // some earlier head of this trip improved my cell
