@@ -3,8 +3,8 @@
 // The open list is a monotone bucket queue with a sorted window (the round-1 designs it replaced -- lane-owned LDS
 // bins with an argmin + rescan per pop, and four speculative pops over those bins -- are in the history):
 //
-//   pool    entries live unsorted in HBM buckets keyed by floor(f * Q) (Q = 128, 512 circular buckets: a push is at
-//           most 2*sqrt(2) above the pop that made it, 363 buckets); an append is one LDS atomic for the slot
+//   pool    entries live unsorted in HBM buckets keyed by floor(f * Q) (Q = 256, 1024 circular buckets: a push is at
+//           most 2*sqrt(2) above the pop that made it, 725 buckets); an append is one LDS atomic for the slot
 //           index and ONE fire-and-forget 16-byte store of (g, cell) -- nothing waits for it;
 //   window  when the window runs dry the next non-empty buckets (<= 64 entries) are loaded one entry per lane and
 //           sorted on the full key (f, g, cell): the buckets already are in key order, so each entry only has to be
@@ -28,24 +28,32 @@ namespace pf {
 #define PF_LDS_ORDER() asm volatile("" ::: "memory")
 PF_DEV unsigned long long dbits(double x) { return (unsigned long long)__double_as_longlong(x); }
 
+// Bucket geometry.  r04: 1/256-wide buckets (1024 circular ones of 256 entries) halve the runs the refill has to order once more --
+// A/B on one box against 1/128 x 512 x 512: mpa512 190.9 -> 194.1 k evals/s, astar1024 55.6 -> 57.9 k solves/s, ga512 equal (r02
+// found no gain beyond 1/128, when the trip still carried what r04 took out of it).  PF_SW_NBK must cover 2*sqrt(2)*Q + 1 buckets
+// and its counts must fit below the sort's staging area; a -DPF_TWO_WAVE build keeps the r03 geometry (its rings live between them).
+#if defined(PF_TWO_WAVE) && !defined(PF_SW_Q)
+#define PF_SW_Q 128.0
+#define PF_SW_NBK 512
+#define PF_SW_CAP 512
+#endif
 #ifndef PF_SW_Q
-#define PF_SW_Q 128.0     /* buckets per unit of f; PF_SW_NBK must cover 2*sqrt(2)*Q + 1 buckets.  r02: 64 -> 128 halves the runs the
-                             refill has to order (A/B on one box: mpa512 160.1 -> 166.4 k evals/s, ga512 16.4 -> 17.1 k; 256: no further gain) */
+#define PF_SW_Q 256.0     /* buckets per unit of f (r01 64, r02 128: mpa512 160.1 -> 166.4 k evals/s) */
 #endif
 #ifndef PF_EARLY_REFILL
 #define PF_EARLY_REFILL 1   /* 0: refill only when the window is empty (A/B builds: 123-127 k against 131.5 k evals/s) */
 #endif
 #ifndef PF_EARLY_BELOW
-#define PF_EARLY_BELOW 7    /* the early refill runs when fewer live entries than this are left (7 = the heads of one trip) */
+#define PF_EARLY_BELOW 7    /* the early refill runs when fewer live entries than this are left (7 = the heads of one trip; 14 measured 1 % slower) */
 #endif
 #ifndef PF_RUN_SORT
 #define PF_RUN_SORT 1       /* 0: the bitonic network for every refill (A/B builds) */
 #endif
 #ifndef PF_SW_NBK
-#define PF_SW_NBK 512     /* circular buckets, a power of two (a stress build with a quarter of it sends far keys through the spill list) */
+#define PF_SW_NBK 1024    /* circular buckets, a power of two (a stress build with a quarter of it sends far keys through the spill list) */
 #endif
 #ifndef PF_SW_CAP
-#define PF_SW_CAP 512    /* entries per bucket (a stress build with -DPF_SW_CAP=8 drives everything through the spill list) */
+#define PF_SW_CAP 256    /* entries per bucket (a stress build with -DPF_SW_CAP=8 drives everything through the spill list) */
 #endif
 
 PF_DEV bool key_lt(double f1, double g1, int c1, double f2, double g2, int c2) {   // branch-free (f, g, cell) order
