@@ -149,7 +149,9 @@ PF_DEV int count_key_lt(int acc, double f1, double g1, int c1, double f2, double
 #ifndef PF_SORT_UNROLL
 #define PF_SORT_UNROLL 8
 #endif
+#ifndef PF_SORT_LDS
 #define PF_SORT_LDS 6144    /* staging: 64 x 32 B in the wave's LDS, [6144, 8192): free while the pop loop runs (pf_astar.h) */
+#endif
 struct __attribute__((aligned(16))) SortFG { double f, g; };
 PF_DEV void sort_runs(char* lds, double& f, double& g, int& c, int start, int m, int lane) {
   char* base = lds + PF_SORT_LDS;
@@ -385,7 +387,7 @@ PF_DEV bool respill(const SwPool& P, SwWin& W, int lane) {
 #ifndef PF_SELECT_MIN
 #define PF_SELECT_MIN 256   /* bucket size from which the pivot selection replaces the sort-and-merge pass */
 #endif
-#define PF_SEL_LDS 6144     /* byte offset of the staging area (64 x 20 B) in the wave's LDS, between the bucket counts and the replay table */
+#define PF_SEL_LDS PF_SORT_LDS   /* staging area of the pivot selection (64 x 20 B): the run sort's */
 PF_DEV int take_smallest_select(const SwPool& P, char* lds, int bi, int c0, double& wf, double& wg, int& wc, int lane) {
   constexpr int CAP = PF_SW_CAP;
   double* sf = (double*)(lds + PF_SEL_LDS); double* sg = sf + 64; int* sc = (int*)(sg + 64);
