@@ -571,10 +571,20 @@ struct TabuLast {
 
 // ---- 8-lane group arithmetic without LDS round trips (DPP only) ----
 // max over the group, in every lane (quad swaps, then the half-row mirror)
+// (every lane of these three patterns has a source lane, so the DPP move needs no previous value -- no copy in front of it -- and
+// the maximum is the bare instruction: fmax() puts a canonicalising v_max(x, x) in front of every step.  21 -> 9 instructions.
+// The operands are never NaN here: products of finite table entries, or the -1.0 of a lane without a candidate.)
+template <int CTRL>
+PF_DEV double dpp_full_d(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+PF_DEV double vmax_raw(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 PF_DEV double gmax8(double v) {
-  v = fmax(v, dpp_d<0xB1, 0xF>(v));    // quad_perm:[1,0,3,2]
-  v = fmax(v, dpp_d<0x4E, 0xF>(v));    // quad_perm:[2,3,0,1]
-  v = fmax(v, dpp_d<0x141, 0xF>(v));   // row_half_mirror
+  v = vmax_raw(v, dpp_full_d<0xB1>(v));    // quad_perm:[1,0,3,2]
+  v = vmax_raw(v, dpp_full_d<0x4E>(v));    // quad_perm:[2,3,0,1]
+  v = vmax_raw(v, dpp_full_d<0x141>(v));   // row_half_mirror
   return v;
 }
 // lane j of each group: ((a0 + a1) + a2 ... ) + aj, added in exactly that order (a sequential Python sum / numpy cumsum)
@@ -593,6 +603,12 @@ PF_DEV double glast8(double v) {
   const double lo = dpp_d<0x157, 0xF>(v), hi = dpp_d<0x15F, 0xF>(v);   // row_newbcast:7 / :15
   return (lane_id() & 8) ? hi : lo;
 }
+// Ballots of COMPOUND predicates are written as the AND of the ballots of their single compares, B(a) & B(b): the ballot of one
+// compare IS the compare's lane mask, but for `a & b` the compiler ANDs the two masks, turns the result into a 0/1 vector register
+// and compares that with zero again -- two vector instructions (and a scalar wait on them) per ballot, thirteen ballots per round of
+// k_maaco_walk8.  (A negated term needs a positive one beside it: ~B(x) also holds the lanes that are switched off.)
+typedef unsigned long long pf_u64;
+PF_DEV pf_u64 B(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __global__ __launch_bounds__(64) void k_maaco_walk(MaacoArgs p) {
   const int lane = lane_id();
   const Grid& G = p.G;
@@ -645,12 +661,13 @@ __global__ __launch_bounds__(64) void k_maaco_walk(MaacoArgs p) {
       if (inb) { vw = tl.patch(widx, visit[widx]); tv = p.tau[nidx]; ev = p.eta[(size_t)nidx * 2 + turn]; }
       else if (lane == 9) mmask = G.mm[cur];
       const unsigned M = (unsigned)bcast_i((int)mmask, 9);
-      const bool ok = inb && (M & hbit) && !tabu_test(vw, epoch, nc);   // valid, not tabu, no corner cut (:93-95,:100-120)
-      const unsigned mall = (unsigned)(__ballot(ok) & 0xFF);
+      // valid, not tabu, no corner cut (:93-95,:100-120); the low byte of the mask = lanes 0..7
+      const unsigned mall = (unsigned)(B((unsigned)nr < (unsigned)R) & B((unsigned)nc < (unsigned)C) & B((M & hbit) != 0u) &
+                                       ~(B((vw >> 16) == epoch) & B(((vw >> (nc & 15)) & 1u) != 0u))) & 0xFFu;
       // strategy 2 orientation: current -> target (:152-157)
-      const int vr = tr - cr, vc = tc - cc;
-      const bool o2 = !((vc > 0 && mdc < 0) || (vc < 0 && mdc > 0) || (vr > 0 && mdr < 0) || (vr < 0 && mdr > 0));
-      const unsigned O2 = (unsigned)(__ballot(o2 && lane < 8) & 0xFF);
+      // (RowMask[sign vr] & ColMask[sign vc] from two constants: see k_maaco_walk8)
+      const unsigned ur = (unsigned)min(max(tr + 1 - cr, 0), 2), uc = (unsigned)min(max(tc + 1 - cc, 0), 2);
+      const unsigned O2 = __builtin_amdgcn_ubfe(0xF8FF1Fu, ur << 3, 8u) & __builtin_amdgcn_ubfe(0xD6FF6Bu, uc << 3, 8u);
       unsigned cand = mall & O1;                                  // :165
       if (!cand) cand = mall & O2;                                // :168-169
       if (!cand) cand = mall;                                     // :172-180
@@ -668,9 +685,9 @@ __global__ __launch_bounds__(64) void k_maaco_walk(MaacoArgs p) {
       unsigned msel = cand;                                       // the set random.choice draws from
       bool chosen = false;
       if (greedy) {                                               // :241-250 running max with absolute tolerance, closed form (k_maaco_walk8)
-        const unsigned eq = (unsigned)__ballot(cmine && attr == Mx) & 0xFFu;
+        const unsigned eq = (unsigned)(B(attr == Mx)) & cand;      // (cand = the lanes 0..7 that hold a candidate)
         if (!eq) { rc = 1; break; }
-        msel = (unsigned)__ballot(cmine && k >= __builtin_ctz(eq) && fabs(attr - Mx) < 1e-9) & 0xFFu;
+        msel = (unsigned)(B(k >= __builtin_ctz(eq)) & B(fabs(attr - Mx) < 1e-9)) & cand;
       } else if (!(bcast_d(Mx, 0) * 8.0 < 5e-10)) {               // (else the ordered sum is below 1e-9 whatever its rounding: k_maaco_walk8)
         const double sum = bcast_d(gscan8(attr, k), 7);           // :252 sum() in candidate order (ordered 8-lane scan)
         if (!(sum < 1e-9)) {                                      // else :253-254: random.choice over all candidates
@@ -696,7 +713,7 @@ __global__ __launch_bounds__(64) void k_maaco_walk(MaacoArgs p) {
         const unsigned nsel = (unsigned)__builtin_popcount(msel);
         const int kb = 32 - __builtin_clz(nsel);
         const unsigned rk = (unsigned)(Wk >> (64 - kb));
-        const unsigned acc = (unsigned)__ballot(lane >= 1 && lane < 8 && rk < nsel) & 0xFFu;
+        const unsigned acc = (unsigned)B(rk < nsel) & 0xFEu;
         unsigned r;
         if (acc) { const int first = __builtin_ctz(acc); r = (unsigned)bcast_i((int)rk, first); g.advance(1u + (unsigned)first); }
         else { g.advance(8); do { r = (unsigned)(g.next64() >> (64 - kb)); } while (r >= nsel); }
@@ -750,10 +767,12 @@ __global__ __launch_bounds__(64) void k_maaco_walk(MaacoArgs p) {
 // lanes idle until the queue is empty.  Same draws, same arithmetic, same order as k_maaco_walk.
 // ---------------------------------------------------------------------------
 PF_DEV unsigned gballot8(bool p) { return (unsigned)(__builtin_amdgcn_ballot_w64(p) >> (lane_id() & 56)) & 0xFFu; }
+// (g8: my group's byte of a wave mask; compound predicates as B(a) & B(b), see above k_maaco_walk)
+PF_DEV unsigned g8(pf_u64 m) { return (unsigned)(m >> (lane_id() & 56)) & 0xFFu; }
 PF_DEV int gbcast8_i(int v, int k) { return __builtin_amdgcn_ds_bpermute(((lane_id() & 56) + k) << 2, v); }
 // index of the idx-th set bit of an 8-bit mask (lane k tests bit k)
 PF_DEV int gnth8(unsigned m, int idx, int k) {
-  return __builtin_ctz(gballot8(((m >> k) & 1u) && __builtin_popcount(m & ((1u << k) - 1u)) == idx) | 0x100u);
+  return __builtin_ctz(g8(B(((m >> k) & 1u) != 0u) & B(__builtin_popcount(m & ((1u << k) - 1u)) == idx)) | 0x100u);
 }
 PF_DEV double gbcast8_d(double v, int k) {
   const int lo = gbcast8_i(__double2loint(v), k), hi = gbcast8_i(__double2hiint(v), k);
@@ -780,7 +799,8 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
   const unsigned O1 = gballot8(o1);
   const int max_steps = RC * 2;                                    // MAACO.py:283
   // q0 is in [0.01, 0.99] (MAACO.py:226): q0 2^53 is exact, its floor the largest 53-bit draw that still takes the greedy rule
-  const uint64_t q0_bits = p.q0 >= 1.0 ? ~0ull : (p.q0 < 0.0 ? 0ull : (uint64_t)(p.q0 * 9007199254740992.0));
+  // (as `draw < q0_lim`: a `<=` against a run-time bound compiles to two compares, one for the bound's all-ones case)
+  const uint64_t q0_lim = p.q0 >= 1.0 ? (1ull << 53) : (p.q0 < 0.0 ? 0ull : (uint64_t)(p.q0 * 9007199254740992.0) + 1ull);
   unsigned long long steps_tot = 0, cand_tot = 0, cells_tot = 0, ovf_tot = 0;
   // per-ant state (replicated in the 8 lanes of the group)
   int a = -1, cr = 0, cc = 0, n = 0, prev_k = -1, nturn = 0, rc = 0;
@@ -865,11 +885,13 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
         pr_wait += __builtin_amdgcn_s_memtime() - pr_ta; }
 #endif
       // (bitwise on purpose: the short-circuit forms compiled to branches, each a scalar round trip on a freshly written lane mask)
-      const bool ok = inb & ((M & hbit) != 0u) & !(((vw >> 16) == epoch) & (((vw >> (nc & 15)) & 1u) != 0u));
-      const unsigned mall = gballot8(ok);
-      const int vr = tr - cr, vc = tc - cc;
-      const bool o2 = !(((vc > 0) & (mdc < 0)) | ((vc < 0) & (mdc > 0)) | ((vr > 0) & (mdr < 0)) | ((vr < 0) & (mdr > 0)));
-      const unsigned O2 = gballot8(o2);
+      const unsigned mall = g8(B((unsigned)nr < (unsigned)R) & B((unsigned)nc < (unsigned)C) & B((M & hbit) != 0u) &
+                               ~(B((vw >> 16) == epoch) & B(((vw >> (nc & 15)) & 1u) != 0u)));
+      // strategy 2 orientation, current -> target (:152-157): a move is kept iff its row step does not oppose sign(vr) and its column
+      // step does not oppose sign(vc) -- the eight-move mask is RowMask[sign vr] & ColMask[sign vc], two bit-field extracts from
+      // constants (moves 0..7 = AM_DR / AM_DC order) instead of eight compares, their scalar mask logic and a ballot
+      const unsigned ur = (unsigned)min(max(tr + 1 - cr, 0), 2), uc = (unsigned)min(max(tc + 1 - cc, 0), 2);
+      const unsigned O2 = __builtin_amdgcn_ubfe(0xF8FF1Fu, ur << 3, 8u) & __builtin_amdgcn_ubfe(0xD6FF6Bu, uc << 3, 8u);
       unsigned cand = mall & O1;                                    // :165
       if (!cand) cand = mall & O2;                                  // :168-169
       if (!cand) cand = mall;                                       // :172-180
@@ -880,7 +902,7 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
         const bool cmine = (cand >> k) & 1u;
         // :232 q = word 1 of the step (lane 0 of the group holds it): one ballot tells the group which rule applies
         // (q = (w >> 11) 2^-53 exactly, so q <= q0 iff w >> 11 <= floor(q0 2^53): two integer instructions instead of the conversion)
-        const bool greedy = (gballot8((Wk >> 11) <= q0_bits) & 1u) != 0;
+        const bool greedy = (g8(B((Wk >> 11) < q0_lim)) & 1u) != 0;
         const double attr = cmine ? tv * ev : 0.0;                  // :238; the other lanes add an exact zero to the ordered sums below
         int pick = 0;
 #ifdef PF_WALK_PROBE
@@ -898,12 +920,13 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
         // :241-250, the running maximum with its absolute tolerance, in closed form: the tie set restarts at the FIRST occurrence of
         // the maximum (`attr > max` drops every earlier member there) and from then on collects the candidates within 1e-9 of it
         // (none can exceed it).  NaN neither restarts nor joins, as in the loop.
-        const unsigned eq = gballot8(cmine & (attr == Mx));
-        const unsigned bm = gballot8(cmine & (k >= __builtin_ctz(eq | 0x100u)) & (fabs(attr - Mx) < 1e-9));
+        const pf_u64 cmm = B(((cand >> k) & 1u) != 0u);
+        const unsigned eq = g8(cmm & B(attr == Mx));
+        const unsigned bm = g8(cmm & B(k >= __builtin_ctz(eq | 0x100u)) & B(fabs(attr - Mx) < 1e-9));
         const bool tiny = Mx * 8.0 < 5e-10;                         // (a NaN maximum compares false: the sum decides)
         if (greedy && !eq) { rc = 1; done = true; }
         bool chosen = false;                                        // the roulette proper picked (two words of the stream: q and u)
-        if (__ballot(!greedy && !tiny)) {
+        if (B(true) & ~B(greedy) & ~B(tiny)) {
           // The sums of :252-259 run over the candidates in candidate order.  Candidate j lives in lane j, so each is one
           // ordered 8-lane scan (7 dependent DPP steps, no LDS round trip per candidate); every quotient belongs to one
           // candidate and is computed in its lane.  (The scans run for the whole wave; only the ants that need them use the result.)
@@ -937,12 +960,11 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
           const unsigned nsel = (unsigned)__builtin_popcount(msel) | (msel ? 0u : 1u);   // (>= 1: a failed ant's value is never used)
           const int kb = 32 - __builtin_clz(nsel);
           unsigned rk = (unsigned)(Wk >> (64 - kb));
-          const unsigned acc = gballot8(k >= 1 && rk < nsel);
-          const bool more = !chosen && !done && acc == 0u;           // all seven rejected (n = 1: once in 128 steps): draw on, one word at a time
+          const unsigned acc = g8(B(rk < nsel)) & 0xFEu;             // (word 1 is q: lanes k >= 1)
           unsigned r = (unsigned)gbcast8_i((int)rk, __builtin_ctz(acc | 0x80u));
           if (!chosen) g.advance(acc ? 1u + (unsigned)__builtin_ctz(acc) : 8u);
-          if (__ballot(more)) {
-            if (more) { do { r = (unsigned)(g.next64() >> (64 - kb)); } while (r >= nsel); }
+          if (B(acc == 0u)) {                                        // all seven rejected (n = 1: once in 128 steps): draw on, one word at a time
+            if (!chosen && !done && acc == 0u) { do { r = (unsigned)(g.next64() >> (64 - kb)); } while (r >= nsel); }
           }
           if (!chosen) pick = gnth8(msel, (int)r, k);
         }
