@@ -603,12 +603,6 @@ PF_DEV double glast8(double v) {
   const double lo = dpp_d<0x157, 0xF>(v), hi = dpp_d<0x15F, 0xF>(v);   // row_newbcast:7 / :15
   return (lane_id() & 8) ? hi : lo;
 }
-// Ballots of COMPOUND predicates are written as the AND of the ballots of their single compares, B(a) & B(b): the ballot of one
-// compare IS the compare's lane mask, but for `a & b` the compiler ANDs the two masks, turns the result into a 0/1 vector register
-// and compares that with zero again -- two vector instructions (and a scalar wait on them) per ballot, thirteen ballots per round of
-// k_maaco_walk8.  (A negated term needs a positive one beside it: ~B(x) also holds the lanes that are switched off.)
-typedef unsigned long long pf_u64;
-PF_DEV pf_u64 B(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __global__ __launch_bounds__(64) void k_maaco_walk(MaacoArgs p) {
   const int lane = lane_id();
   const Grid& G = p.G;
@@ -767,7 +761,7 @@ __global__ __launch_bounds__(64) void k_maaco_walk(MaacoArgs p) {
 // lanes idle until the queue is empty.  Same draws, same arithmetic, same order as k_maaco_walk.
 // ---------------------------------------------------------------------------
 PF_DEV unsigned gballot8(bool p) { return (unsigned)(__builtin_amdgcn_ballot_w64(p) >> (lane_id() & 56)) & 0xFFu; }
-// (g8: my group's byte of a wave mask; compound predicates as B(a) & B(b), see above k_maaco_walk)
+// (g8: my group's byte of a wave mask; compound predicates as B(a) & B(b): pf_device.h)
 PF_DEV unsigned g8(pf_u64 m) { return (unsigned)(m >> (lane_id() & 56)) & 0xFFu; }
 PF_DEV int gbcast8_i(int v, int k) { return __builtin_amdgcn_ds_bpermute(((lane_id() & 56) + k) << 2, v); }
 // index of the idx-th set bit of an 8-bit mask (lane k tests bit k)

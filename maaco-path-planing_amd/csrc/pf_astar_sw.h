@@ -59,6 +59,9 @@ PF_DEV unsigned long long dbits(double x) { return (unsigned long long)__double_
 PF_DEV bool key_lt(double f1, double g1, int c1, double f2, double g2, int c2) {   // branch-free (f, g, cell) order
   return (f1 < f2) | ((f1 == f2) & ((g1 < g2) | ((g1 == g2) & (c1 < c2))));
 }
+PF_DEV pf_u64 key_lt_m(double f1, double g1, int c1, double f2, double g2, int c2) {   // ... as a wave mask (B / PL: pf_device.h)
+  return B(f1 < f2) | (B(f1 == f2) & (B(g1 < g2) | (B(g1 == g2) & B(c1 < c2))));
+}
 PF_DEV int bperm_i(int src_lane, int v) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
 PF_DEV double bperm_d(int src_lane, double v) {
   const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
@@ -232,6 +235,8 @@ PF_DEV void geo_to_lds(char* smem, int lane) {
   for (int i = lane; i < (int)(sizeof(GeoTab) / 4); i += 64) dst[i] = src[i];
 }
 
+// lanes 0..48 as head pairs (e, h) = (lane / 7, lane % 7): the lanes with e < h
+constexpr unsigned long long make_pairs_eh() { unsigned long long m = 0; for (int l = 0; l < 49; ++l) if (l / 7 < l % 7) m |= 1ull << l; return m; }
 #define PF_SW_SPILL 16384
 static_assert((double)PF_SW_NBK >= 2.8285 * PF_SW_Q + 1.0, "a push lies at most 2*sqrt(2) above the pop that made it: the circular range must cover that");
 static_assert(4 * (PF_SW_NBK + 1) <= PF_SORT_LDS, "bucket counts and the sort's staging area share the wave's LDS");
@@ -301,8 +306,7 @@ struct SwWin {
 // insert a key that is below the limit; a full window returns its largest entry to the pool, which becomes the limit
 template <bool PR = false>
 PF_DEV bool win_insert(const SwPool& P, SwWin& W, double kf, double kg, int kc, int lane, PrLink* L = nullptr) {
-  const bool live = lane >= W.wp && lane < W.wn;
-  const int p = W.wp + __builtin_popcountll(__ballot(live && key_lt(W.wf, W.wg, W.wc, kf, kg, kc)));   // first live lane not below the key
+  const int p = W.wp + __builtin_popcountll(B(lane >= W.wp) & B(lane < W.wn) & key_lt_m(W.wf, W.wg, W.wc, kf, kg, kc));   // first live lane not below the key
   if (W.wn < 64) {
     const double sf = wave_up_d(W.wf), sg = wave_up_d(W.wg); const int sc = wave_up_i(W.wc);
     if (lane > p && lane <= W.wn) { W.wf = sf; W.wg = sg; W.wc = sc; }
@@ -479,7 +483,7 @@ PF_DEV int drop_superseded(const Rec* rec, int C, double& wf, double wg, int wc)
     const Rec r = rec[(wc >> 16) * C + (wc & 0xFFFF)];
     if ((r.meta & PF_M_CLOSED) || r.g != wg) { wf = PF_INF; live = false; }
   }
-  return __builtin_popcountll(__ballot(live));
+  return __builtin_popcountll(B(wf != PF_INF));
 }
 
 // ---- early refill: fewer than `below` entries left in the window.  With the front bucket and the spill list empty, every pool
@@ -667,7 +671,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
   W.n_pool = 0; W.n_spill = 0;
   if (PR) pr_search_start(*L, tr, tc, W.bcur, VARIANT == 2, lane);
   int steps = 0, status = 1;
-  unsigned nbr_l = 0, push_l = 0, dk_l = 0;                  // per-lane event counts, summed over the wave once at the end
+  unsigned nbr_s = 0, push_s = 0, dk_s = 0;                  // event counts of the wave (uniform)
   int n_max = 1;
 #ifdef PF_TRIPS
   unsigned tr_short = 0, tr_full = 0, tr_viol = 0, tr_near = 0, tr_pot = 0;
@@ -769,9 +773,10 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     // "far"); each lane then reads its source lane from a table in LDS, [e][offset][sub] -> bpermute address (bit 0:
     // head e IS my cell; 63*4: none).  All in the shadow of the loads.
     const int Dr_ = (rch >> 16) - (rce >> 16), Dc_ = (rch & 0xFFFF) - (rce & 0xFFFF);
-    const bool nearp = lane_t < NH * NH && pe < ph && ph < nh && (unsigned)(Dr_ + 2) <= 4u && (unsigned)(Dc_ + 2) <= 4u;
-    const int pcode = nearp ? (Dr_ + 2) * 5 + (Dc_ + 2) : 25;
-    const unsigned long long nearg = __ballot(nearp);           // bit 7e+h
+    // (predicates as wave masks from here on: B(compare) / PL(mask), pf_device.h -- every ballot below is a scalar AND)
+    constexpr pf_u64 PAIRS_EH = make_pairs_eh();                // lane < 49 && e < h
+    const pf_u64 nearg = PAIRS_EH & B(ph < nh) & B((unsigned)(Dr_ + 2) <= 4u) & B((unsigned)(Dc_ + 2) <= 4u);   // bit 7e+h
+    const int pcode = PL(nearg) ? (Dr_ + 2) * 5 + (Dc_ + 2) : 25;
     const unsigned char* geo = (const unsigned char*)O.lf + PF_GEO_OFF;
     int fsrc[NH - 1];
     {
@@ -796,24 +801,26 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     SW_T(t3)                          // meaningful in the self lanes (sub == 8)
     // VARIANT 0: an entry superseded by a decrease-key (astar.py:96-100 rewrites it in place) is not a pop of the
     // reference: its head is consumed without effect and without being counted
-    const bool self_stale = SEM == 0 && sub == 8 && ((cur_meta & PF_M_CLOSED) || rn.g != pg);
-    const unsigned long long stm = __ballot(have && self_stale);
-    const bool my_stale = (stm >> grp) & 1ull;
+    constexpr pf_u64 SELF7 = 0x7Full, MOVES = 0x7FFFFFFFFFFFFF80ull;   // lanes 0..6: the self lanes (sub == 8); lanes 7..62: the move lanes (sub < 8)
+    const pf_u64 mHave = B(grp < nh);
+    pf_u64 stm = 0ull;
+    if (SEM == 0) stm = SELF7 & mHave & (B((cur_meta & PF_M_CLOSED) != 0u) | B(rn.g != pg));
     const unsigned M = (unsigned)bperm_i(grp, (int)rn.tagmm) & 0xFFu;   // my head's self lane is lane `grp`: its record's mask byte
     if (SEM == 1) cur_g = bperm_d(grp, rn.g);
     const double base_g = SEM == 0 ? pg : cur_g;           // astar.py:85 popped g / MPA.py:135 g_score[current]
-    const bool rvalid = (rn.tagmm >> PF_TAG_SHIFT) == tag;
-    const bool avoided = (rn.meta >> PF_AVOID_SHIFT) == avm;
-    const bool closed = rvalid && (rn.meta & PF_M_CLOSED);
-    bool ok = have && sub < 8 && ((M >> d) & 1u) && !my_stale && cur != target;
-    if (SEM == 0) ok = ok && !closed && !(avoided && nidx != start && nidx != target);
-    else ok = ok && !avoided;
+    const pf_u64 mValid = B((rn.tagmm >> PF_TAG_SHIFT) == tag);
+    const pf_u64 mAvoid = B((rn.meta >> PF_AVOID_SHIFT) == avm);
+    pf_u64 mOk = mHave & MOVES & B(((M >> d) & 1u) != 0u) & B(cur != target);
+    if (SEM == 0) mOk &= ~B(((stm >> grp) & 1ull) != 0ull) & ~(mValid & B((rn.meta & PF_M_CLOSED) != 0u)) & ~(mAvoid & B(nidx != start) & B(nidx != target));
+    else mOk &= ~mAvoid;
+    const bool ok = PL(mOk);
+    const bool rvalid = PL(mValid);
     const double tent = base_g + cost;
     const unsigned stale7 = SEM == 0 ? (unsigned)stm & 0x7Fu : 0u;   // the self lanes are lanes 0..6
     // ---- replay the earlier heads' effects on my cell (see above), in head order ----
     const double g0 = rvalid ? rn.g : PF_INF;
     double gmin = g0;                                           // g_score of my cell as head `grp` will find it
-    bool clsd = false;
+    pf_u64 mClsd = 0ull;                                        // (closed-set variants) an earlier head of this trip pops my cell
     int pred = 63 * 4;                                          // the last earlier lane that writes my cell's record (bit 0: by popping it)
     {
       // The replay arithmetic runs for every row: a lane with no counterpart in head e reads lane 63 (+inf, no
@@ -837,23 +844,24 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
         // (wave-uniform) head e has no near successor: every lane's source is "none", nothing below changes anything.  Skipped in
         // the closed-set variants only -- A/B on one box: ga512 +1.7 %, but the MPA variant's leaner row lost 3 % to the branches
         if (SEM == 0 && !((nearg >> (7 * e)) & 0x7Full)) continue;
-        bool popev = fsrc[e] & 1;                                          // head e pops my cell ...
-        if (SEM == 0) popev = popev && !((stale7 >> e) & 1u);               // ... unless it is a superseded entry
-        const bool rel = tf[e] < gmin && !(SEM == 0 && clsd);             // head e's lane improves my cell
-        gmin = rel ? tf[e] : gmin;
-        if (SEM == 0) clsd = clsd || popev;
-        pred = (rel || popev) ? fsrc[e] : pred;
+        pf_u64 mPop = B((fsrc[e] & 1) != 0);                               // head e pops my cell ...
+        if (SEM == 0 && ((stale7 >> e) & 1u)) mPop = 0ull;                  // ... unless it is a superseded entry (uniform)
+        const pf_u64 mRel = SEM == 0 ? (B(tf[e] < gmin) & ~mClsd) : B(tf[e] < gmin);   // head e's lane improves my cell
+        gmin = PL(mRel) ? tf[e] : gmin;
+        if (SEM == 0) mClsd |= mPop;
+        pred = PL(mRel | mPop) ? fsrc[e] : pred;
       }
       }
     }
-    const bool imp = gmin < g0;                                 // some earlier head of this trip improved my cell
+    const pf_u64 mImp = B(gmin < g0);                           // some earlier head of this trip improved my cell
     // in the open list: after the last event on my cell -- an improvement puts it there, a pop takes it out (MPA.py:
     // 122/147); the closed-set variants test "has an entry" (astar.py:92)
-    const bool inop = SEM == 0 ? (rvalid || imp) : (pred == 63 * 4 ? (rvalid && (rn.meta & PF_M_INOPEN)) : !(pred & 1));
-    const bool okd = ok && !(SEM == 0 && clsd);                 // astar.py:83 closed set, incl. this trip's earlier pops
-    const bool better = okd && tent < gmin;                     // astar.py:87 / MPA.py:137
-    const bool in_open = inop;
-    const bool push0 = SEM == 0 ? better : (better && !in_open);
+    pf_u64 mInop;
+    if (SEM == 0) mInop = mValid | mImp;
+    else { const pf_u64 mNoPred = B(pred == 63 * 4); mInop = (mNoPred & mValid & B((rn.meta & PF_M_INOPEN) != 0u)) | (B((pred & 1) == 0) & ~mNoPred); }
+    const pf_u64 mOkd = SEM == 0 ? (mOk & ~mClsd) : mOk;             // astar.py:83 closed set, incl. this trip's earlier pops
+    const pf_u64 mBetter = mOkd & B(tent < gmin);               // astar.py:87 / MPA.py:137
+    const pf_u64 mPush0 = SEM == 0 ? mBetter : (mBetter & ~mInop);
     const double fnew = tent + hn;                             // astar.py:90 / MPA.py:140
     const int nrc = (nr << 16) | nc;
     // ---- which heads take effect ----
@@ -866,12 +874,12 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
       // A push can only violate a head that exists, lies behind its own group and has f >= the key -- so at the very least the
       // LAST head: no push at or below f_last from a group before the last one means no violation at all, and the six compares
       // (with the twelve v_readlane that fetch the heads' f) run only in the trips that may lose a head (one in ten).
-      if (__ballot(push0 && grp < nh - 1 && fb <= f_last)) {
+      if (mPush0 & B(grp < nh - 1) & B(fb <= f_last)) {
         int c_ = 0;
 #pragma unroll
         for (int h = 1; h < NH; ++h) c_ += dbits(bcast_d(W.wf, W.wp + (h < nh ? h : nh - 1))) < fb ? 1 : 0;   // (past the last head: its f again, so the list stays sorted)
         const int hv = (c_ > grp ? c_ : grp) + 1;
-        const unsigned hmin = wave_min_u32(push0 ? (unsigned)hv : (unsigned)NH);
+        const unsigned hmin = wave_min_u32(PL(mPush0) ? (unsigned)hv : (unsigned)NH);
         viol = (0x7Fu << hmin) & 0x7Fu;
       }
     }
@@ -880,11 +888,10 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     // REAL head; since a head can only take effect when every earlier real head did, testing nearness against all
     // earlier real heads (not just the committed ones) changes nothing.  Everything below the first failing real head
     // is consumed; the target, or the step cap, cuts that prefix short.
-    const unsigned tgtm = (unsigned)__ballot(lane_t < NH && rch == trc);      // bit h: head h is the target
+    const unsigned tgtm = (unsigned)(SELF7 & B(rch == trc));                  // bit h: head h is the target (lanes 0..6 are the pairs (0, h))
     // an earlier head improved head h's OWN cell: its relaxations would start from another g (MPA.py:135) or its entry
     // is superseded (astar.py:96-100) -- the one effect that is not replayed; the trip stops there
-    const unsigned long long impm = __ballot(sub == 8 && imp);
-    const unsigned c1 = (unsigned)impm & 0x7Eu;
+    const unsigned c1 = (unsigned)mImp & 0x7Eu;                 // (the self lanes are lanes 0..6)
     const unsigned exist7 = (1u << nh) - 1u;
     int first = __builtin_ctz((((viol | c1) & ~stale7) | ~exist7) | 0x80u);   // first failing real head (or nh)
     unsigned real = ((1u << first) - 1u) & ~stale7;             // the real pops below it
@@ -903,18 +910,19 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     SW_T(t4)
     if (consumed == 0) { status = 2; break; }                   // only the step cap can stop head 0
     W.wp += consumed;
-    const bool eff = (E >> grp) & 1u;
+    const pf_u64 mEff = B(((E >> grp) & 1u) != 0u);
+    const pf_u64 mBE = mBetter & mEff;
     // a record written twice in this trip keeps the LAST write: a lane that writes tells the previous writer of its
     // cell (forward permute; lanes nobody addresses read 0) to keep quiet -- no two lanes store to one address
     bool keep = true;
-    if (__ballot(better && eff && pred != 63 * 4))              // (rare: two improvements of one cell in one trip)
-      keep = __builtin_amdgcn_ds_permute((better && eff) ? (pred & ~3) : 63 * 4, 1) == 0;
-    if (eff && sub == 8 && keep)                                // astar.py:74 closed.add / leave the open list
+    if (mBE & ~B(pred == 63 * 4))                               // (rare: two improvements of one cell in one trip)
+      keep = __builtin_amdgcn_ds_permute(PL(mBE) ? (pred & ~3) : 63 * 4, 1) == 0;
+    if (PL(mEff & SELF7) && keep)                                // astar.py:74 closed.add / leave the open list
       rec[cur].meta = SEM == 0 ? (cur_meta | PF_M_CLOSED) : (cur_meta & ~PF_M_INOPEN);
-    const bool push = push0 && eff;
-    nbr_l += (okd && eff) ? 1u : 0u;
-    if (SEM == 0) dk_l += (better && in_open && eff) ? 1u : 0u;
-    if (better && eff && keep) {
+    const pf_u64 mPush = mPush0 & mEff;
+    nbr_s += (unsigned)__builtin_popcountll(mOkd & mEff);       // (event counts of the wave: one scalar popcount each)
+    if (SEM == 0) dk_s += (unsigned)__builtin_popcountll(mBE & mInop);
+    if (PL(mBE) && keep) {
       Rec wv; wv.g = tent; wv.tagmm = (tag << PF_TAG_SHIFT) | (rn.tagmm & 0xFFu);
       wv.meta = (rn.meta & PF_AVOID_KEEP) | (unsigned)d | (SEM == 1 ? PF_M_INOPEN : 0u);
       rec[nidx] = wv;
@@ -922,18 +930,18 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     // ---- pushes: below the limit -> into the window, else -> pool bucket ----
     // The slot index of a pool append comes from an LDS atomic; it is requested here and used after the window
     // inserts, so its latency is covered by them.
-    const bool tow = push && key_lt(fnew, tent, nrc, W.lf, W.lg, W.lc);
-    const bool top = push && !tow;
+    const pf_u64 mTow = mPush & key_lt_m(fnew, tent, nrc, W.lf, W.lg, W.lc);
+    const pf_u64 mTop = mPush & ~mTow;
     const int pba = (int)(fnew * PF_SW_Q);
     const int pb = pba < W.bcur ? NBK : (pba & (NBK - 1));       // below every regular bucket: the front bucket
-    const bool inrange = pba - W.bcur < NBK;                   // inside the circular bucket range (front bucket: always)
+    const pf_u64 mInr = B(pba - W.bcur < NBK);                 // inside the circular bucket range (front bucket: always)
     int pat = 0;
-    const unsigned long long pm = __ballot(push), im0 = __ballot(tow);
+    const unsigned long long pm = mPush, im0 = mTow;
     if (PR) {
       // two-wave mode: 16 bytes into the ring, in lane order; the pool wave buckets them
       if (L->tail - rhead > PF_PR_RING_N - 128) { if (!pr_wait_room(*L)) { status = 3; break; } }
       const unsigned long long tm = pm & ~im0;
-      if (top) {
+      if (PL(mTop)) {
         const unsigned at = (L->tail + (unsigned)__builtin_popcountll(tm & ((1ull << lane) - 1ull))) & (PF_PR_RING_N - 1);
         ent_put(L->ring + at, tent, nrc); L->ring_f[at] = fnew;     // (f travels too: the pool wave need not take the square root again)
       }
@@ -945,20 +953,20 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
         pr_request(*L, 64 - (W.wn - W.wp) - __builtin_popcountll(im0), lane);
       else pr_publish(*L, lane);
     } else {
-      if (top && inrange) pat = __hip_atomic_fetch_add(&P.cnt[pb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (PL(mTop & mInr)) pat = __hip_atomic_fetch_add(&P.cnt[pb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     W.n_pool += __builtin_popcountll(pm & ~im0);
-    push_l += (push && !(SEM == 0 && in_open)) ? 1u : 0u;       // heappush calls of the reference
+    push_s += (unsigned)__builtin_popcountll(SEM == 0 ? (mPush & ~mInop) : mPush);   // heappush calls of the reference
     SW_T(t5)
     unsigned long long im = im0;
-    const unsigned long long dkm = SEM == 0 ? __ballot(push && in_open) : 0ull;   // decrease-keys among the pushes
+    const unsigned long long dkm = SEM == 0 ? (mPush & mInop) : 0ull;   // decrease-keys among the pushes
     while (im) {
       const int l = __builtin_ctzll(im); im &= im - 1;
       const int kc = bcast_i(nrc, l);
       if (SEM == 0 && ((dkm >> l) & 1ull)) {
         // decrease-key (astar.py:96-100): if the entry it supersedes is in the window, take it out now instead of
         // dropping it when it reaches the head (it would cost a head slot and a batch of loads)
-        const unsigned long long qm = __ballot(lane >= W.wp && lane < W.wn && W.wc == kc);
+        const unsigned long long qm = B(lane >= W.wp) & B(lane < W.wn) & B(W.wc == kc);
         if (qm) {
           const int q = __builtin_ctzll(qm);
           const double sf = wave_down_d(W.wf), sg = wave_down_d(W.wg); const int sc = wave_down_i(W.wc);
@@ -972,12 +980,12 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     if (status == 3) break;
     SW_T(t6)
     if (!PR) {
-      const bool fits = inrange && pat < CAP;
-      if (top && fits) ent_put(P.be + pb * CAP + pat, tent, nrc);
-      const unsigned long long sm = __ballot(top && !fits);     // bucket full or beyond the circular range: spill list
+      const pf_u64 mFits = mInr & B(pat < CAP);
+      if (PL(mTop & mFits)) ent_put(P.be + pb * CAP + pat, tent, nrc);
+      const unsigned long long sm = mTop & ~mFits;              // bucket full or beyond the circular range: spill list
       if (sm) {
-        if (top && !fits) {
-          if (inrange) __hip_atomic_fetch_add(&P.cnt[pb], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // a number past the end: give it back
+        if (PL(sm)) {
+          if (PL(mInr)) __hip_atomic_fetch_add(&P.cnt[pb], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // a number past the end: give it back
           const int at = W.n_spill + __builtin_popcountll(sm & ((1ull << lane) - 1ull));
           if (at < PF_SW_SPILL) ent_put(P.se + at, tent, nrc);
         }
@@ -1021,11 +1029,11 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     if (ovf) status = 3;                                        // the pool wave lost entries (or never answered): never silent
   }
   if (n_max > st.max_open) st.max_open = n_max;
-  st.pops += (unsigned long long)steps; st.pushes += 1u + (unsigned)wave_sum_i((int)push_l);
+  st.pops += (unsigned long long)steps; st.pushes += 1u + push_s;
 #ifdef PF_TRIPS
-  st.nbr += tr_viol; st.deckey += tr_near; st.spills += tr_pot; (void)tr_full; (void)tr_short; (void)nbr_l; (void)dk_l;
+  st.nbr += tr_viol; st.deckey += tr_near; st.spills += tr_pot; (void)tr_full; (void)tr_short; (void)nbr_s; (void)dk_s;
 #else
-  st.nbr += (unsigned)wave_sum_i((int)nbr_l); st.deckey += (unsigned)wave_sum_i((int)dk_l);
+  st.nbr += nbr_s; st.deckey += dk_s;
 #endif
   return status;
 }

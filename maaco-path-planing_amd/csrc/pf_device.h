@@ -57,6 +57,15 @@ PF_DEV double bcast_d(double v, int lane) {
   int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
   return __hiloint2double(hi, lo);
 }
+// Predicates as wave masks.  The ballot of ONE compare is that compare's lane mask (the v_cmp writes it), but for a compound
+// predicate `a & b` the compiler ANDs the two masks, turns the result into a 0/1 vector register and compares that with zero
+// again: two vector instructions and a scalar wait per ballot (thirteen per round of k_maaco_walk8, eight per A* trip).  So
+// compound predicates are built from the masks of their single compares, B(a) & B(b), in scalar registers, and turned back into
+// a lane predicate -- for a select, a store or a branch -- by PL(mask), which costs nothing (the mask IS the condition operand).
+// A negated term needs a positive one beside it where lanes may be switched off: ~B(x) holds those lanes too.
+typedef unsigned long long pf_u64;
+PF_DEV pf_u64 B(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+PF_DEV bool PL(pf_u64 m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 PF_DEV int first_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 PF_DEV uint64_t first_u64(uint64_t v) {
   uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
