@@ -893,15 +893,18 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     // is superseded (astar.py:96-100) -- the one effect that is not replayed; the trip stops there
     const unsigned c1 = (unsigned)mImp & 0x7Eu;                 // (the self lanes are lanes 0..6)
     const unsigned exist7 = (1u << nh) - 1u;
-    int first = __builtin_ctz((((viol | c1) & ~stale7) | ~exist7) | 0x80u);   // first failing real head (or nh)
-    unsigned real = ((1u << first) - 1u) & ~stale7;             // the real pops below it
-    if (real & tgtm) { first = __builtin_ctz(real & tgtm) + 1; real &= (1u << first) - 1u; }   // astar.py:64 / MPA.py:123
     const int allowed = max_steps - steps;                       // the cap counts real pops (astar.py:58 / MPA.py:118)
-    if (__builtin_popcount(real) > allowed) {
-      unsigned r_ = real; int keep = allowed > 0 ? allowed : 0;
-      while (keep-- > 0) r_ &= r_ - 1;                           // drop the `allowed` lowest real heads ...
-      first = __builtin_ctz(r_);                                 // ... the next one is where the cap stops the loop
-      real &= (1u << first) - 1u;
+    int first = nh; unsigned real = exist7;                      // the usual trip: nothing in the way, every head takes effect ...
+    if (((viol | c1 | tgtm | stale7) != 0u) | (allowed < NH)) {  // ... decided by ONE scalar test instead of the dependent chain below
+      first = __builtin_ctz((((viol | c1) & ~stale7) | ~exist7) | 0x80u);   // first failing real head (or nh)
+      real = ((1u << first) - 1u) & ~stale7;                     // the real pops below it
+      if (real & tgtm) { first = __builtin_ctz(real & tgtm) + 1; real &= (1u << first) - 1u; }   // astar.py:64 / MPA.py:123
+      if (__builtin_popcount(real) > allowed) {
+        unsigned r_ = real; int keep = allowed > 0 ? allowed : 0;
+        while (keep-- > 0) r_ &= r_ - 1;                         // drop the `allowed` lowest real heads ...
+        first = __builtin_ctz(r_);                               // ... the next one is where the cap stops the loop
+        real &= (1u << first) - 1u;
+      }
     }
     const int consumed = first;
     const bool hit = (real & tgtm) != 0;
