@@ -165,12 +165,14 @@ PF_DEV void sort_runs(char* lds, double& f, double& g, int& c, int start, int m,
   const char* run = base + start * 32;
   // PF_SORT_UNROLL entries a round, read unconditionally (their LDS reads go out back to back; past my run's end they return
   // other runs' entries or bytes behind the staging area -- inside the wave's LDS, ignored by the t + u < m test)
-  for (int t = 0; __ballot(t < m) != 0ull; t += PF_SORT_UNROLL) {
+  for (int t = 0;; t += PF_SORT_UNROLL) {
+    const pf_u64 m0 = B(t < m);                                    // (the round's first mask is the loop test)
+    if (!m0) break;
     SortFG e[PF_SORT_UNROLL]; int ec[PF_SORT_UNROLL];
 #pragma unroll
     for (int u = 0; u < PF_SORT_UNROLL; ++u) { e[u] = *(const SortFG*)(run + (t + u) * 32); ec[u] = *(const int*)(run + (t + u) * 32 + 16); }
 #pragma unroll
-    for (int u = 0; u < PF_SORT_UNROLL; ++u) below = count_key_lt(below, e[u].f, e[u].g, ec[u], f, g, c, __ballot(t + u < m));
+    for (int u = 0; u < PF_SORT_UNROLL; ++u) below = count_key_lt(below, e[u].f, e[u].g, ec[u], f, g, c, u == 0 ? m0 : B(t + u < m));
   }
   PF_LDS_ORDER();
   const bool live = f != PF_INF;
@@ -741,7 +743,8 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     // instructions with their scalar index arithmetic -- bought the load addresses ~70 clocks of LDS latency at 4x the issue slots)
     const int hsrc = W.wp + grp < 64 ? W.wp + grp : 63;            // my group's head lives in this window lane
     const int prc = bperm_i(hsrc, W.wc);                        // (r << 16 | c)
-    const bool have = grp < nh;                                 // (lane 63 is group 7: never)
+    const pf_u64 mHave = B(grp < nh);                           // (lane 63 is group 7: never; as a wave mask, see below)
+    const bool have = PL(mHave);
     const int pr = prc >> 16, pc = prc & 0xFFFF;
     const int cur = pr * C + pc;
     // ---- one batch of loads: 8 neighbour records, the cell's own record, its move mask (and g, MPA variant) ----
@@ -802,7 +805,6 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     // VARIANT 0: an entry superseded by a decrease-key (astar.py:96-100 rewrites it in place) is not a pop of the
     // reference: its head is consumed without effect and without being counted
     constexpr pf_u64 SELF7 = 0x7Full, MOVES = 0x7FFFFFFFFFFFFF80ull;   // lanes 0..6: the self lanes (sub == 8); lanes 7..62: the move lanes (sub < 8)
-    const pf_u64 mHave = B(grp < nh);
     pf_u64 stm = 0ull;
     if (SEM == 0) stm = SELF7 & mHave & (B((cur_meta & PF_M_CLOSED) != 0u) | B(rn.g != pg));
     const unsigned M = (unsigned)bperm_i(grp, (int)rn.tagmm) & 0xFFu;   // my head's self lane is lane `grp`: its record's mask byte
@@ -856,9 +858,10 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     const pf_u64 mImp = B(gmin < g0);                           // some earlier head of this trip improved my cell
     // in the open list: after the last event on my cell -- an improvement puts it there, a pop takes it out (MPA.py:
     // 122/147); the closed-set variants test "has an entry" (astar.py:92)
+    const pf_u64 mNoPred = SEM == 1 ? B(pred == 63 * 4) : 0ull;  // (MPA variant: used twice) nothing earlier in this trip writes my cell's record
     pf_u64 mInop;
     if (SEM == 0) mInop = mValid | mImp;
-    else { const pf_u64 mNoPred = B(pred == 63 * 4); mInop = (mNoPred & mValid & B((rn.meta & PF_M_INOPEN) != 0u)) | (B((pred & 1) == 0) & ~mNoPred); }
+    else mInop = (mNoPred & mValid & B((rn.meta & PF_M_INOPEN) != 0u)) | (B((pred & 1) == 0) & ~mNoPred);
     const pf_u64 mOkd = SEM == 0 ? (mOk & ~mClsd) : mOk;             // astar.py:83 closed set, incl. this trip's earlier pops
     const pf_u64 mBetter = mOkd & B(tent < gmin);               // astar.py:87 / MPA.py:137
     const pf_u64 mPush0 = SEM == 0 ? mBetter : (mBetter & ~mInop);
@@ -918,7 +921,7 @@ __device__ __forceinline__ int pop_loop_sw(const Grid& G, Rec* rec, const Open& 
     // a record written twice in this trip keeps the LAST write: a lane that writes tells the previous writer of its
     // cell (forward permute; lanes nobody addresses read 0) to keep quiet -- no two lanes store to one address
     bool keep = true;
-    if (mBE & ~B(pred == 63 * 4))                               // (rare: two improvements of one cell in one trip)
+    if (mBE & ~(SEM == 1 ? mNoPred : B(pred == 63 * 4)))        // (rare: two improvements of one cell in one trip)
       keep = __builtin_amdgcn_ds_permute(PL(mBE) ? (pred & ~3) : 63 * 4, 1) == 0;
     if (PL(mEff & SELF7) && keep)                                // astar.py:74 closed.add / leave the open list
       rec[cur].meta = SEM == 0 ? (cur_meta | PF_M_CLOSED) : (cur_meta & ~PF_M_INOPEN);
