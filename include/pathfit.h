@@ -279,7 +279,7 @@ int pf_mpa_memory(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_sl
  * / Dijkstra / GA / PSO decodes) try the parallel label-settling engine first: -1 (default) the Dijkstra variant
  * always (it is always certified) and the A* searches of the decodes at the head of a batch's longest-first queue
  * ("astar_settle_top", per mille of the batch, default 0 since r03; a decode is a chain of W + 1 searches, so a fallback costs
- * one link) and -- "astar_settle_tail", per mille of the search slots, default 600 -- every decode search that starts once
+ * one link) and -- "astar_settle_tail", per mille of the search slots, default 400 -- every decode search that starts once
  * the batch's unfinished agents no longer fill that share of the chip (the long chains the batch ends on, on an idle chip); 1 every A* search too (exact -- certified or handed back to the sequential loop -- but slower
  * on batches of single searches); 0 never (the sequential loop's pop / push counters are the reference's).  Test hook: "astar_step_cap" > 0
  * lowers the connectors' step cap below the reference's 3RC / 2RC (astar.py:58, MPA.py:118) so that the cap path

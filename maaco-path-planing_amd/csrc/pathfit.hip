@@ -2469,7 +2469,7 @@ static const int kWavesPerCU = env_int("PF_WAVES_PER_CU", kSlotsPerCU);   // res
 static int g_mpa_prune = 1;   // exact bound pruning of MPA rebuilds (pf_set_option "mpa_prune")
 static int g_settle_top = env_int("PF_SETTLE_TOP", 0);  // auto mode ("astar_settle" -1): per mille of a DECODE batch, from the head of the longest-first queue, whose A* searches
                                                          // also try the engine (pf_set_option "astar_settle_top")
-static int g_settle_tail = env_int("PF_SETTLE_TAIL", 600);   // auto mode: per mille of the SEARCH SLOTS; once no more agents of a decode batch than this are unfinished, every search that starts
+static int g_settle_tail = env_int("PF_SETTLE_TAIL", 400);   // (r03: 600; re-measured after the r04 trip cuts: 200 / 400 / 600 / 800 -> ga512 23.9 / 23.8 / 23.6 / 23.1 k, pso512 13.2 / 13.4 / 12.9 / 12.9 k) auto mode: per mille of the SEARCH SLOTS; once no more agents of a decode batch than this are unfinished, every search that starts
                                                               // tries the engine (pf_set_option "astar_settle_tail")
 static int g_settle = env_int("PF_SETTLE", -1);  // closed-set searches try the 64-nodes-per-trip engine first (pf_settle.h; pf_set_option "astar_settle"):
                                                   // -1 (default) Dijkstra only -- h == 0 makes every node regular, so it is never handed back, and it measures

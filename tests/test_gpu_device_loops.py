@@ -352,7 +352,7 @@ def test_head_of_queue_settling_leaves_decodes_unchanged():
             c = e.counters()
             outs.append((dc.download(), dl.download(), ds.download(), dst.download(), c["settled_searches"] + c["sequential_searches"]))
     finally:
-        e.set_option("astar_settle", -1); e.set_option("astar_settle_top", 0); e.set_option("astar_settle_tail", 600)
+        e.set_option("astar_settle", -1); e.set_option("astar_settle_top", 0); e.set_option("astar_settle_tail", 400)
     ref = outs[0]
     assert ref[4] == 0 and outs[1][4] == 0                    # nothing tries the engine with a share of 0
     tried = [o[4] for o in outs]
