@@ -271,7 +271,8 @@ int pf_mpa_memory(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_sl
                   double* d_pop_stats);
 
 /* Tuning knobs (results never change): "maaco_pack8_min" ants per batch from which eight ants share a wavefront
- * (default 2048);
+ * (default 2048); "maaco_load_ahead" the packed walk kernel's load-ahead form (all of a step's loads issued together plus touches of the
+ * records two steps ahead): -1 (default) for batches of at most one wavefront per SIMD, 0 never, 1 always;
  * "mpa_prune" 0/1 exact bound pruning of MPA rebuilds (default 1); "two_wave" 0/1 MPA._a_star searches (pf_mpa_iter_batch,
  * pf_astar_batch variant 1) on two-wavefront workgroups -- a pop wave and a pool wave, csrc/pf_astar_pr.h -- default 0:
  * identical pops, measured 0.9x; compiled only with -DPF_TWO_WAVE (PF_EXTRA_FLAGS of build.py), otherwise

@@ -774,6 +774,13 @@ PF_DEV double gbcast8_d(double v, int k) {
 }
 
 // eight ants per wavefront: the 8 lanes of a group hold the 8 moves of one ant
+// AHEAD, the form for batches that leave a SIMD ONE wavefront (8 192 ants: a step then waits ~2 000 clocks for memory, and nothing
+// else runs meanwhile): all of a step's loads are issued before anything waits for one of them (the compiler otherwise sinks the
+// pheromone load behind the candidate test: a second round trip), and every move lane also asks for the pheromone record and
+// the tabu word two steps ahead in its direction -- where the NEXT step's neighbours live -- right behind the step's own loads
+// (memory returns in order: they cannot delay them; results unused).  A/B on one box (M evals/s): 8 192 ants @1024^2 2.87 -> 3.04;
+// 16 384 ants @512^2 (two wavefronts per SIMD, issue-bound) 8.75 -> 8.50 -- so the host picks the form by occupancy.
+template <bool AHEAD>
 __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
   const Grid& G = p.G;
   const int R = G.R, C = G.C, RC = R * C;
@@ -833,8 +840,10 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
   // One wave-uniform test per round: "did an ant finish?" (one round in a hundred).  Emitting, deposit marking, fetching the group's
   // next ant and the end-of-queue test all sit behind it; a round that only steps pays for nothing else.  (A wave none of whose
   // groups got an ant -- the queue was drained by the others' first fetches -- never enters the loop: every exit is behind any_fin.)
+  unsigned pft0 = 0, pft1 = 0;
   if (__ballot(alive)) for (;;) {
     bool done = alive & (((cr == tr) & (cc == tc)) | (steps >= max_steps));
+    const unsigned pft0_prev = pft0, pft1_prev = pft1;
 #ifdef PF_WALK_PROBE
     __builtin_amdgcn_sched_barrier(0); const unsigned long long pr_r0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
     bool pr_stepped = false; unsigned long long pr_u0 = 0;
@@ -858,7 +867,8 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
       // lane), i.e. the eight next words at once -- q, the first word of the choice, and six more for random.choice's rejection
       // loop (_randbelow redraws while the k-bit value is >= n: every second draw for n = 1, every fourth for n = 3), which used to
       // cost the wave a full mix64 (~25 instructions, eight quarter-rate multiplies) per extra draw of its unluckiest ant.
-      const uint64_t Wk = g.peek64(1 + (uint64_t)k);
+      uint64_t Wk = 0;
+      if (!AHEAD) Wk = g.peek64(1 + (uint64_t)k);
 #ifdef PF_WALK_PROBE
       __builtin_amdgcn_sched_barrier(0); const unsigned long long pr_ta = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
       pr_head += pr_ta - pr_r0; pr_stepped = true; pr_act += 1;   // (per-lane copies: lane 0 reports, so the in-step stamps cover the rounds in which group 0 stepped)
@@ -867,12 +877,24 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
         // unconditional loads (a move that leaves the map reads cell 0 and is rejected by `inb` below): a branch around them costs
         // a scalar round trip on the mask, and loads under a branch keep the compiler from counting them
         const unsigned widx_c = inb ? widx : 0u, nidx_c = inb ? nidx : 0u;
-        vw = tl.patch((int)widx_c, visit[widx_c]);
+        const unsigned vw_raw = visit[widx_c];
         // one divergent vector load less per step: tau and eta'[turn] in one
         const unsigned toff = __umul24(nidx_c, 24u) + ((unsigned)turn << 3);
         const pf_d2u te = *(const pf_d2u*)((const char*)p.tep + (size_t)toff);
+        if (AHEAD) {
+          const int r2 = nr + mdr, c2 = nc + mdc;
+          const bool in2 = ((unsigned)r2 < (unsigned)R) & ((unsigned)c2 < (unsigned)C);
+          const unsigned t2 = in2 ? __umul24((unsigned)r2, (unsigned)C) + (unsigned)c2 : nidx_c;
+          const unsigned w2 = in2 ? __umul24((unsigned)r2, (unsigned)WPR) + ((unsigned)c2 >> 4) : widx_c;
+          pft0 = *(const unsigned*)((const char*)p.tep + (size_t)__umul24(t2, 24u));
+          pft1 = visit[w2];
+          __builtin_amdgcn_sched_barrier(0);                        // (all of the step's loads are issued before anything waits for one of them)
+        }
+        vw = tl.patch((int)widx_c, vw_raw);
         tv = turn ? te.x : te.y; ev = turn ? te.y : te.x;
+        if (AHEAD) asm volatile("" :: "v"(pft0_prev), "v"(pft1_prev));   // (the previous step's touches: older than the loads just waited for)
       }
+      if (AHEAD) Wk = g.peek64(1 + (uint64_t)k);                    // (in the shadow of the loads just issued)
 #ifdef PF_WALK_PROBE
       { __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
@@ -889,7 +911,8 @@ __global__ __launch_bounds__(64) void k_maaco_walk8(MaacoArgs p) {
       unsigned cand = mall & O1;                                    // :165
       if (!cand) cand = mall & O2;                                  // :168-169
       if (!cand) cand = mall;                                       // :172-180
-      if (!cand) { rc = 1; done = true; }                           // :287-288
+      // (AHEAD: the dead end "uses" the pheromone record too, so that its load stays in front of the candidate test)
+      if (!cand) { rc = 1; done = true; if (AHEAD) asm volatile("" :: "v"(tv), "v"(ev)); }   // :287-288
       else {
         const int ncand = __builtin_popcount(cand);
         cand_tot += ncand;
@@ -2243,7 +2266,7 @@ struct pf_handle {
   int* d_best_row = nullptr; int best_row_cap = 0;   // the overall best ant's path row, [0] = length (pf_maaco_iterate / pf_maaco_best_path)
   char* d_mctl = nullptr;             // pf_maaco_iterate's own {work counter @0, DevCounters @16}: zeroed by k_maaco_best_take for the next walk
   bool mctl_clean = false;
-  unsigned* d_visit = nullptr; unsigned* d_visit_epoch = nullptr; int maaco_slots = 0;
+  unsigned* d_visit = nullptr; unsigned* d_visit_epoch = nullptr; int maaco_slots = 0; int maaco_cus = 256;
   unsigned long long* d_bits = nullptr; size_t bits_words = 0; int dep_cap = 0;
   uint8_t* d_flag = nullptr;          // chunk flags of d_bits: [(RC + 63) / 64][bits_words] bytes (MaacoArgs::flag)
   // MPA
@@ -2478,6 +2501,7 @@ static int g_settle = env_int("PF_SETTLE", -1);  // closed-set searches try the 
 static double g_doubt_log = 1.0 / 8589934592.0;   // 2^-33 relative margin on normalvariate's accept test (pf_set_option "mpa_doubt_log_e15" overrides, in 1e-15)
 static double g_doubt_round = 1e-7;                // absolute margin on the fraction fed to round()   ("mpa_doubt_round_e15")
 static int g_maaco_pack8_min = env_int("PF_MAACO_PACK8_MIN", 2048);   // ants per batch from which 8 ants share a wavefront
+static int g_maaco_ahead = env_int("PF_MAACO_TOUCH", -1);   // load-ahead form of k_maaco_walk8 (pf_set_option "maaco_load_ahead"): -1 by occupancy (at most one wavefront per SIMD), 0 never, 1 always
 static int g_maaco_groups = env_int("PF_MAACO_GROUPS", 8);   // ants per wavefront of k_maaco_walk8 (pf_set_option "maaco_ants_per_wave": 1..8)
 static int g_maaco_mark = env_int("PF_MAACO_MARK", 1);   // successful ants mark their deposits in the walk kernel (pf_set_option "maaco_mark_in_walk")
 static int g_tabu_epoch = -1;                      // test hook ("maaco_tabu_epoch"): >= 0 -> the next walk batch starts its tabu slots from this epoch (wrap coverage)
@@ -2874,6 +2898,7 @@ int pf_set_option(pf_handle* h, const char* name, int64_t value) {
   if (!name) return failmsg(h, "pf_set_option: bad arguments");
   if (!strcmp(name, "astar_step_cap")) { g_step_cap = value > 0 ? (long long)value : 0; return 0; }
   if (!strcmp(name, "maaco_pack8_min")) { g_maaco_pack8_min = (int)value; return 0; }
+  if (!strcmp(name, "maaco_load_ahead")) { g_maaco_ahead = value < 0 ? -1 : (value ? 1 : 0); return 0; }
   if (!strcmp(name, "maaco_ants_per_wave")) { g_maaco_groups = value < 1 ? 1 : (value > 8 ? 8 : (int)value); return 0; }
   if (!strcmp(name, "mpa_prune")) { g_mpa_prune = value != 0; return 0; }
 #ifdef PF_TWO_WAVE
@@ -2967,7 +2992,7 @@ int pf_maaco_setup(pf_handle* h, const pf_maaco_params* p) {
     const size_t vwords = (size_t)h->R * (size_t)((h->C + 15) >> 4);
     int vs = cus * 128;
     while ((size_t)vs * vwords * sizeof(unsigned) > (32ull << 30) && vs > cus * 32) vs /= 2;
-    h->maaco_slots = vs;
+    h->maaco_slots = vs; h->maaco_cus = cus;
     CK(hipMalloc(&h->d_visit, sizeof(unsigned) * (size_t)vs * vwords));
     CK(hipMemsetAsync(h->d_visit, 0, sizeof(unsigned) * (size_t)vs * vwords, h->stream));
     CK(hipMalloc(&h->d_visit_epoch, sizeof(unsigned) * vs));
@@ -3060,7 +3085,10 @@ static int maaco_enqueue_walk(pf_handle* h, int32_t iter, uint64_t seed, int32_t
   }
   if (pack8) hipLaunchKernelGGL(k_pack_tep, dim3((h->RC + 255) / 256), dim3(256), 0, h->stream, h->RC, a.tau, a.eta, h->d_tep);
   CK(hipEventRecord(h->ev0, h->stream));
-  if (pack8) hipLaunchKernelGGL(k_maaco_walk8, dim3(grid), dim3(64), 0, h->stream, a);
+  // (the load-ahead form when the batch leaves every SIMD at most one wavefront: see k_maaco_walk8)
+  const bool ahead = g_maaco_ahead < 0 ? grid <= h->maaco_cus * 4 : g_maaco_ahead != 0;
+  if (pack8 && ahead) hipLaunchKernelGGL(k_maaco_walk8<true>, dim3(grid), dim3(64), 0, h->stream, a);
+  else if (pack8) hipLaunchKernelGGL(k_maaco_walk8<false>, dim3(grid), dim3(64), 0, h->stream, a);
   else hipLaunchKernelGGL(k_maaco_walk, dim3(grid), dim3(64), 0, h->stream, a);
   CK(hipGetLastError());
   CK(hipEventRecord(h->ev1, h->stream));

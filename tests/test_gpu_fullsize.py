@@ -287,16 +287,17 @@ def test_maaco_one_pass_update_equals_three_kernel_form_and_numpy_at_512():
 MAACO_KW = dict(alpha=1.0, beta=7.0, rho=0.1, Q=2.5, a_turn_coef=1.0, wh_max=0.9, wh_min=0.2, k_h_adaptive=0.9, q0_initial=0.5)
 
 
-@pytest.mark.parametrize("G,N,seed,pack8_min,ants_per_wave", [(512, 16384, 0, None, 8), (1024, 8192, 0, None, 8), (1024, 8192, 3, 1, 8),
-                                                              (512, 16384, 4, 1 << 30, 8), (512, 5000, 6, 1, 1)])
-def test_maaco_full_bench_batches_vs_oracle(G, N, seed, pack8_min, ants_per_wave):
+@pytest.mark.parametrize("G,N,seed,pack8_min,ants_per_wave,ahead", [(512, 16384, 0, None, 8, -1), (1024, 8192, 0, None, 8, -1), (1024, 8192, 3, 1, 8, 0),
+                                                                    (512, 16384, 4, 1 << 30, 8, -1), (512, 5000, 6, 1, 1, -1), (512, 16384, 7, None, 8, 1)])
+def test_maaco_full_bench_batches_vs_oracle(G, N, seed, pack8_min, ants_per_wave, ahead):
     """The bench batches themselves (maaco512: 16 384 ants on G512; maaco1024 = BASELINE configs[4]'s per-GPU share: 8 192 ants on
     G1024), iterations 1-3 through the one-enqueue iteration entry (pf_maaco_iterate), against the oracle restatement of
     MAACO.py:278-332 -- EVERY ant of every iteration, cell for cell: the oracle walks the same (seed, iteration, ant) streams over the
     pheromone matrix downloaded before the iteration, so a wrong-but-legal selection (a tie set, a roulette index, a q0 branch)
     anywhere in 600-1 700 steps shows.  The pheromone after each update must equal the oracle's sequential update over all paths.
     pack8_min None = the library's own choice of kernel for the batch; 1 / 2^30 force the packed / one-ant-per-wave kernels;
-    ants_per_wave < 8 leaves groups of the packed kernel idle (5 000 ants, one group per wave, 4 096 waves: groups fetch a second ant)."""
+    ants_per_wave < 8 leaves groups of the packed kernel idle (5 000 ants, one group per wave, 4 096 waves: groups fetch a second ant);
+    ahead -1 / 0 / 1 = the packed kernel's load-ahead form by occupancy (on for 8 192 ants, off for 16 384) / never / always."""
     import pathfit
     from pathfit import env
     import pf_oracle as po
@@ -306,6 +307,7 @@ def test_maaco_full_bench_batches_vs_oracle(G, N, seed, pack8_min, ants_per_wave
     m = pathfit.MAACO(g, N, 100, C0_initial_pheromone=0.1, seed=seed, **MAACO_KW)
     if pack8_min is not None:
         m.engine.set_option("maaco_pack8_min", pack8_min)
+    m.engine.set_option("maaco_load_ahead", ahead)
     m.engine.set_option("maaco_ants_per_wave", ants_per_wave)     # (1: groups 1..7 of every wavefront stay idle; 5 000 ants on 4 096 waves: groups refetch inside the loop)
     try:
         P = po.MaacoParams(alpha=1.0, beta=7.0, rho=0.1, Q=2.5, a_turn=1.0, wh_max=0.9, wh_min=0.2, k_h=0.9, q0_initial=0.5, C0=0.1,
@@ -338,6 +340,7 @@ def test_maaco_full_bench_batches_vs_oracle(G, N, seed, pack8_min, ants_per_wave
     finally:
         m.engine.set_option("maaco_pack8_min", 2048)
         m.engine.set_option("maaco_ants_per_wave", 8)
+        m.engine.set_option("maaco_load_ahead", -1)
 
 
 def test_cfg3_mpa_sweeps_4096_512_vs_oracle():
