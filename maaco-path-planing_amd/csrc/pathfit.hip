@@ -1200,6 +1200,48 @@ PF_DEV double dep_word(double t, unsigned long long x, const double* dw) {
   }
   return t;
 }
+// The dense path in TWO instructions per ant.  An ant's bit, moved to one of the exponent bits of a double's high word (bits 20..30)
+// and masked there, IS a double -- 0.0 or 2^(2^k - 1023) for exponent bit k -- and with the deposit pre-scaled by the inverse power of
+// two (dws[j] = d_j 2^(1023 - 2^k), exact: the caller has checked d_j < 4), fma(dws[j], that double, t) adds exactly d_j or exactly
+// nothing: one rounding, of t + d_j, as the plain add.  Six shifted views of the word put every ant's bit on an exponent bit
+// (ant j on bit 20 + j % 11); per ant a v_and and the fma, where bit -> 0.0 / 1.0 took a v_bfe and a v_cvt_f64_u32.
+PF_DEV double dep_word_scaled(double t, unsigned long long x, const double* dw, const double* dws) {
+  if (__any((int)__builtin_popcountll(x) > PF_DEP_DENSE)) {
+    const unsigned lo = (unsigned)x, hi = (unsigned)(x >> 32);
+    unsigned v[6];
+    v[0] = lo << 20; v[1] = lo << 9;                                // ants 0..10, 11..21
+    v[2] = __builtin_amdgcn_alignbit(hi, lo, 2); v[3] = __builtin_amdgcn_alignbit(hi, lo, 13); v[4] = __builtin_amdgcn_alignbit(hi, lo, 24);   // 22..32, 33..43, 44..54
+    v[5] = hi >> 3;                                                 // 55..63
+    double d[8], e[8];                                              // values read one batch ahead (wave-uniform addresses: LDS broadcasts)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d[k] = dws[k];
+#pragma unroll
+    for (int j0 = 0; j0 < 64; j0 += 8) {
+      if (j0 + 8 < 64) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = dws[j0 + 8 + k];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int j = j0 + k;
+        t = __builtin_fma(d[k], __hiloint2double((int)(v[j / 11] & (1u << (20 + j % 11))), 0), t);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) d[k] = e[k];
+    }
+    return t;
+  }
+  while (x) {
+    const int j0 = __builtin_ctzll(x); x &= x - 1;
+    const bool h1 = x != 0; const int j1 = h1 ? __builtin_ctzll(x) : j0; x &= x - 1;
+    const bool h2 = x != 0; const int j2 = h2 ? __builtin_ctzll(x) : j0; x &= x - 1;
+    const bool h3 = x != 0; const int j3 = h3 ? __builtin_ctzll(x) : j0; x &= x - 1;
+    const double d0 = dw[j0], d1 = dw[j1], d2 = dw[j2], d3 = dw[j3];
+    t += d0; t += h1 ? d1 : 0.0; t += h2 ? d2 : 0.0; t += h3 ? d3 : 0.0;
+  }
+  return t;
+}
+#define PF_UPD_CHUNK 8192   /* ants per LDS stage of k_tau_update: their deposits and the pre-scaled ones (2 x 64 KB) */
 // Every word of the matrix is read here exactly once, so the kernel also leaves it zeroed for the next iteration (a
 // store per non-zero word) instead of the host clearing n/8 bytes per cell -- 512 MB at 16 384 ants on G512 -- every time.
 __global__ __launch_bounds__(1024) void k_tau_deposit(double* tau, const uint8_t* occ, int RC, unsigned long long* bits, int nwords,
@@ -1294,7 +1336,8 @@ __global__ __launch_bounds__(1024) void k_maaco_best_take(int n, const double* p
 __global__ __launch_bounds__(1024) void k_tau_update(double* tau, const uint8_t* occ, int RC, unsigned long long* bits, int nwords,
                                                     const double* dep, double keep, const double* state, double tmin_a, double tmax_a,
                                                     uint8_t* flag, int fstride) {
-  extern __shared__ __attribute__((aligned(16))) double sdep[];    // [PF_DEP_CHUNK]
+  extern __shared__ __attribute__((aligned(16))) double sdep[];    // [PF_UPD_CHUNK] deposits, then [PF_UPD_CHUNK] pre-scaled (dep_word_scaled)
+  double* sdeps = sdep + PF_UPD_CHUNK;
   if (state && state[8] != 0.0) return;                            // an ant overflowed: the iteration is redone, tau stays
   const double tmin = state ? state[6] : tmin_a, tmax = state ? state[7] : tmax_a;
   // a wavefront owns one 64-cell stretch (512-byte word loads); the 16 wavefronts of a block take stretches gridDim.x apart, so the
@@ -1309,11 +1352,15 @@ __global__ __launch_bounds__(1024) void k_tau_update(double* tau, const uint8_t*
   int probe_dense = 0, probe_chunks = 0;
 #endif
   uint8_t* frow = flag + (size_t)seg * fstride;
-  for (int c0 = 0; c0 < nwords; c0 += PF_DEP_CHUNK / 64) {
-    const int cw = nwords - c0 < PF_DEP_CHUNK / 64 ? nwords - c0 : PF_DEP_CHUNK / 64;
+  for (int c0 = 0; c0 < nwords; c0 += PF_UPD_CHUNK / 64) {
+    const int cw = nwords - c0 < PF_UPD_CHUNK / 64 ? nwords - c0 : PF_UPD_CHUNK / 64;
     __syncthreads();
-    for (int k = threadIdx.x; k < cw * 64; k += blockDim.x) sdep[k] = dep[c0 * 64 + k];
-    __syncthreads();
+    bool big = false;                                              // a deposit of 4 or more (or a NaN) would overflow its scaling by 2^1022
+    for (int k = threadIdx.x; k < cw * 64; k += blockDim.x) {
+      const double v = dep[c0 * 64 + k];
+      sdep[k] = v; sdeps[k] = __builtin_ldexp(v, 1023 - (1 << ((k & 63) % 11))); big |= !(v < 4.0);
+    }
+    const bool scaled = __syncthreads_or(big) == 0;                 // (block-uniform; Q / L is ~4e-3 with the reference's parameters)
     if (!seg_live) continue;
     for (int k0 = 0; k0 < cw; k0 += 64) {
       // which of the next 64 words have anything in this stretch: one flag byte per lane -> a wave-uniform mask, walked in word
@@ -1350,7 +1397,7 @@ __global__ __launch_bounds__(1024) void k_tau_update(double* tau, const uint8_t*
           probe_chunks += 1; probe_dense += __any((int)__builtin_popcountll(x) > PF_DEP_DENSE) ? 1 : 0;
 #endif
 #if PF_TAU_PROBE != 1
-          t = dep_word(t, x, sdep + (idx[u] - c0) * 64);
+          t = scaled ? dep_word_scaled(t, x, sdep + (idx[u] - c0) * 64, sdeps + (idx[u] - c0) * 64) : dep_word(t, x, sdep + (idx[u] - c0) * 64);
 #else
           t += x == 12345ull ? 1.0 : 0.0;
 #endif
@@ -2999,7 +3046,7 @@ int pf_maaco_setup(pf_handle* h, const pf_maaco_params* p) {
     CK(hipMemsetAsync(h->d_visit_epoch, 0, sizeof(unsigned) * vs, h->stream));
     CK(hipStreamSynchronize(h->stream));
   }
-  CK(hipFuncSetAttribute((const void*)k_tau_update, hipFuncAttributeMaxDynamicSharedMemorySize, PF_DEP_CHUNK * (int)sizeof(double)));
+  CK(hipFuncSetAttribute((const void*)k_tau_update, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PF_UPD_CHUNK * (int)sizeof(double)));
   h->maaco_ready = true;
   if (h->d_best_row) CK(hipMemsetAsync(h->d_best_row, 0, sizeof(int), h->stream));   // a new colony has no best path yet
   return maaco_refresh_taua(h);
@@ -3137,7 +3184,7 @@ int pf_maaco_iterate(pf_handle* h, int32_t iter, uint64_t seed, int32_t ant0, in
                      (const int*)d_cells, (const int*)d_len, path_cap, h->d_best_row);
   CK(hipEventRecord(h->ev2, h->stream));
   const int words = (n + 63) / 64;
-  hipLaunchKernelGGL(k_tau_update, dim3((h->RC + 1023) / 1024), dim3(1024), PF_DEP_CHUNK * sizeof(double), h->stream, h->d_tau, h->d_occ,
+  hipLaunchKernelGGL(k_tau_update, dim3((h->RC + 1023) / 1024), dim3(1024), 2 * PF_UPD_CHUNK * sizeof(double), h->stream, h->d_tau, h->d_occ,
                      h->RC, h->d_bits, words, h->d_dep, 1.0 - h->mp.rho, (const double*)h->d_mstate, 0.0, 0.0, h->d_flag, (int)h->bits_words);
   CK(hipGetLastError());
   // the host needs the 13 doubles, not the pheromone: it waits for the take-over test only, the update pass runs on behind the
@@ -3215,7 +3262,7 @@ int pf_maaco_update(pf_handle* h, int32_t n, int32_t path_cap, const int32_t* d_
   const double tmax = (1.0 / (1.0 - h->mp.rho)) * (1.0 / bl);       // :317
   int mx = h->C > h->R ? h->C : h->R; if (mx < 1) mx = 1;
   const double tmin = tmax / (2.0 * mx);                            // :323
-  hipLaunchKernelGGL(k_tau_update, dim3((h->RC + 1023) / 1024), dim3(1024), PF_DEP_CHUNK * sizeof(double), h->stream, h->d_tau, h->d_occ,
+  hipLaunchKernelGGL(k_tau_update, dim3((h->RC + 1023) / 1024), dim3(1024), 2 * PF_UPD_CHUNK * sizeof(double), h->stream, h->d_tau, h->d_occ,
                      h->RC, h->d_bits, h->dep_words, h->d_dep, 1.0 - h->mp.rho, (const double*)nullptr, tmin, tmax, h->d_flag, (int)h->bits_words);
   CK(hipGetLastError());
   if (h->dep_words) h->bits_clean = true;

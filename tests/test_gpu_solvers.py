@@ -116,6 +116,25 @@ def test_maaco_solve_matches_oracle_loop(beta):
     assert np.array_equal(m.pheromone_matrix, ref["tau"])
 
 
+@pytest.mark.parametrize("Q", [2.5, 110.0, 4000.0, 1e-12])
+def test_maaco_dense_deposit_paths_any_deposit_size(Q):
+    """The pheromone pass adds the deposits of a cell's ants in ant order; where more than a dozen of a 64-ant word visit a cell it
+    steps through all 64 with the ant's bit turned into a double -- by default as 0.0 / 2^(2^k - 1023) against deposits pre-scaled by
+    the inverse power of two (exact for deposits below 4), else as 0.0 / 1.0.  400 ants on the 20 x 20 map make every word around the
+    start dense; Q = 2.5 takes the scaled form, Q = 110 puts deposits on both sides of the limit (the shortest possible walk is 26.9
+    long: Q / L reaches 4.09; a block whose chunk holds one deposit of 4 or more falls back as a whole), Q = 4000 takes the 0.0 / 1.0
+    form, Q = 1e-12 scales tiny deposits up by 2^1022.  Pheromone, path and curve must equal the oracle loop bit for bit."""
+    import pathfit, pf_oracle as po, pf_loops
+    g, s, t = gio.grid("fig7")
+    kw = dict(alpha=1.0, beta=7.0, rho=0.1, Q=Q, a_turn_coef=1.0, wh_max=0.9, wh_min=0.2, k_h_adaptive=0.9, q0_initial=0.5)
+    m = pathfit.MAACO(g, 400, 3, C0_initial_pheromone=0.1, seed=11, **kw)
+    path, length, turns = m.solve_path_planning()
+    ref = pf_loops.maaco_solve(po.Oracle(g), s, t, 400, 3, C0=0.1, seed=11, **kw)
+    assert [r * 20 + c for r, c in path] == list(ref["path"]) and length == ref["length"] and turns == ref["turns"]
+    assert m.convergence_curve_data == ref["curve"]
+    assert np.array_equal(m.pheromone_matrix, ref["tau"])
+
+
 @pytest.mark.parametrize("n_ants", [50, 3000])
 def test_maaco_path_rows_too_short_redo_leaves_pheromone_untouched(n_ants):
     """The overflow-redo branch of the one-enqueue iteration (pf_maaco_iterate): with path rows of 8 cells every iteration's first
