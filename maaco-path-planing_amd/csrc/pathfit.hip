@@ -1162,7 +1162,7 @@ __global__ __launch_bounds__(64) void k_visit_bits(int n, int path_cap, const in
 #define PF_TAU_FLY 4        // chunks of a stretch in flight while the previous PF_TAU_FLY are summed (k_tau_update)
 #endif
 #ifndef PF_DEP_DENSE
-#define PF_DEP_DENSE 12
+#define PF_DEP_DENSE 8    /* (12 before the two-instruction dense form; 3 / 5 / 8 / 12 / 18 -> maaco512 8.83 / 8.92 / 8.93 / 8.87 / 8.69 M evals/s) */
 #endif
 PF_DEV double dep_word(double t, unsigned long long x, const double* dw) {
   if (__any((int)__builtin_popcountll(x) > PF_DEP_DENSE)) {
