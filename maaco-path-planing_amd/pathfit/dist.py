@@ -509,25 +509,37 @@ class ShardedMPA:
         self.d_fit_loc = e.buf(max(n, 1), np.float64)
         self.d_gidx, self.d_slot = e.buf(max(n, 1), np.int32), e.buf(max(n, 1), np.int32)
         self.d_hdr = e.buf(8, np.float64)
+        self._fresh = False        # the global list is sorted on the population as it stands (set by _resort, cleared by a sweep)
+        self._head = None          # ... and its head (global id, fitness) has been read
 
     @property
     def gorder(self):
         return self.d_gorder.download()
 
     def _resort(self):
+        """The reference sorts at the end of an iteration (MPA.py:412) and again at the start of the next (:333) -- a stable sort of
+        a list that is already sorted on the same keys, i.e. nothing: the second one (gather, all_gather, three kernels, a 16-byte
+        read and its host round trip) is skipped while no sweep has touched the population since."""
+        if self._fresh:
+            return
         m, c, e = self.local, self.comm, self.local.engine
         n = self.counts[c.rank]
         e.gather_col(n, m.d_stats, 5, 4, self.d_fit_loc)
         c.all_gather(self.d_fit_loc, 0, self.d_fit_all, self.counts)  # 8 B per predator
         e.sort_order_by_key(self.N, self.d_fit_all, 1, 0, self.d_gorder)
+        self._fresh, self._head = True, None
 
     def _first(self):
-        """global id at the head of the list + its fitness (one 16-byte read)."""
+        """global id at the head of the list + its fitness (one 16-byte read per sort)."""
+        if self._head is not None:
+            return self._head
         e = self.local.engine
         if hasattr(e, "sorted_head"):
-            return e.sorted_head(self.d_gorder, self.d_fit_all)
-        gid = int(self.d_gorder.read(0, 1)[0])                       # (CPU fakes of the gloo tests)
-        return gid, float(self.d_fit_all.read(gid, 1)[0])
+            self._head = e.sorted_head(self.d_gorder, self.d_fit_all)
+        else:
+            gid = int(self.d_gorder.read(0, 1)[0])                   # (CPU fakes of the gloo tests)
+            self._head = (gid, float(self.d_fit_all.read(gid, 1)[0]))
+        return self._head
 
     def step(self, it):
         m, c, e = self.local, self.comm, self.local.engine
@@ -549,6 +561,7 @@ class ShardedMPA:
         phase = 1 if it <= m.num_iterations / 3 else (2 if it <= 2 * m.num_iterations / 3 else 3)
         e.mpa_iter(phase, CF, it, m.seed, n, cap, m.d_cells, m.d_len, m.d_stats, self.d_gidx, self.d_slot, el_c.ptr, -1, el_s.ptr,
                    m.d_cand_cells, m.d_cand_len, m.d_cand_stats, m.d_c2_cells, m.d_c2_len, m.d_c2_stats, m.d_status)
+        self._fresh, self._head = False, None                        # the sweep has rewritten the population
         m._check_overflow()
         self._resort()                                                # :412
         return self._first()[1]

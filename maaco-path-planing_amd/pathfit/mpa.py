@@ -125,8 +125,13 @@ class MPA:
         return self.d_cells.read(slot * self.path_cap, L)
 
     def _sort(self):
-        """list.sort(key=fitness) is stable (MPA.py:321,:333,:412): device radix sort of the list order."""
+        """list.sort(key=fitness) is stable (MPA.py:321,:333,:412): device sort of the list order.  The sort at the start of an
+        iteration (:333) re-sorts the list the end of the previous one (:412) left sorted on the same keys -- nothing -- and is
+        skipped while no sweep has touched the population since."""
+        if getattr(self, "_sorted", False):
+            return
         self.engine.sort_order_by_key(self.n_local, self.d_stats, 5, 4, self.d_order)
+        self._sorted = True
 
     def _best_row(self):
         """(storage slot, stats[5]) of population[0] -- two small reads."""
@@ -164,6 +169,7 @@ class MPA:
                          self.d_cells, self.d_len, self.d_stats)            # :381-384
             e.mpa_fads(CF, it, self.seed, N, cap, self.d_gidx, self.d_order, self.d_cells, self.d_len, self.d_stats, self.d_status)   # :387-410
             self._check_overflow()
+        self._sorted = False                                             # the sweep has rewritten the population
         self._sort()                                                     # :412
         slot, s = self._best_row()
         # :415-437 best-so-far with the 4-level tie-break
