@@ -559,9 +559,9 @@ class ShardedMPA:
         ratio = it / m.num_iterations
         CF = 0.0 if ratio >= 1.0 else ((1.0 - ratio) ** (2.0 * ratio) if ratio > 0 else 1.0)
         phase = 1 if it <= m.num_iterations / 3 else (2 if it <= 2 * m.num_iterations / 3 else 3)
+        self._fresh, self._head = False, None                        # the sweep rewrites the population
         e.mpa_iter(phase, CF, it, m.seed, n, cap, m.d_cells, m.d_len, m.d_stats, self.d_gidx, self.d_slot, el_c.ptr, -1, el_s.ptr,
                    m.d_cand_cells, m.d_cand_len, m.d_cand_stats, m.d_c2_cells, m.d_c2_len, m.d_c2_stats, m.d_status)
-        self._fresh, self._head = False, None                        # the sweep has rewritten the population
         m._check_overflow()
         self._resort()                                                # :412
         return self._first()[1]

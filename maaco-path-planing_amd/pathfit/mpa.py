@@ -96,6 +96,7 @@ class MPA:
         self.d_cand_stats, self.d_status = e.buf((N, 5), np.float64), e.buf(N, np.int32)
         self.d_c2_cells, self.d_c2_len, self.d_c2_stats = e.buf((N, cap), np.int32), e.buf(N, np.int32), e.buf((N, 5), np.float64)
         self.d_order = e.put(np.arange(N, dtype=np.int32))               # the list: sorted position -> storage slot
+        self._sorted = False                                             # (see _sort)
         self.d_gidx = e.put(np.arange(N, dtype=np.int32))                # single GPU: every predator is local
         self._el_cells, self._el_len, self._el_stats = e.mpa_elite_bufs()
 
@@ -155,6 +156,7 @@ class MPA:
         CF = 0.0 if ratio >= 1.0 else ((1.0 - ratio) ** (2.0 * ratio) if ratio > 0 else 1.0)   # :336
         phase = 1 if it <= self.num_iterations / 3 else (2 if it <= 2 * self.num_iterations / 3 else 3)
         el_c, el_s = self._el_cells.ptr, self._el_stats.ptr
+        self._sorted = False                                             # the sweep rewrites the population
         if self.fused:
             e.mpa_iter(phase, CF, it, self.seed, N, cap, self.d_cells, self.d_len, self.d_stats, self.d_gidx, self.d_order,
                        el_c, -1, el_s, self.d_cand_cells, self.d_cand_len, self.d_cand_stats,
@@ -169,7 +171,6 @@ class MPA:
                          self.d_cells, self.d_len, self.d_stats)            # :381-384
             e.mpa_fads(CF, it, self.seed, N, cap, self.d_gidx, self.d_order, self.d_cells, self.d_len, self.d_stats, self.d_status)   # :387-410
             self._check_overflow()
-        self._sorted = False                                             # the sweep has rewritten the population
         self._sort()                                                     # :412
         slot, s = self._best_row()
         # :415-437 best-so-far with the 4-level tie-break
